@@ -1,0 +1,116 @@
+/*
+ * hnsw_oracle.h -- CPU parity oracle for the redis_hnsw hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C restatement of the reference's
+ * src/hnsw/core.rs + src/hnsw/metrics.rs (zhao-lang/redis_hnsw v0.2.1).  Only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it,
+ * and there only as the checker / the timed CPU baseline.  The product
+ * (redis_hnsw_amd/, libhnsw_mi355x.so) never links, imports or calls it.
+ *
+ * Pinning: the reference is Rust and cannot be compiled in this image (no
+ * rustc/cargo), so oracle/_ref does not exist.  The oracle is pinned against
+ * every known-answer test the reference holds for this path
+ * (src/hnsw/metrics_tests.rs:3-33, src/hnsw/core_tests.rs:12-53); see
+ * tests/test_oracle_kat.py.
+ *
+ * Two deliberate, documented restatement choices (neither is observable on
+ * tie-free data):
+ *   1. Ids are dense u32 in insertion order; names stay on the caller's side.
+ *   2. Rust's BinaryHeap leaves the order of EQUAL similarities unspecified
+ *      (core_tests.rs:50-53 does not assert it).  The oracle fixes a total
+ *      order: larger sim first, then smaller id.  Every comparison the
+ *      reference makes on `sim` is made on that (sim, id) key here.
+ *   3. The level RNG is entropy seeded in the reference (core.rs:344), so
+ *      levels are an explicit input (or drawn from a seeded generator using
+ *      the same formula floor(-ln U * 1/ln m), core.rs:338,601-605).
+ */
+#ifndef HNSW_ORACLE_H
+#define HNSW_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hnsw_oracle hnsw_oracle;
+
+/* per-call work counters */
+typedef struct {
+    uint64_t n_dist;   /* metric evaluations (core.rs:550,621,652,711)       */
+    uint64_t n_ids;    /* neighbour ids scanned (core.rs:646,702)             */
+    uint64_t n_expand; /* candidates expanded (core.rs:631 pops that expand)  */
+} hnsw_oracle_counters;
+
+/* ---- metric kernels: src/hnsw/metrics.rs -------------------------------- */
+/* metrics.rs:79-84 : sequential left fold of (x-y)*(x-y), no FMA, negated   */
+float hnsw_oracle_sim_scalar(const float *a, const float *b, size_t n);
+/* metrics.rs:48-77 : 4x8-lane FMA accumulators, AVX2 hsum order, negated.
+ * Uses real AVX2+FMA when the host has them, else a lane-exact fmaf
+ * emulation (bit-identical).  n must be a multiple of 32.                   */
+float hnsw_oracle_sim_avx(const float *a, const float *b, size_t n);
+/* the lane-exact emulation on its own (for testing the two agree)          */
+float hnsw_oracle_sim_avx_emulated(const float *a, const float *b, size_t n);
+/* metrics.rs:14-23 : dispatch; AVX order iff n % 32 == 0                    */
+float hnsw_oracle_euclidean(const float *a, const float *b, size_t n);
+
+/* ---- index: src/hnsw/core.rs -------------------------------------------- */
+/* core.rs:322-347. seed feeds the oracle's own level generator (used only
+ * when add() is called with level < 0).                                     */
+hnsw_oracle *hnsw_oracle_new(uint32_t dim, uint32_t m, uint32_t ef_construction,
+                             uint64_t seed);
+void hnsw_oracle_free(hnsw_oracle *o);
+
+/* core.rs:383-412 + 489-599.  level < 0 => draw (core.rs:601-605).  The first
+ * node ignores `level` (core.rs:393-405: no draw, level 0).  touched (may be
+ * NULL) receives the ids update_fn would be called for (core.rs:580-584), in
+ * unspecified order.  Returns the new node id (>= 0) or -1 on error.        */
+int64_t hnsw_oracle_add(hnsw_oracle *o, const float *v, int32_t level,
+                        uint32_t *touched, uint32_t touched_cap,
+                        uint32_t *n_touched);
+
+/* core.rs:477-486 + 865-892 : ef = ef_construction.  Returns the number of
+ * results written (min(k, ef, reachable)), nearest first.  ctrs may be NULL. */
+uint32_t hnsw_oracle_search(const hnsw_oracle *o, const float *q, uint32_t k,
+                            uint32_t *ids, float *sims,
+                            hnsw_oracle_counters *ctrs);
+
+/* B independent searches on `threads` pthreads (baseline B of BASELINE.md);
+ * ids/sims are [B][k], n_out is [B]; ctrs (may be NULL) is summed.          */
+void hnsw_oracle_search_batch(const hnsw_oracle *o, const float *Q, uint32_t B,
+                              uint32_t k, uint32_t *ids, float *sims,
+                              uint32_t *n_out, uint32_t threads,
+                              hnsw_oracle_counters *ctrs);
+
+/* ---- introspection / bulk transfer --------------------------------------- */
+uint32_t hnsw_oracle_node_count(const hnsw_oracle *o);
+uint32_t hnsw_oracle_max_layer(const hnsw_oracle *o);
+int64_t hnsw_oracle_enterpoint(const hnsw_oracle *o); /* -1 if none          */
+uint32_t hnsw_oracle_level(const hnsw_oracle *o, uint32_t id);
+uint32_t hnsw_oracle_degree(const hnsw_oracle *o, uint32_t id, uint32_t layer);
+/* copies min(cap, degree) ids in stored order (core.rs:646 iteration order) */
+uint32_t hnsw_oracle_neighbors(const hnsw_oracle *o, uint32_t id, uint32_t layer,
+                               uint32_t *out, uint32_t cap);
+const float *hnsw_oracle_vector(const hnsw_oracle *o, uint32_t id);
+void hnsw_oracle_insert_counters(const hnsw_oracle *o, hnsw_oracle_counters *c);
+
+/* per-layer CSR export: row_ptr has n+1 entries, col has row_ptr[n] entries */
+uint64_t hnsw_oracle_layer_nnz(const hnsw_oracle *o, uint32_t layer);
+void hnsw_oracle_export_layer(const hnsw_oracle *o, uint32_t layer,
+                              uint64_t *row_ptr, uint32_t *col);
+void hnsw_oracle_export_levels(const hnsw_oracle *o, uint32_t *levels);
+
+/* rebuild an oracle index from a frozen graph (mirror of make_index,
+ * src/lib.rs:252-315): vectors [n][dim], levels [n], per-layer CSR.          */
+hnsw_oracle *hnsw_oracle_import(uint32_t dim, uint32_t m, uint32_t ef_construction,
+                                uint32_t n, const float *vectors,
+                                const uint32_t *levels, int64_t enterpoint,
+                                uint32_t n_layers,
+                                const uint64_t *const *row_ptr,
+                                const uint32_t *const *col);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,117 @@
+"""Pins the CPU oracle against every known-answer test the reference holds for
+the hot path:
+  src/hnsw/metrics_tests.rs:3-33   (diff_is_zero, diff_is_512, diff_is_512_2_x512, diff_non_x32)
+  src/hnsw/core_tests.rs:12-53     (ctor, 100-point build, search [10;4] k=5)
+The vectors are reproduced from the test descriptions, not copied source.
+"""
+import numpy as np
+import pytest
+
+EPS = float(np.finfo(np.float32).eps)
+
+
+# ---- metrics_tests.rs -------------------------------------------------------
+def test_diff_is_zero(oracle_mod):  # metrics_tests.rs:3-9
+    a, b = np.ones(512, np.float32), np.ones(512, np.float32)
+    assert abs(oracle_mod.sim_avx(a, b) - 0.0) < EPS
+    assert abs(oracle_mod.sim_scalar(a, b) - 0.0) < EPS
+
+
+def test_diff_is_512(oracle_mod):  # metrics_tests.rs:11-17
+    a, b = np.zeros(512, np.float32), np.ones(512, np.float32)
+    assert abs(oracle_mod.sim_avx(a, b) - -512.0) < EPS
+    assert abs(oracle_mod.sim_scalar(a, b) - -512.0) < EPS
+
+
+def test_diff_is_512_2_x512(oracle_mod):  # metrics_tests.rs:19-25
+    a, b = np.zeros(512, np.float32), np.full(512, 512.0, np.float32)
+    assert abs(oracle_mod.sim_avx(a, b) - -134217728.0) < EPS
+    assert abs(oracle_mod.sim_scalar(a, b) - -134217728.0) < EPS
+
+
+def test_diff_non_x32(oracle_mod):  # metrics_tests.rs:27-33 (scalar only)
+    a, b = np.zeros(33, np.float32), np.ones(33, np.float32)
+    assert abs(oracle_mod.sim_scalar(a, b) - -33.0) < EPS
+    assert abs(oracle_mod.euclidean(a, b) - -33.0) < EPS  # dispatch falls to scalar, metrics.rs:18
+
+
+# ---- the two summation orders really are the reference's --------------------
+def _avx_order_numpy(a, b):
+    """metrics.rs:48-77 restated with numpy float32 ops (fma via float64 product,
+    exact for f32 inputs, then one rounding)."""
+    a = a.astype(np.float32); b = b.astype(np.float32)
+    e = np.zeros((4, 8), np.float32)
+    for i in range(0, a.size, 32):
+        for acc in range(4):
+            d = (a[i + 8 * acc:i + 8 * acc + 8] - b[i + 8 * acc:i + 8 * acc + 8]).astype(np.float32)
+            # fused multiply-add: exact product + addend, rounded once
+            e[acc] = (d.astype(np.float64) * d.astype(np.float64) + e[acc].astype(np.float64)).astype(np.float32)
+    v = ((e[0] + e[1]).astype(np.float32) + (e[2] + e[3]).astype(np.float32)).astype(np.float32)
+    s = (v[:4] + v[4:]).astype(np.float32)
+    return -np.float32(np.float32(s[0] + s[1]) + np.float32(s[2] + s[3]))
+
+
+@pytest.mark.parametrize("dim", [32, 64, 128, 768])
+def test_avx_order_bit_exact(oracle_mod, dim):
+    rng = np.random.default_rng(dim)
+    for _ in range(50):
+        a = rng.random(dim, dtype=np.float32)
+        b = rng.random(dim, dtype=np.float32)
+        hw = np.float32(oracle_mod.sim_avx(a, b))
+        em = np.float32(oracle_mod.sim_avx_emulated(a, b))
+        ref = _avx_order_numpy(a, b)
+        # float64 product+add then a single rounding equals fmaf except for
+        # double-rounding corner cases, which these inputs do not hit
+        assert hw.tobytes() == em.tobytes()
+        assert hw.tobytes() == np.float32(ref).tobytes()
+
+
+def test_scalar_order_bit_exact(oracle_mod):
+    rng = np.random.default_rng(5)
+    for dim in (1, 3, 4, 33, 100):
+        a = rng.random(dim, dtype=np.float32); b = rng.random(dim, dtype=np.float32)
+        acc = np.float32(0)
+        for x, y in zip(a, b):
+            d = np.float32(x - y)
+            acc = np.float32(acc + np.float32(d * d))
+        assert np.float32(oracle_mod.sim_scalar(a, b)).tobytes() == np.float32(-acc).tobytes()
+
+
+# ---- core_tests.rs ----------------------------------------------------------
+def _line_index(oracle_mod, seed):
+    """core_tests.rs:21-28: 100 nodes node{i} with data [i;4], Index::new(.., 4, 5, 16)."""
+    idx = oracle_mod.OracleIndex(4, m=5, ef_construction=16, seed=seed)
+    for i in range(100):
+        idx.add(np.full(4, float(i), np.float32))  # level drawn, like the reference
+    return idx
+
+
+def test_ctor(oracle_mod):  # core_tests.rs:12-19
+    idx = oracle_mod.OracleIndex(4, m=5, ef_construction=16)
+    assert idx.m == 5 and idx.ef_construction == 16
+    assert idx.node_count == 0 and idx.max_layer == 0 and idx.enterpoint == -1
+    ids, sims = idx.search(np.zeros(4, np.float32), 5)   # core.rs:481-483: empty -> Ok([])
+    assert len(ids) == 0
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_hnsw_test_search(oracle_mod, seed):  # core_tests.rs:21-53, for 40 level sequences
+    idx = _line_index(oracle_mod, seed)
+    assert idx.node_count == 100 and idx.enterpoint >= 0
+    ids, sims = idx.search(np.full(4, 10.0, np.float32), 5)
+    assert len(ids) == 5
+    assert ids[0] == 10                                   # res[0].name == "node10"
+    for got, want in zip(sims, [0.0, -4.0, -4.0, -16.0, -16.0]):
+        assert abs(float(got) - want) < EPS
+    # names of tied ranks are not asserted by the reference; as sets they must be {9,11},{8,12}
+    assert set(ids[1:3].tolist()) == {9, 11} and set(ids[3:5].tolist()) == {8, 12}
+
+
+def test_first_node_level_zero_and_no_draw(oracle_mod):  # core.rs:393-405
+    idx = oracle_mod.OracleIndex(4, m=5, ef_construction=16)
+    idx.add(np.zeros(4, np.float32), level=3)
+    assert idx.level(0) == 0 and idx.max_layer == 0 and idx.enterpoint == 0
+    idx.add(np.ones(4, np.float32), level=2)
+    assert idx.max_layer == 2 and idx.enterpoint == 1     # core.rs:587-593
+    assert idx.neighbors(1, 0).tolist() == [0] and idx.neighbors(0, 0).tolist() == [1]
+    assert idx.neighbors(1, 1).tolist() == []
