@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py -- HNSW.SEARCH throughput of the MI355X engine on BASELINE.json's
+headline configuration (C2: 1M x 128 f32, M=16, ef=200, k=10, 1024-query batches).
+
+A step = one pass of the hot path (hnsw_search_batch_device) over one batch of
+queries already resident in HBM.  One process per GPU; the index is replicated,
+every rank serves its own batch (weak scaling) and the [B,k] results are
+all-gathered over RCCL.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def draw_levels(n, m, seed=7):
+    """floor(-ln U / ln M), numpy default_rng(seed); node 0 at level 0 (core.rs:393-405, 601-605)."""
+    u = np.maximum(np.random.default_rng(seed).random(n), np.finfo(np.float64).tiny)
+    lv = np.floor(-np.log(u) / np.log(float(m))).astype(np.int64)
+    lv[0] = 0
+    return np.minimum(lv, 31).astype(np.int32)
+
+
+def brute_force_gt(torch, V_dev, Q_dev, k):
+    """exact top-k by squared L2 on the GPU (fp32 matmul, chunked)"""
+    vn = (V_dev * V_dev).sum(1)
+    out = []
+    for i in range(0, Q_dev.shape[0], 256):
+        q = Q_dev[i:i + 256]
+        d = vn[None, :] - 2.0 * (q @ V_dev.T)
+        out.append(d.topk(k, dim=1, largest=False).indices)
+    return torch.cat(out).cpu().numpy()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nodes", type=int, default=1_000_000)
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--m", type=int, default=16)
+    ap.add_argument("--ef", type=int, default=200)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--build", default="fast", choices=["fast", "exact"])
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from redis_hnsw_amd import Index
+    N, dim, M, ef, k, B = args.nodes, args.dim, args.m, args.ef, args.k, args.batch
+    t0 = time.time()
+    V = np.random.default_rng(1).random((N, dim), dtype=np.float32)
+    n_qbatches = 8
+    Qall = np.random.default_rng(2).random((n_qbatches * B * world, dim), dtype=np.float32)
+    levels = draw_levels(N, M, 7)
+
+    # ---- build (HNSW.NODE.ADD on the GPU), replicate ---------------------------------
+    index = Index("bench", dim, M, ef, device=local_rank)
+    graph = None
+    t_build = None
+    if rank == 0:
+        tb = time.time()
+        index.add_batch(V, levels=levels, mode=args.build)
+        torch.cuda.synchronize()
+        t_build = time.time() - tb
+        if world > 1 or not args.no_cpu_baseline:
+            graph = index.export_graph(with_vectors=False)
+    if world > 1:
+        # one-time index distribution: rank 0's graph to every replica over RCCL
+        meta = [None]
+        if rank == 0:
+            meta[0] = dict(enterpoint=graph["enterpoint"], max_layer=graph["max_layer"],
+                           nnz=[int(len(c)) for c in graph["col"]])
+        dist.broadcast_object_list(meta, src=0)
+        meta = meta[0]
+        L = meta["max_layer"] + 1
+        dev = torch.device("cuda", local_rank)
+        lv_t = torch.from_numpy(graph["levels"].astype(np.int64)).to(dev) if rank == 0 else torch.empty(N, dtype=torch.int64, device=dev)
+        dist.broadcast(lv_t, src=0)
+        rps, cols = [], []
+        for l in range(L):
+            rp_t = torch.from_numpy(graph["row_ptr"][l].astype(np.int64)).to(dev) if rank == 0 else torch.empty(N + 1, dtype=torch.int64, device=dev)
+            cl_t = torch.from_numpy(graph["col"][l].astype(np.int64)).to(dev) if rank == 0 else torch.empty(meta["nnz"][l], dtype=torch.int64, device=dev)
+            dist.broadcast(rp_t, src=0)
+            dist.broadcast(cl_t, src=0)
+            rps.append(rp_t.cpu().numpy().astype(np.uint64))
+            cols.append(cl_t.cpu().numpy().astype(np.uint32))
+        if rank != 0:
+            g = dict(vectors=V, levels=lv_t.cpu().numpy().astype(np.uint32), enterpoint=meta["enterpoint"],
+                     max_layer=meta["max_layer"], row_ptr=rps, col=cols)
+            index.import_graph(g)
+        dist.barrier()
+
+    # ---- device-resident inputs/outputs ---------------------------------------------
+    dev = torch.device("cuda", local_rank)
+    myQ = torch.from_numpy(Qall[rank * n_qbatches * B:(rank + 1) * n_qbatches * B]).to(dev)
+    d_ids = torch.empty((B, k), dtype=torch.int32, device=dev)
+    d_sims = torch.empty((B, k), dtype=torch.float32, device=dev)
+    d_n = torch.empty((B,), dtype=torch.int32, device=dev)
+    g_ids = torch.empty((world * B, k), dtype=torch.int32, device=dev) if world > 1 else None
+    g_sims = torch.empty((world * B, k), dtype=torch.float32, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream()
+
+    def step(i):
+        q = myQ[(i % n_qbatches) * B:(i % n_qbatches + 1) * B]
+        index.search_batch_device(q.data_ptr(), B, k, d_ids.data_ptr(), d_sims.data_ptr(), d_n.data_ptr(),
+                                  stream.cuda_stream)
+        if world > 1:   # the path's one real exchange: gather every shard's top-k
+            dist.all_gather_into_tensor(g_ids, d_ids)
+            dist.all_gather_into_tensor(g_sims, d_sims)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    index.reset_counters()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t_start = time.perf_counter()
+    ev0.record(stream)
+    for i in range(args.steps):
+        step(args.warmup + i)
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t_wall = time.perf_counter() - t_start
+    if world > 1:
+        tt = torch.tensor([t_wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_wall = float(tt.item())
+    stream_ms = ev0.elapsed_time(ev1)
+    sc, _ = index.counters()
+
+    # ---- recall@k against brute force (rank 0's batches) ------------------------------
+    recall = None
+    if rank == 0:
+        V_dev = torch.from_numpy(V).to(dev)
+        nb = min(2, n_qbatches)
+        hits = tot = 0
+        for b in range(nb):
+            q = myQ[b * B:(b + 1) * B]
+            index.search_batch_device(q.data_ptr(), B, k, d_ids.data_ptr(), d_sims.data_ptr(), d_n.data_ptr(),
+                                      stream.cuda_stream)
+            torch.cuda.synchronize()
+            got = d_ids.cpu().numpy().astype(np.int64)
+            gt = brute_force_gt(torch, V_dev, q, k)
+            for a, bb in zip(got, gt):
+                hits += len(set(a.tolist()) & set(bb.tolist()))
+                tot += k
+        recall = hits / tot
+        del V_dev
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (k_search) -------------------------------------
+    launches = args.steps
+    bytes_per_launch = (sc.n_dist * 4 * dim + sc.n_ids * 4) / launches + B * (4 * dim + 8 * k)
+    kernel_ms = stream_ms / launches     # HIP events on the launch stream around the timed region
+    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                    kernel="k_search", kernel_ms=round(kernel_ms, 4),
+                    algorithmic_bytes_per_launch=int(bytes_per_launch),
+                    n_dist_per_query=round(sc.n_dist / (launches * B), 1),
+                    n_ids_per_query=round(sc.n_ids / (launches * B), 1))
+
+    # ---- CPU baseline: the oracle (C restatement of the Rust path), bounded sample -------
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import oracle
+        graph["vectors"] = V
+        o = oracle.OracleIndex.from_graph(dim, M, ef, graph)
+        Qs = Qall[:B]
+        o.search_batch(Qs[:64], k, threads=1)              # warm-up
+        done = 0
+        tc = time.perf_counter()
+        chunk = 128
+        while True:
+            lo = done % B
+            o.search_batch(Qs[lo:lo + chunk], k, threads=1)
+            done += chunk
+            if time.perf_counter() - tc > args.cpu_seconds:
+                break
+        t1 = time.perf_counter() - tc
+        cores = os.cpu_count() or 1
+        tc = time.perf_counter()
+        reps = 0
+        while True:
+            o.search_batch(Qs, k, threads=cores)
+            reps += 1
+            if time.perf_counter() - tc > args.cpu_seconds / 2:
+                break
+        tN = time.perf_counter() - tc
+        cpu = dict(value=round(done / t1, 1), unit="queries/s", cores=1, kind="port",
+                   sample="%d queries of the same 1024-query batch on the same graph, 1 thread, %.1f s" % (done, t1),
+                   all_cores=dict(value=round(reps * B / tN, 1), cores=cores))
+
+    qps = world * B * args.steps / t_wall
+    out = {
+        "metric": "HNSW.SEARCH QPS + recall@10, 1M x 128 f32, ef=200",
+        "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * t_wall / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C2: %d nodes x dim %d, M=%d, ef=%d, k=%d, batch=%d queries/GPU, uniform[0,1) f32, replicated index"
+                               % (N, dim, M, ef, k, B),
+                   "nodes": N, "dim": dim, "M": M, "ef": ef, "k": k, "batch": B, "build": args.build,
+                   "parallelism": "replica x%d, query batch sharded" % world},
+        "recall_at_10": None if recall is None else round(recall, 4),
+        "build_seconds": None if t_build is None else round(t_build, 2),
+        "setup_seconds": round(time.time() - t0, 1),
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

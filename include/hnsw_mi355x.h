@@ -1,0 +1,143 @@
+/*
+ * hnsw_mi355x.h -- C ABI of the MI355X-native HNSW engine (libhnsw_mi355x.so).
+ *
+ * This is the drop-in boundary for the hot path of zhao-lang/redis_hnsw: the
+ * Rust module keeps its command layer (src/lib.rs) and its name <-> node map,
+ * and binds these entry points with `extern "C"` where it calls
+ * Index<f32,f32> today (INTEGRATION.md shows the shim).  Citations are to the
+ * reference tree.
+ *
+ * Conventions
+ *  - Nodes are dense u32 ids in insertion order; names never cross the ABI.
+ *  - Similarity is the reference's: sim = -(squared L2), larger is closer
+ *    (src/hnsw/metrics.rs:75,80), bit-identical summation order.
+ *  - All pointers are caller owned.  "host" entry points take host memory and
+ *    return when the result is in the output buffers.  "_device" entry points
+ *    take device (HBM) pointers + a hipStream_t and only enqueue work.
+ *  - One caller at a time per handle (the reference runs on the Redis command
+ *    thread and takes try_write/try_read, src/lib.rs:349,474).
+ *  - Every function returns an hnsw_status; hnsw_last_error() gives the text.
+ *  - There is no CPU fallback: without a usable gfx950 device hnsw_create
+ *    fails with HNSW_ERR_DEVICE.
+ */
+#ifndef HNSW_MI355X_H
+#define HNSW_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hnsw_index hnsw_index;
+
+typedef enum {
+    HNSW_OK = 0,
+    HNSW_ERR_DIM_MISMATCH = 1, /* "data dimension: {} does not match Index" core.rs:390,479 */
+    HNSW_ERR_DUPLICATE = 2,    /* "Node: {:?} already exists" core.rs:408 (raised by the host mirror) */
+    HNSW_ERR_NOT_FOUND = 3,    /* "Node: {:?} does not exist" core.rs:421 */
+    HNSW_ERR_DEVICE = 4,       /* HIP failure / no gfx950 device */
+    HNSW_ERR_INVALID = 5,      /* bad argument or unsupported parameter */
+    HNSW_ERR_CAPACITY = 6      /* internal table overflow (reported, never silent) */
+} hnsw_status;
+
+/* work counters, summed over the calls since the last reset    */
+typedef struct {
+    uint64_t n_dist;   /* vectors fetched + metric evaluations               */
+    uint64_t n_ids;    /* neighbour ids scanned                              */
+    uint64_t n_expand; /* candidates expanded                                */
+    uint64_t n_spill;  /* queries whose visited set spilled from LDS to HBM  */
+} hnsw_counters;
+
+typedef struct {
+    uint32_t dim, m, m_max, m_max0, ef_construction;
+    uint32_t node_count, max_layer;
+    int64_t enterpoint;        /* -1 when the index is empty                 */
+    uint32_t stride0, stride_upper; /* words per adjacency row (slot 0 = count) */
+    uint32_t max_degree0, max_degree_upper;
+    uint64_t hbm_bytes;        /* device memory held by the handle           */
+} hnsw_info;
+
+/* Index::new (core.rs:322-347): m_max = m, m_max0 = 2m, level_mult = 1/ln m.
+ * seed feeds the engine's own level generator (used when level < 0 is passed
+ * to hnsw_add; the reference seeds from entropy, core.rs:344).  device is a
+ * HIP device ordinal.                                                        */
+hnsw_status hnsw_create(uint32_t dim, uint32_t m, uint32_t ef_construction,
+                        uint64_t seed, int device, hnsw_index **out);
+void hnsw_destroy(hnsw_index *h);
+const char *hnsw_last_error(const hnsw_index *h); /* valid until the next call on h */
+
+/* Index::add_node (core.rs:383-412 -> insert :489-599), executed on the GPU,
+ * exactly the reference's serial algorithm.  level < 0 draws
+ * floor(-ln U / ln m) (core.rs:601-605); the first node ignores it
+ * (core.rs:393-405).  touched (may be NULL) receives the ids the reference
+ * would pass to update_fn (core.rs:580-584), unordered.                      */
+hnsw_status hnsw_add(hnsw_index *h, const float *v, uint32_t dim, int32_t level,
+                     uint32_t *out_id, uint32_t *touched, uint32_t touched_cap,
+                     uint32_t *n_touched);
+
+/* Bulk build (BASELINE.json config 5).  mode 0 = exact: n sequential
+ * hnsw_add() calls without per-call host round trips for `touched`.
+ * mode 1 = fast: inserts are planned in data-parallel batches against a
+ * snapshot and committed together -- NOT link-for-link identical to the
+ * reference's serial order; judged by recall parity only.  levels may be NULL. */
+hnsw_status hnsw_add_batch(hnsw_index *h, const float *V, uint32_t n, uint32_t dim,
+                           const int32_t *levels, uint32_t mode);
+
+/* Index::search_knn (core.rs:477-486 -> :865-892); ef = ef_construction
+ * (core.rs:485).  Writes min(k, ef, reachable) results, nearest first; an empty
+ * index returns HNSW_OK with *n_out = 0 (core.rs:481-483).                   */
+hnsw_status hnsw_search(hnsw_index *h, const float *q, uint32_t dim, uint32_t k,
+                        uint32_t *ids, float *sims, uint32_t *n_out);
+
+/* B independent queries, Q row-major [B][dim]; ids/sims are [B][k] (rows are
+ * padded with id 0xFFFFFFFF / sim -inf past n_out[b]); n_out is [B].          */
+hnsw_status hnsw_search_batch(hnsw_index *h, const float *Q, uint32_t B, uint32_t dim,
+                              uint32_t k, uint32_t *ids, float *sims, uint32_t *n_out);
+
+/* Same, with every buffer already resident in HBM; enqueues on `stream`
+ * (a hipStream_t, NULL = the null stream) and returns without synchronising. */
+hnsw_status hnsw_search_batch_device(hnsw_index *h, const float *dQ, uint32_t B,
+                                     uint32_t dim, uint32_t k, uint32_t *d_ids,
+                                     float *d_sims, uint32_t *d_n_out, void *stream);
+
+/* Replaces make_index (src/lib.rs:252-315): load a frozen graph straight into
+ * HBM.  vectors [n][dim]; levels [n]; per layer l < n_layers a CSR
+ * (row_ptr[l] has n+1 entries, col[l] the neighbour ids in stored order).    */
+hnsw_status hnsw_import(hnsw_index *h, uint32_t n, const float *vectors,
+                        const uint32_t *levels, int64_t enterpoint, uint32_t n_layers,
+                        const uint64_t *const *row_ptr, const uint32_t *const *col);
+
+/* Export for IndexRedis/NodeRedis write-through (src/types.rs:62-91,292-309). */
+hnsw_status hnsw_get_info(hnsw_index *h, hnsw_info *info);
+hnsw_status hnsw_get_levels(hnsw_index *h, uint32_t *levels /*[node_count]*/);
+hnsw_status hnsw_get_vector(hnsw_index *h, uint32_t id, float *out /*[dim]*/);
+hnsw_status hnsw_get_neighbors(hnsw_index *h, uint32_t id, uint32_t layer,
+                               uint32_t *out, uint32_t cap, uint32_t *n);
+hnsw_status hnsw_layer_nnz(hnsw_index *h, uint32_t layer, uint64_t *nnz);
+hnsw_status hnsw_export_layer(hnsw_index *h, uint32_t layer, uint64_t *row_ptr /*[n+1]*/,
+                              uint32_t *col);
+
+/* Engine knobs (not part of the reference surface): "lds_hash_bits" (log2 of
+ * the per-query LDS visited table), "grid" (cap on resident query waves),
+ * "fast_seed" / "fast_batch_max" / "fast_batch_div" (fast build schedule).   */
+hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value);
+
+hnsw_status hnsw_get_counters(hnsw_index *h, hnsw_counters *search, hnsw_counters *insert);
+hnsw_status hnsw_reset_counters(hnsw_index *h);
+
+/* Timing of the most recent search kernel launch measured with HIP events on
+ * the stream it ran on (milliseconds); synchronises that stream.             */
+hnsw_status hnsw_last_search_kernel_ms(hnsw_index *h, float *ms);
+
+/* Device metric on its own: sims[i] = euclidean(a[i], b[i]) for n pairs of
+ * host vectors (metrics.rs:14-23 dispatch: AVX2 order iff dim % 32 == 0).
+ * Used by the metric known-answer tests.                                      */
+hnsw_status hnsw_metric_pairs(int device, const float *a, const float *b, uint32_t n,
+                              uint32_t dim, float *sims);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,72 @@
+"""ctypes view of include/hnsw_mi355x.h.  Loading fails loudly when the HIP
+library has not been built: there is no Python / CPU fallback."""
+import ctypes as C
+import os
+
+from . import build as _build
+
+OK, ERR_DIM_MISMATCH, ERR_DUPLICATE, ERR_NOT_FOUND, ERR_DEVICE, ERR_INVALID, ERR_CAPACITY = range(7)
+
+
+class Counters(C.Structure):
+    _fields_ = [("n_dist", C.c_uint64), ("n_ids", C.c_uint64), ("n_expand", C.c_uint64), ("n_spill", C.c_uint64)]
+
+
+class Info(C.Structure):
+    _fields_ = [("dim", C.c_uint32), ("m", C.c_uint32), ("m_max", C.c_uint32), ("m_max0", C.c_uint32),
+                ("ef_construction", C.c_uint32), ("node_count", C.c_uint32), ("max_layer", C.c_uint32),
+                ("enterpoint", C.c_int64), ("stride0", C.c_uint32), ("stride_upper", C.c_uint32),
+                ("max_degree0", C.c_uint32), ("max_degree_upper", C.c_uint32), ("hbm_bytes", C.c_uint64)]
+
+
+fp = C.POINTER(C.c_float)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+i32p = C.POINTER(C.c_int32)
+H = C.c_void_p
+
+# every symbol include/hnsw_mi355x.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "hnsw_create": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(H)]),
+    "hnsw_destroy": (None, [H]),
+    "hnsw_last_error": (C.c_char_p, [H]),
+    "hnsw_add": (C.c_int, [H, fp, C.c_uint32, C.c_int32, u32p, u32p, C.c_uint32, u32p]),
+    "hnsw_add_batch": (C.c_int, [H, fp, C.c_uint32, C.c_uint32, i32p, C.c_uint32]),
+    "hnsw_search": (C.c_int, [H, fp, C.c_uint32, C.c_uint32, u32p, fp, u32p]),
+    "hnsw_search_batch": (C.c_int, [H, fp, C.c_uint32, C.c_uint32, C.c_uint32, u32p, fp, u32p]),
+    "hnsw_search_batch_device": (C.c_int, [H, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hnsw_import": (C.c_int, [H, C.c_uint32, fp, u32p, C.c_int64, C.c_uint32, C.POINTER(u64p), C.POINTER(u32p)]),
+    "hnsw_get_info": (C.c_int, [H, C.POINTER(Info)]),
+    "hnsw_get_levels": (C.c_int, [H, u32p]),
+    "hnsw_get_vector": (C.c_int, [H, C.c_uint32, fp]),
+    "hnsw_get_neighbors": (C.c_int, [H, C.c_uint32, C.c_uint32, u32p, C.c_uint32, u32p]),
+    "hnsw_layer_nnz": (C.c_int, [H, C.c_uint32, u64p]),
+    "hnsw_export_layer": (C.c_int, [H, C.c_uint32, u64p, u32p]),
+    "hnsw_set_tuning": (C.c_int, [H, C.c_char_p, C.c_int64]),
+    "hnsw_get_counters": (C.c_int, [H, C.POINTER(Counters), C.POINTER(Counters)]),
+    "hnsw_reset_counters": (C.c_int, [H]),
+    "hnsw_last_search_kernel_ms": (C.c_int, [H, fp]),
+    "hnsw_metric_pairs": (C.c_int, [C.c_int, fp, fp, C.c_uint32, C.c_uint32, fp]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen redis_hnsw_amd/lib/libhnsw_mi355x.so and bind every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build it with `python -m redis_hnsw_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        f = getattr(lib, name)  # AttributeError if the .so does not export it
+        f.restype = res
+        f.argtypes = args
+    _lib = lib
+    return lib

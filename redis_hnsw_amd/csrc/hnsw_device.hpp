@@ -1,0 +1,509 @@
+// hnsw_device.hpp -- device-side building blocks of the MI355X HNSW engine.
+//
+// gfx950 only.  One 64-lane wavefront owns one query (or one insert); all
+// per-query state lives in that wave's LDS slice:
+//   W      sorted (dist, id) keys, the reference's W and C heaps in one array
+//   hash   exact open-addressing visited set (core.rs:614 HashSet), spills
+//          to an HBM table when it fills
+//   fresh  compacted ids of the unvisited neighbours of the current candidate
+//   dsc    their squared distances
+// The vector matrix is row-major f32 [N][dim]; 8 lanes stream one row with
+// 16 B loads (one 128 B line per 8-lane group per load instruction).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hnsw {
+
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+constexpr uint32_t kNoUpper = 0xFFFFFFFFu;
+constexpr int MODE_AVX = 0;    // dim % 32 == 0 : metrics.rs:48-77 summation order
+constexpr int MODE_SCALAR = 1; // otherwise     : metrics.rs:79-84 left fold
+
+// sticky status bits in DevHeader::status
+constexpr uint32_t ST_VISITED_OVERFLOW = 1u; // spill table full
+constexpr uint32_t ST_ROW_OVERFLOW = 2u;     // adjacency row full (engine bug: host re-strides first)
+constexpr uint32_t ST_ROW_DROPPED = 4u;      // fast build dropped a reverse link
+constexpr uint32_t ST_ASYMMETRIC = 8u;       // rm of a non-neighbour (reference would panic, core.rs:150)
+
+struct DevHeader {
+    uint32_t node_count;
+    uint32_t max_layer;
+    int32_t enterpoint;
+    uint32_t max_deg0;
+    uint32_t max_degU;
+    uint32_t status;
+    uint32_t n_touched; // exact insert: length of the touched list
+    uint32_t pad;
+    unsigned long long ctr_search[4]; // n_dist, n_ids, n_expand, n_spill
+    unsigned long long ctr_insert[4];
+};
+
+struct GraphView {
+    const float *vec;           // [cap][dim]
+    uint32_t *adj0;             // [cap][stride0]  word 0 = count, then ids in stored order
+    uint32_t *adjU;             // [upper slots][strideU]
+    const uint32_t *upper_base; // [cap] first upper slot (layer 1) or kNoUpper
+    const uint32_t *levels;     // [cap]
+    DevHeader *hdr;
+    uint32_t dim, stride0, strideU;
+};
+
+__device__ __forceinline__ uint32_t *row_ptr(const GraphView &g, uint32_t id, uint32_t lc)
+{
+    if (lc == 0) return g.adj0 + (size_t)id * g.stride0;
+    return g.adjU + (size_t)(g.upper_base[id] + lc - 1) * g.strideU;
+}
+
+// ---------------------------------------------------------------------------
+// keys: (squared distance bits << 32) | (id << 1) | expanded.  Squared
+// distances are >= +0 so their IEEE bits order like unsigned ints; smaller key
+// = nearer = larger reference sim, ties to the smaller id (tie order).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t pack_key(float d, uint32_t id)
+{
+    return ((uint64_t)__float_as_uint(d) << 32) | ((uint64_t)id << 1);
+}
+__device__ __forceinline__ uint32_t key_id(uint64_t k) { return (uint32_t)(k & 0xFFFFFFFFu) >> 1; }
+__device__ __forceinline__ float key_dist(uint64_t k) { return __uint_as_float((uint32_t)(k >> 32)); }
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane)
+{
+    uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+    uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
+
+// ---------------------------------------------------------------------------
+// cross-lane moves inside an 8-lane group (DPP, no LDS traffic)
+// ---------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x)
+{
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1;    // quad_perm [1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;    // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7-i inside each 8
+
+// Lane i of an 8-lane group reads the 16-byte piece pp(i) of every 128-byte
+// block.  Pieces 0..3 on lanes 0..3, pieces 7..4 on lanes 4..7, so that the
+// three exchanges the AVX2 order needs are all single DPP moves:
+//   piece ^ 2 = quad xor 2, piece ^ 4 = half mirror, piece ^ 1 = quad xor 1.
+__device__ __forceinline__ int piece_of_lane(int lane)
+{
+    int i = lane & 7;
+#ifdef HNSW_NO_DPP
+    return i;
+#else
+    return i < 4 ? i : 11 - i;
+#endif
+}
+
+template <int T>
+struct QReg {
+    float4 q[T > 0 ? T : 1];
+};
+
+// The reference's AVX2 kernel (metrics.rs:48-77) keeps 4 accumulators x 8
+// lanes; element 32t + 8a + j goes to lane j of accumulator a by one FMA per
+// t.  A piece p holds j = 4(p%2)+c of accumulator a = p/2, c = 0..3.
+template <int T>
+__device__ __forceinline__ float4 avx_accumulate(const float4 (&q)[T], const float4 (&v)[T])
+{
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        float dx = __fsub_rn(q[t].x, v[t].x), dy = __fsub_rn(q[t].y, v[t].y);
+        float dz = __fsub_rn(q[t].z, v[t].z), dw = __fsub_rn(q[t].w, v[t].w);
+        acc.x = __fmaf_rn(dx, dx, acc.x); // metrics.rs:57,60,64,68
+        acc.y = __fmaf_rn(dy, dy, acc.y);
+        acc.z = __fmaf_rn(dz, dz, acc.z);
+        acc.w = __fmaf_rn(dw, dw, acc.w);
+    }
+    return acc;
+}
+
+// (e1+e2)+(e3+e4) per lane (metrics.rs:71-74), low128+high128 (:37-39),
+// (s0+s1)+(s2+s3) (:27-31).  Every lane of the group ends with the result.
+__device__ __forceinline__ float avx_reduce(float4 a)
+{
+#ifdef HNSW_NO_DPP
+#define HNSW_X(v, m) __shfl_xor((v), (m))
+    a.x = __fadd_rn(a.x, HNSW_X(a.x, 2)); a.y = __fadd_rn(a.y, HNSW_X(a.y, 2));
+    a.z = __fadd_rn(a.z, HNSW_X(a.z, 2)); a.w = __fadd_rn(a.w, HNSW_X(a.w, 2));
+    a.x = __fadd_rn(a.x, HNSW_X(a.x, 4)); a.y = __fadd_rn(a.y, HNSW_X(a.y, 4));
+    a.z = __fadd_rn(a.z, HNSW_X(a.z, 4)); a.w = __fadd_rn(a.w, HNSW_X(a.w, 4));
+    a.x = __fadd_rn(a.x, HNSW_X(a.x, 1)); a.y = __fadd_rn(a.y, HNSW_X(a.y, 1));
+    a.z = __fadd_rn(a.z, HNSW_X(a.z, 1)); a.w = __fadd_rn(a.w, HNSW_X(a.w, 1));
+#undef HNSW_X
+#else
+    a.x = __fadd_rn(a.x, dpp_mov<DPP_QUAD_XOR2>(a.x)); a.y = __fadd_rn(a.y, dpp_mov<DPP_QUAD_XOR2>(a.y));
+    a.z = __fadd_rn(a.z, dpp_mov<DPP_QUAD_XOR2>(a.z)); a.w = __fadd_rn(a.w, dpp_mov<DPP_QUAD_XOR2>(a.w));
+    a.x = __fadd_rn(a.x, dpp_mov<DPP_HALF_MIRROR>(a.x)); a.y = __fadd_rn(a.y, dpp_mov<DPP_HALF_MIRROR>(a.y));
+    a.z = __fadd_rn(a.z, dpp_mov<DPP_HALF_MIRROR>(a.z)); a.w = __fadd_rn(a.w, dpp_mov<DPP_HALF_MIRROR>(a.w));
+    a.x = __fadd_rn(a.x, dpp_mov<DPP_QUAD_XOR1>(a.x)); a.y = __fadd_rn(a.y, dpp_mov<DPP_QUAD_XOR1>(a.y));
+    a.z = __fadd_rn(a.z, dpp_mov<DPP_QUAD_XOR1>(a.z)); a.w = __fadd_rn(a.w, dpp_mov<DPP_QUAD_XOR1>(a.w));
+#endif
+    return __fadd_rn(__fadd_rn(a.x, a.y), __fadd_rn(a.z, a.w));
+}
+
+// per-wave LDS slices
+struct WaveMem {
+    uint64_t *W;     // [R*64] sorted keys
+    uint64_t *S;     // [64]   select_neighbors result list (insert kernels)
+    uint32_t *fresh; // [64]
+    float *dsc;      // [64]
+    float *qlds;     // [dim]  query copy (generic / scalar modes; also float4 view)
+    uint32_t *aux;   // [kAuxWords] scratch for the insert kernels
+};
+
+// Load the wave's query into registers (AVX mode, T > 0) or LDS (T == 0).
+template <int MODE, int T>
+__device__ __forceinline__ void load_query(const float *src, uint32_t dim, QReg<T> &qr, float *qlds, int lane)
+{
+    if constexpr (MODE == MODE_AVX && T > 0) {
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        const int pp = piece_of_lane(lane);
+#pragma unroll
+        for (int t = 0; t < T; ++t) qr.q[t] = s4[t * 8 + pp];
+    } else {
+        for (uint32_t i = lane; i < dim; i += 64) qlds[i] = src[i];
+        __syncthreads();
+    }
+}
+
+// Squared distances from the query to fresh[0..nf) -> dsc[0..nf).
+template <int MODE, int T>
+__device__ __forceinline__ void compute_dists(const GraphView &g, const QReg<T> &qr, const WaveMem &m,
+                                              uint32_t nf, int lane)
+{
+    if constexpr (MODE == MODE_SCALAR) {
+        // metrics.rs:79-84 left fold; one lane per vector keeps the order exact
+        if ((uint32_t)lane < nf) {
+            const float *v = g.vec + (size_t)m.fresh[lane] * g.dim;
+            float acc = 0.f;
+            for (uint32_t i = 0; i < g.dim; ++i) {
+                float d = __fsub_rn(m.qlds[i], v[i]);
+                acc = __fadd_rn(acc, __fmul_rn(d, d));
+            }
+            m.dsc[lane] = acc;
+        }
+    } else if constexpr (T > 0) {
+        const int grp = lane >> 3, pp = piece_of_lane(lane);
+        constexpr int RB = (T <= 4) ? 4 : (T <= 8 ? 2 : 1); // rounds of 8 vectors in flight
+        for (uint32_t base = 0; base < nf; base += 8 * RB) {
+            float4 v[RB][T];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                uint32_t vi = base + r * 8 + grp;
+                if (vi < nf) {
+                    const float4 *p = reinterpret_cast<const float4 *>(g.vec + (size_t)m.fresh[vi] * g.dim) + pp;
+#pragma unroll
+                    for (int t = 0; t < T; ++t) v[r][t] = p[t * 8];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                uint32_t vi = base + r * 8 + grp;
+                if (vi < nf) {
+                    float d = avx_reduce(avx_accumulate<T>(qr.q, v[r]));
+                    if ((lane & 7) == 0) m.dsc[vi] = d;
+                }
+            }
+        }
+    } else {
+        // AVX order, any dim % 32 == 0: query pieces come from LDS
+        const int grp = lane >> 3, pp = piece_of_lane(lane);
+        const uint32_t Trt = g.dim >> 5;
+        const float4 *q4 = reinterpret_cast<const float4 *>(m.qlds) + pp;
+        for (uint32_t base = 0; base < nf; base += 8) {
+            uint32_t vi = base + grp;
+            if (vi < nf) {
+                const float4 *p = reinterpret_cast<const float4 *>(g.vec + (size_t)m.fresh[vi] * g.dim) + pp;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (uint32_t t = 0; t < Trt; ++t) {
+                    float4 x = p[t * 8], q = q4[t * 8];
+                    float dx = __fsub_rn(q.x, x.x), dy = __fsub_rn(q.y, x.y);
+                    float dz = __fsub_rn(q.z, x.z), dw = __fsub_rn(q.w, x.w);
+                    acc.x = __fmaf_rn(dx, dx, acc.x); acc.y = __fmaf_rn(dy, dy, acc.y);
+                    acc.z = __fmaf_rn(dz, dz, acc.z); acc.w = __fmaf_rn(dw, dw, acc.w);
+                }
+                float d = avx_reduce(acc);
+                if ((lane & 7) == 0) m.dsc[vi] = d;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// exact visited set: LDS open addressing, spilling to an HBM table
+// ---------------------------------------------------------------------------
+struct Visited {
+    uint32_t *lds;
+    uint32_t *glob;
+    uint32_t lbits, gbits;
+    uint32_t count;   // wave-uniform
+    bool spilled;     // wave-uniform
+    bool glob_dirty;  // wave-uniform
+};
+
+__device__ __forceinline__ uint32_t hash_slot(uint32_t id, uint32_t bits)
+{
+    return (id * 0x9E3779B1u) >> (32u - bits);
+}
+
+__device__ __forceinline__ void visited_clear(Visited &v, int lane)
+{
+    uint4 *t4 = reinterpret_cast<uint4 *>(v.lds);
+    const uint32_t n4 = (1u << v.lbits) >> 2;
+    const uint4 e = make_uint4(kEmpty, kEmpty, kEmpty, kEmpty);
+    for (uint32_t i = lane; i < n4; i += 64) t4[i] = e;
+    if (v.glob_dirty) {
+        uint4 *g4 = reinterpret_cast<uint4 *>(v.glob);
+        const uint32_t m4 = (1u << v.gbits) >> 2;
+        for (uint32_t i = lane; i < m4; i += 64) g4[i] = e;
+        __threadfence();
+        v.glob_dirty = false;
+    }
+    v.count = 0;
+    v.spilled = false;
+    __syncthreads();
+}
+
+// true if id was not in the set (and is now).  Lanes of one wave may call this
+// concurrently with distinct ids.
+__device__ __forceinline__ bool visited_insert(const Visited &v, uint32_t id)
+{
+    if (!v.spilled) {
+        const uint32_t mask = (1u << v.lbits) - 1u;
+        uint32_t h = hash_slot(id, v.lbits);
+        for (;;) {
+            uint32_t old = atomicCAS(&v.lds[h], kEmpty, id);
+            if (old == kEmpty) return true;
+            if (old == id) return false;
+            h = (h + 1) & mask;
+        }
+    } else {
+        const uint32_t mask = (1u << v.gbits) - 1u;
+        uint32_t h = hash_slot(id, v.gbits);
+        for (;;) {
+            uint32_t old = atomicCAS(&v.glob[h], kEmpty, id);
+            if (old == kEmpty) return true;
+            if (old == id) return false;
+            h = (h + 1) & mask;
+        }
+    }
+}
+
+__device__ __forceinline__ bool visited_contains(const Visited &v, uint32_t id)
+{
+    const uint32_t *t = v.spilled ? v.glob : v.lds;
+    const uint32_t bits = v.spilled ? v.gbits : v.lbits;
+    const uint32_t mask = (1u << bits) - 1u;
+    uint32_t h = hash_slot(id, bits);
+    for (;;) {
+        uint32_t cur = t[h];
+        if (cur == kEmpty) return false;
+        if (cur == id) return true;
+        h = (h + 1) & mask;
+    }
+}
+
+// Make room for up to 64 more ids.  Returns false if even the HBM table is full.
+__device__ __forceinline__ bool visited_reserve(Visited &v, int lane, unsigned long long *spill_ctr)
+{
+    if (!v.spilled) {
+        const uint32_t cap = 1u << v.lbits;
+        if (v.count + 64 <= cap - (cap >> 3)) return true;
+        // move every entry to the HBM table and continue there
+        const uint32_t gmask = (1u << v.gbits) - 1u;
+        for (uint32_t i = lane; i < cap; i += 64) {
+            uint32_t id = v.lds[i];
+            if (id != kEmpty) {
+                uint32_t h = hash_slot(id, v.gbits);
+                for (;;) {
+                    uint32_t old = atomicCAS(&v.glob[h], kEmpty, id);
+                    if (old == kEmpty) break;
+                    h = (h + 1) & gmask;
+                }
+            }
+        }
+        __threadfence();
+        __syncthreads();
+        v.spilled = true;
+        v.glob_dirty = true;
+        if (lane == 0 && spill_ctr) atomicAdd(spill_ctr, 1ull);
+    }
+    const uint32_t gcap = 1u << v.gbits;
+    return v.count + 64 <= gcap - (gcap >> 3);
+}
+
+// ---------------------------------------------------------------------------
+// W: merge up to 64 new keys (one per lane, `take` marks the lanes that carry
+// one) into the sorted list W[0..nW), keep the best `cap`.  Rank-and-scatter:
+// every old entry moves up by the number of new keys below it, every new key
+// lands at (#old below) + (#new below).  Equivalent to the reference pushing
+// the neighbours one by one (core.rs:657-664) -- the final W is the top-`cap`
+// of the union either way.
+// ---------------------------------------------------------------------------
+template <int R>
+__device__ __forceinline__ uint32_t merge_sorted(uint64_t *W, uint32_t nW, uint32_t cap, uint64_t nk,
+                                                 bool take, int lane)
+{
+    const uint64_t tmask = __ballot(take);
+    if (tmask == 0) return nW;
+    uint64_t w[R];
+    uint32_t up[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        uint32_t i = r * 64 + lane;
+        w[r] = i < nW ? W[i] : ~0ull;
+        up[r] = 0;
+    }
+    uint32_t mypos = 0;
+    uint64_t mm = tmask;
+    while (mm) {
+        const int j = __ffsll((unsigned long long)mm) - 1;
+        mm &= mm - 1;
+        const uint64_t s = readlane64(nk, j);
+        uint32_t rank = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool below = w[r] < s;
+            rank += __popcll(__ballot(below));
+            up[r] += below ? 0u : 1u;
+        }
+        rank += __popcll(__ballot(take && nk < s));
+        if (lane == j) mypos = rank;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        uint32_t i = r * 64 + lane;
+        if (i < nW) {
+            uint32_t np = i + up[r];
+            if (np < cap) W[np] = w[r];
+        }
+    }
+    if (take && mypos < cap) W[mypos] = nk;
+    const uint32_t total = nW + (uint32_t)__popcll(tmask);
+    __syncthreads();
+    return total < cap ? total : cap;
+}
+
+// index of the nearest entry not yet expanded (core.rs:631 pop of C), or -1.
+template <int R>
+__device__ __forceinline__ int find_unexpanded(const uint64_t *W, uint32_t nW, int lane)
+{
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        uint32_t i = r * 64 + lane;
+        if (r * 64u >= nW) break;
+        bool u = i < nW && !(W[i] & 1ull);
+        uint64_t b = __ballot(u);
+        if (b) return r * 64 + (__ffsll((unsigned long long)b) - 1);
+    }
+    return -1;
+}
+
+constexpr uint32_t kAuxWords = 512; // insert scratch: one adjacency row (degree <= 511)
+
+// LDS carve-up shared by the search and insert kernels.
+// [W: R*64*8][S: 64*8][fresh: 64*4][dsc: 64*4][aux: kAuxWords*4][qlds: dim*4 (T==0)][hash: 4<<lbits]
+__host__ __device__ inline size_t lds_bytes(int R, int T, uint32_t dim, uint32_t lbits)
+{
+    size_t b = (size_t)R * 64 * 8 + 64 * 8 + 64 * 4 + 64 * 4 + kAuxWords * 4;
+    if (T == 0) b += ((size_t)dim * 4 + 15) & ~(size_t)15;
+    b += (size_t)4 << lbits;
+    return b;
+}
+
+template <int R, int T>
+__device__ __forceinline__ void carve(unsigned char *smem, uint32_t dim, uint32_t lbits, WaveMem &m, Visited &vis)
+{
+    unsigned char *p = smem;
+    m.W = reinterpret_cast<uint64_t *>(p); p += (size_t)R * 64 * 8;
+    m.S = reinterpret_cast<uint64_t *>(p); p += 64 * 8;
+    m.fresh = reinterpret_cast<uint32_t *>(p); p += 64 * 4;
+    m.dsc = reinterpret_cast<float *>(p); p += 64 * 4;
+    m.aux = reinterpret_cast<uint32_t *>(p); p += kAuxWords * 4;
+    m.qlds = reinterpret_cast<float *>(p);
+    if (T == 0) p += ((size_t)dim * 4 + 15) & ~(size_t)15;
+    vis.lds = reinterpret_cast<uint32_t *>(p);
+    vis.lbits = lbits;
+}
+
+struct WorkCtr {
+    uint32_t n_dist, n_ids, n_expand;
+};
+
+// ---------------------------------------------------------------------------
+// search_level (core.rs:607-675).  W doubles as C: an entry is a live
+// candidate while its `expanded` bit is clear.  The reference's C also keeps
+// pairs already evicted from W, but those can never be expanded: W's furthest
+// only improves, so `c.sim < f.sim` (core.rs:635) stops the loop the moment
+// one is popped.  Leaves W[0..n) sorted nearest first; returns n.
+// ---------------------------------------------------------------------------
+template <int MODE, int T, int R>
+__device__ uint32_t search_level(const GraphView &g, const WaveMem &m, Visited &vis, const QReg<T> &qr,
+                                 uint32_t ep, uint32_t ef, uint32_t lc, WorkCtr &ctr, int lane, bool &fail)
+{
+    visited_clear(vis, lane);                    // core.rs:614
+    if (lane == 0) {
+        m.fresh[0] = ep;
+        visited_insert(vis, ep);                 // core.rs:617
+    }
+    vis.count = 1;
+    __syncthreads();
+    compute_dists<MODE, T>(g, qr, m, 1, lane);   // core.rs:621
+    ctr.n_dist += 1;
+    __syncthreads();
+    if (lane == 0) m.W[0] = pack_key(m.dsc[0], ep); // core.rs:627-628
+    uint32_t nW = 1;
+    __syncthreads();
+    const uint32_t stride = lc ? g.strideU : g.stride0;
+
+    for (;;) {
+        const int pos = find_unexpanded<R>(m.W, nW, lane); // core.rs:631
+        if (pos < 0) break;                               // core.rs:630,635
+        const uint64_t ckey = m.W[pos];
+        const uint32_t c = key_id(ckey);
+        __syncthreads();
+        if (lane == 0) m.W[pos] = ckey | 1ull;
+        ctr.n_expand += 1;
+
+        const uint32_t *row = row_ptr(g, c, lc);          // core.rs:645
+        uint32_t word = (uint32_t)lane < stride ? row[lane] : 0u;
+        uint32_t cnt = __builtin_amdgcn_readfirstlane(word);
+        if (cnt > stride - 1) cnt = stride - 1;
+        ctr.n_ids += cnt;
+        for (uint32_t wbase = 0; wbase <= cnt; wbase += 64) { // core.rs:646 stored order
+            const uint32_t wi = wbase + lane;
+            if (wbase) word = wi < stride ? row[wi] : 0u;
+            const bool valid = wi >= 1 && wi <= cnt;
+            if (!visited_reserve(vis, lane, &g.hdr->ctr_search[3])) { fail = true; return nW; }
+            const bool fresh = valid && visited_insert(vis, word); // core.rs:648-649
+            const uint64_t fm = __ballot(fresh);
+            const uint32_t nf = __popcll(fm);
+            if (nf == 0) continue;
+            if (fresh) m.fresh[__popcll(fm & lanemask_lt(lane))] = word;
+            vis.count += nf;
+            ctr.n_dist += nf;
+            __syncthreads();
+            compute_dists<MODE, T>(g, qr, m, nf, lane);    // core.rs:652
+            __syncthreads();
+            const bool have = (uint32_t)lane < nf;
+            const uint64_t key = have ? pack_key(m.dsc[lane], m.fresh[lane]) : ~0ull;
+            const uint64_t worst = nW == ef ? m.W[ef - 1] : ~0ull; // core.rs:651
+            const bool take = have && key < worst;          // core.rs:657
+            nW = merge_sorted<R>(m.W, nW, ef, key, take, lane); // core.rs:659-664
+        }
+        __syncthreads();
+    }
+    return nW;
+}
+
+} // namespace hnsw

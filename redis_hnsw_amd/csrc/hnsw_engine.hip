@@ -1,0 +1,864 @@
+// hnsw_engine.hip -- host side of libhnsw_mi355x.so: the C ABI of
+// include/hnsw_mi355x.h over the gfx950 kernels.  No CPU compute path exists
+// here: every search / insert is a kernel launch, and creation fails without
+// a device.
+#include "../../include/hnsw_mi355x.h"
+#include "hnsw_insert.hpp"
+#include "hnsw_kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace hnsw;
+
+struct hnsw_index {
+    uint32_t dim = 0, m = 0, m_max = 0, m_max0 = 0, efc = 0;
+    double level_mult = 0;
+    int device = 0;
+    int mode = MODE_AVX, T = 0;
+    uint32_t cap = 0, n = 0, max_layer = 0;
+    int64_t enterpoint = -1;
+    uint32_t stride0 = 0, strideU = 0, upper_cap = 0, upper_used = 0;
+    uint32_t max_deg0 = 0, max_degU = 0;
+    float *d_vec = nullptr;
+    uint32_t *d_adj0 = nullptr, *d_adjU = nullptr, *d_upper_base = nullptr, *d_levels = nullptr;
+    DevHeader *d_hdr = nullptr;
+    std::vector<uint32_t> h_levels, h_upper_base;
+    // search scratch
+    uint32_t *d_spill = nullptr;
+    uint32_t spill_gbits = 0, spill_slots = 0;
+    float *d_Q = nullptr;
+    uint32_t *d_ids = nullptr, *d_nout = nullptr;
+    float *d_sims = nullptr;
+    size_t stage_q = 0, stage_r = 0, stage_b = 0;
+    // insert scratch
+    uint32_t *d_plan = nullptr;     // [plan_slots][kMaxLayers][1 + 64]
+    uint32_t plan_slots = 0;
+    uint32_t *d_touched = nullptr;  // exact insert touched list
+    uint32_t touched_cap = 0;
+    uint32_t *d_work = nullptr;     // fast build: shrink worklist
+    uint32_t work_cap = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    int lds_bits_override = -1;
+    int grid_override = -1;
+    uint32_t fast_seed = 512, fast_batch_max = 4096, fast_batch_div = 8;
+    uint64_t rng[4] = {0, 0, 0, 0};
+    uint64_t hbm_bytes = 0;
+    std::string err;
+};
+
+namespace {
+
+#define HIP_TRY(h, expr)                                                                       \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                      \
+            return HNSW_ERR_DEVICE;                                                            \
+        }                                                                                      \
+    } while (0)
+
+hnsw_status fail(hnsw_index *h, hnsw_status s, const std::string &msg)
+{
+    h->err = msg;
+    return s;
+}
+
+uint32_t round_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
+uint32_t ceil_log2(uint64_t x)
+{
+    uint32_t b = 0;
+    while ((1ull << b) < x) ++b;
+    return b;
+}
+
+uint64_t splitmix64(uint64_t &x)
+{
+    uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+uint64_t xoshiro_next(uint64_t *s)
+{
+    uint64_t result = rotl64(s[1] * 5, 7) * 9, t = s[1] << 17;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl64(s[3], 45);
+    return result;
+}
+// core.rs:601-605: floor(-ln(U) * level_mult), U in [0,1)
+uint32_t draw_level(hnsw_index *h)
+{
+    double r = (double)(xoshiro_next(h->rng) >> 11) * (1.0 / 9007199254740992.0);
+    double l = -std::log(r) * h->level_mult;
+    if (!(l < (double)(kMaxLayers - 1))) return kMaxLayers - 1;
+    return (uint32_t)l;
+}
+
+template <typename Tp>
+hnsw_status dev_alloc(hnsw_index *h, Tp **p, size_t count, int fill = -1)
+{
+    size_t bytes = count * sizeof(Tp);
+    if (bytes == 0) bytes = sizeof(Tp);
+    HIP_TRY(h, hipMalloc((void **)p, bytes));
+    h->hbm_bytes += bytes;
+    if (fill >= 0) HIP_TRY(h, hipMemsetAsync(*p, fill, bytes, h->stream));
+    return HNSW_OK;
+}
+template <typename Tp>
+void dev_free(hnsw_index *h, Tp *&p, size_t count)
+{
+    if (!p) return;
+    (void)hipFree(p);
+    size_t bytes = count * sizeof(Tp);
+    h->hbm_bytes -= std::min<uint64_t>(h->hbm_bytes, bytes ? bytes : sizeof(Tp));
+    p = nullptr;
+}
+
+GraphView view(const hnsw_index *h)
+{
+    GraphView g;
+    g.vec = h->d_vec;
+    g.adj0 = h->d_adj0;
+    g.adjU = h->d_adjU;
+    g.upper_base = h->d_upper_base;
+    g.levels = h->d_levels;
+    g.hdr = h->d_hdr;
+    g.dim = h->dim;
+    g.stride0 = h->stride0;
+    g.strideU = h->strideU;
+    return g;
+}
+
+uint32_t default_stride(uint32_t mmax, uint32_t m, uint32_t maxdeg)
+{
+    // slot 0 = count; room for m_max plus the over-degree the reference's
+    // shrink step leaves on third parties, in 64-byte units
+    uint32_t want = std::max(mmax, maxdeg) + std::max(m + 2, mmax / 2);
+    return round_up(1 + want, 16);
+}
+
+// grow node capacity (vectors, layer-0 rows, levels, upper_base)
+hnsw_status ensure_node_cap(hnsw_index *h, uint32_t need)
+{
+    if (need <= h->cap) return HNSW_OK;
+    uint32_t ncap = h->cap ? h->cap : 1024;
+    while (ncap < need) ncap *= 2;
+    float *nvec = nullptr;
+    uint32_t *nadj0 = nullptr, *nub = nullptr, *nlv = nullptr;
+    hnsw_status s;
+    if ((s = dev_alloc(h, &nvec, (size_t)ncap * h->dim)) != HNSW_OK) return s;
+    if ((s = dev_alloc(h, &nadj0, (size_t)ncap * h->stride0, 0)) != HNSW_OK) return s;
+    if ((s = dev_alloc(h, &nub, (size_t)ncap, 0xFF)) != HNSW_OK) return s;
+    if ((s = dev_alloc(h, &nlv, (size_t)ncap, 0)) != HNSW_OK) return s;
+    if (h->n) {
+        HIP_TRY(h, hipMemcpyAsync(nvec, h->d_vec, (size_t)h->n * h->dim * 4, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(nadj0, h->d_adj0, (size_t)h->n * h->stride0 * 4, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(nub, h->d_upper_base, (size_t)h->n * 4, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(nlv, h->d_levels, (size_t)h->n * 4, hipMemcpyDeviceToDevice, h->stream));
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    dev_free(h, h->d_vec, (size_t)h->cap * h->dim);
+    dev_free(h, h->d_adj0, (size_t)h->cap * h->stride0);
+    dev_free(h, h->d_upper_base, (size_t)h->cap);
+    dev_free(h, h->d_levels, (size_t)h->cap);
+    h->d_vec = nvec; h->d_adj0 = nadj0; h->d_upper_base = nub; h->d_levels = nlv;
+    h->cap = ncap;
+    return HNSW_OK;
+}
+
+hnsw_status ensure_upper_cap(hnsw_index *h, uint32_t need)
+{
+    if (need <= h->upper_cap) return HNSW_OK;
+    uint32_t ncap = h->upper_cap ? h->upper_cap : 256;
+    while (ncap < need) ncap *= 2;
+    uint32_t *nadj = nullptr;
+    hnsw_status s;
+    if ((s = dev_alloc(h, &nadj, (size_t)ncap * h->strideU, 0)) != HNSW_OK) return s;
+    if (h->upper_used)
+        HIP_TRY(h, hipMemcpyAsync(nadj, h->d_adjU, (size_t)h->upper_used * h->strideU * 4, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    dev_free(h, h->d_adjU, (size_t)h->upper_cap * h->strideU);
+    h->d_adjU = nadj;
+    h->upper_cap = ncap;
+    return HNSW_OK;
+}
+
+// widen adjacency rows (layer 0 and/or upper) keeping their content
+hnsw_status restride(hnsw_index *h, uint32_t nstride0, uint32_t nstrideU)
+{
+    if (nstride0 > h->stride0) {
+        uint32_t *nadj = nullptr;
+        hnsw_status s = dev_alloc(h, &nadj, (size_t)h->cap * nstride0, 0);
+        if (s != HNSW_OK) return s;
+        if (h->n) {
+            uint64_t rows = h->n;
+            uint32_t blocks = (uint32_t)((rows * 64 + 255) / 256);
+            hipLaunchKernelGGL(k_restride, dim3(blocks), dim3(256), 0, h->stream, h->d_adj0, h->stride0, nadj, nstride0, rows);
+        }
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        dev_free(h, h->d_adj0, (size_t)h->cap * h->stride0);
+        h->d_adj0 = nadj;
+        h->stride0 = nstride0;
+    }
+    if (nstrideU > h->strideU) {
+        uint32_t *nadj = nullptr;
+        hnsw_status s = dev_alloc(h, &nadj, (size_t)std::max(h->upper_cap, 1u) * nstrideU, 0);
+        if (s != HNSW_OK) return s;
+        if (h->upper_used) {
+            uint64_t rows = h->upper_used;
+            uint32_t blocks = (uint32_t)((rows * 64 + 255) / 256);
+            hipLaunchKernelGGL(k_restride, dim3(blocks), dim3(256), 0, h->stream, h->d_adjU, h->strideU, nadj, nstrideU, rows);
+        }
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        dev_free(h, h->d_adjU, (size_t)h->upper_cap * h->strideU);
+        h->d_adjU = nadj;
+        h->strideU = nstrideU;
+    }
+    return HNSW_OK;
+}
+
+int pick_R(uint32_t need)
+{
+    if (need <= 64) return 1;
+    if (need <= 256) return 4;
+    if (need <= 512) return 8;
+    if (need <= 1024) return 16;
+    return 0;
+}
+
+uint32_t pick_lbits(const hnsw_index *h, int R, int T)
+{
+    if (h->lds_bits_override >= 4) return (uint32_t)h->lds_bits_override;
+    // expected visited-set size of one layer-0 search: ~0.8 * ef * m_max0
+    // (measured: 3.9 k at ef 200 / m_max0 32); 1.5x head room, then
+    // whatever keeps four waves resident per CU when that is possible.
+    double est = 0.8 * (double)h->efc * (double)h->m_max0 * 1.5;
+    uint32_t bits = std::max(8u, ceil_log2((uint64_t)est));
+    while (bits > 8 && lds_bytes(R, T, h->dim, bits) > 150 * 1024) --bits;
+    return bits;
+}
+
+hnsw_status ensure_spill(hnsw_index *h)
+{
+    uint64_t want = 4ull * h->efc * std::max(h->stride0, 16u);
+    want = std::min<uint64_t>(want, 2ull * std::max(h->n, 1024u));
+    uint32_t gbits = std::max(10u, ceil_log2(want));
+    const uint32_t slots = 2048;
+    if (h->d_spill && h->spill_gbits >= gbits && h->spill_slots >= slots) return HNSW_OK;
+    dev_free(h, h->d_spill, (size_t)h->spill_slots << h->spill_gbits);
+    hnsw_status s = dev_alloc(h, &h->d_spill, (size_t)slots << gbits, 0xFF);
+    if (s != HNSW_OK) return s;
+    h->spill_gbits = gbits;
+    h->spill_slots = slots;
+    return HNSW_OK;
+}
+
+template <int MODE, int T, int R>
+hnsw_status launch_search_t(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t *d_ids,
+                            float *d_sims, uint32_t *d_nout, hipStream_t st)
+{
+    const uint32_t lbits = pick_lbits(h, R, T);
+    const size_t lds = lds_bytes(R, T, h->dim, lbits);
+    auto kern = k_search<MODE, T, R>;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    uint32_t grid = std::min(B, h->spill_slots);
+    if (h->grid_override > 0) grid = std::min<uint32_t>(grid, (uint32_t)h->grid_override);
+    HIP_TRY(h, hipEventRecord(h->ev0, st));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, st, view(h), dQ, B, k, h->efc, lbits, h->d_spill,
+                       h->spill_gbits, d_ids, d_sims, d_nout);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->ev1, st));
+    h->ev_valid = true;
+    return HNSW_OK;
+}
+
+template <int MODE, int T>
+hnsw_status launch_search_r(hnsw_index *h, int R, const float *dQ, uint32_t B, uint32_t k, uint32_t *d_ids,
+                            float *d_sims, uint32_t *d_nout, hipStream_t st)
+{
+    switch (R) {
+    case 1: return launch_search_t<MODE, T, 1>(h, dQ, B, k, d_ids, d_sims, d_nout, st);
+    case 4: return launch_search_t<MODE, T, 4>(h, dQ, B, k, d_ids, d_sims, d_nout, st);
+    case 8: return launch_search_t<MODE, T, 8>(h, dQ, B, k, d_ids, d_sims, d_nout, st);
+    case 16: return launch_search_t<MODE, T, 16>(h, dQ, B, k, d_ids, d_sims, d_nout, st);
+    }
+    return fail(h, HNSW_ERR_INVALID, "ef_construction > 1024 is not supported");
+}
+
+hnsw_status launch_search(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t *d_ids,
+                          float *d_sims, uint32_t *d_nout, hipStream_t st)
+{
+    hnsw_status s = ensure_spill(h);
+    if (s != HNSW_OK) return s;
+    const int R = pick_R(h->efc);
+    if (h->mode == MODE_SCALAR) return launch_search_r<MODE_SCALAR, 0>(h, R, dQ, B, k, d_ids, d_sims, d_nout, st);
+    if (h->T == 4) return launch_search_r<MODE_AVX, 4>(h, R, dQ, B, k, d_ids, d_sims, d_nout, st);
+    if (h->T == 24) return launch_search_r<MODE_AVX, 24>(h, R, dQ, B, k, d_ids, d_sims, d_nout, st);
+    return launch_search_r<MODE_AVX, 0>(h, R, dQ, B, k, d_ids, d_sims, d_nout, st);
+}
+
+hnsw_status ensure_stage(hnsw_index *h, uint32_t B, uint32_t k)
+{
+    size_t nq = (size_t)B * h->dim, nr = (size_t)B * k;
+    hnsw_status s;
+    if (nq > h->stage_q) {
+        dev_free(h, h->d_Q, h->stage_q);
+        if ((s = dev_alloc(h, &h->d_Q, nq)) != HNSW_OK) return s;
+        h->stage_q = nq;
+    }
+    if (nr > h->stage_r) {
+        dev_free(h, h->d_ids, h->stage_r);
+        dev_free(h, h->d_sims, h->stage_r);
+        if ((s = dev_alloc(h, &h->d_ids, nr)) != HNSW_OK) return s;
+        if ((s = dev_alloc(h, &h->d_sims, nr)) != HNSW_OK) return s;
+        h->stage_r = nr;
+    }
+    if (B > h->stage_b) {
+        dev_free(h, h->d_nout, h->stage_b);
+        if ((s = dev_alloc(h, &h->d_nout, B)) != HNSW_OK) return s;
+        h->stage_b = B;
+    }
+    return HNSW_OK;
+}
+
+hnsw_status push_header(hnsw_index *h)
+{
+    DevHeader hd;
+    HIP_TRY(h, hipMemcpyAsync(&hd, h->d_hdr, sizeof hd, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    hd.node_count = h->n;
+    hd.max_layer = h->max_layer;
+    hd.enterpoint = (int32_t)h->enterpoint;
+    hd.max_deg0 = h->max_deg0;
+    hd.max_degU = h->max_degU;
+    HIP_TRY(h, hipMemcpyAsync(h->d_hdr, &hd, sizeof hd, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return HNSW_OK;
+}
+
+hnsw_status pull_header(hnsw_index *h, DevHeader *out = nullptr)
+{
+    DevHeader hd;
+    HIP_TRY(h, hipMemcpyAsync(&hd, h->d_hdr, sizeof hd, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->n = hd.node_count;
+    h->max_layer = hd.max_layer;
+    h->enterpoint = hd.enterpoint;
+    h->max_deg0 = hd.max_deg0;
+    h->max_degU = hd.max_degU;
+    if (out) *out = hd;
+    return HNSW_OK;
+}
+
+hnsw_status check_dev_status(hnsw_index *h, const DevHeader &hd)
+{
+    if (hd.status == 0) return HNSW_OK;
+    char buf[160];
+    snprintf(buf, sizeof buf, "device status 0x%x:%s%s%s%s", hd.status,
+             (hd.status & ST_VISITED_OVERFLOW) ? " visited-set overflow" : "",
+             (hd.status & ST_ROW_OVERFLOW) ? " adjacency row overflow" : "",
+             (hd.status & ST_ROW_DROPPED) ? " reverse link dropped" : "",
+             (hd.status & ST_ASYMMETRIC) ? " asymmetric link" : "");
+    // ROW_DROPPED is informational for the fast build
+    if ((hd.status & ~ST_ROW_DROPPED) == 0) return HNSW_OK;
+    return fail(h, HNSW_ERR_CAPACITY, buf);
+}
+
+#include "hnsw_insert_host.inc"
+
+} // namespace
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+hnsw_status hnsw_create(uint32_t dim, uint32_t m, uint32_t ef_construction, uint64_t seed, int device,
+                        hnsw_index **out)
+{
+    if (!out) return HNSW_ERR_INVALID;
+    *out = nullptr;
+    hnsw_index *h = new hnsw_index();
+    *out = h; // returned even on failure so the caller can read hnsw_last_error()
+    if (dim == 0 || m < 2 || m > 32 || ef_construction == 0 || ef_construction > 1024)
+        return fail(h, HNSW_ERR_INVALID, "supported: dim >= 1, 2 <= M <= 32, 1 <= EFCON <= 1024");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(h, HNSW_ERR_DEVICE, "no HIP device: this engine has no CPU path");
+    if (device < 0 || device >= ndev) return fail(h, HNSW_ERR_DEVICE, "bad device ordinal");
+    HIP_TRY(h, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(h, hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !std::getenv("HNSW_ALLOW_ANY_ARCH"))
+        return fail(h, HNSW_ERR_DEVICE, std::string("built for gfx950, device is ") + prop.gcnArchName);
+    h->device = device;
+    h->dim = dim;
+    h->m = m;
+    h->m_max = m;                               // core.rs:335
+    h->m_max0 = 2 * m;                          // core.rs:336
+    h->efc = ef_construction;                   // core.rs:337
+    h->level_mult = 1.0 / std::log((double)m);  // core.rs:338
+    h->mode = (dim % 32 == 0) ? MODE_AVX : MODE_SCALAR; // metrics.rs:18
+    h->T = (h->mode == MODE_AVX && (dim == 128 || dim == 768)) ? (int)(dim / 32) : 0;
+    uint64_t x = seed;
+    for (int i = 0; i < 4; ++i) h->rng[i] = splitmix64(x);
+    HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIP_TRY(h, hipEventCreate(&h->ev0));
+    HIP_TRY(h, hipEventCreate(&h->ev1));
+    h->stride0 = default_stride(h->m_max0, m, 0);
+    h->strideU = default_stride(h->m_max, m, 0);
+    hnsw_status s;
+    if ((s = dev_alloc(h, &h->d_hdr, 1, 0)) != HNSW_OK) return s;
+    h->enterpoint = -1;
+    if ((s = ensure_node_cap(h, 1024)) != HNSW_OK) return s;
+    if ((s = ensure_upper_cap(h, 256)) != HNSW_OK) return s;
+    if ((s = push_header(h)) != HNSW_OK) return s;
+    return HNSW_OK;
+}
+
+void hnsw_destroy(hnsw_index *h)
+{
+    if (!h) return;
+    if (h->stream) {
+        (void)hipSetDevice(h->device);
+        (void)hipStreamSynchronize(h->stream);
+    }
+    (void)hipFree(h->d_vec); (void)hipFree(h->d_adj0); (void)hipFree(h->d_adjU);
+    (void)hipFree(h->d_upper_base); (void)hipFree(h->d_levels); (void)hipFree(h->d_hdr);
+    (void)hipFree(h->d_spill); (void)hipFree(h->d_Q); (void)hipFree(h->d_ids); (void)hipFree(h->d_sims);
+    (void)hipFree(h->d_nout); (void)hipFree(h->d_plan); (void)hipFree(h->d_touched); (void)hipFree(h->d_work);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char *hnsw_last_error(const hnsw_index *h) { return h ? h->err.c_str() : "null handle"; }
+
+hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
+{
+    if (!h || !key) return HNSW_ERR_INVALID;
+    if (!std::strcmp(key, "lds_hash_bits")) { h->lds_bits_override = (int)value; return HNSW_OK; }
+    if (!std::strcmp(key, "grid")) { h->grid_override = (int)value; return HNSW_OK; }
+    if (!std::strcmp(key, "fast_seed")) { h->fast_seed = (uint32_t)std::max<int64_t>(value, 1); return HNSW_OK; }
+    if (!std::strcmp(key, "fast_batch_max")) { h->fast_batch_max = (uint32_t)std::max<int64_t>(value, 1); return HNSW_OK; }
+    if (!std::strcmp(key, "fast_batch_div")) { h->fast_batch_div = (uint32_t)std::max<int64_t>(value, 1); return HNSW_OK; }
+    return fail(h, HNSW_ERR_INVALID, std::string("unknown tuning key ") + key);
+}
+
+hnsw_status hnsw_add(hnsw_index *h, const float *v, uint32_t dim, int32_t level, uint32_t *out_id,
+                     uint32_t *touched, uint32_t touched_cap, uint32_t *n_touched)
+{
+    if (!h || !v) return HNSW_ERR_INVALID;
+    if (dim != h->dim) {                         // core.rs:389-391
+        char buf[96];
+        snprintf(buf, sizeof buf, "data dimension: %u does not match Index", dim);
+        return fail(h, HNSW_ERR_DIM_MISMATCH, buf);
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    uint32_t nt = 0;
+    hnsw_status s = add_exact(h, v, nullptr, level, out_id, touched != nullptr, &nt);
+    if (s != HNSW_OK) return s;
+    if (touched && nt) {
+        // the device list may repeat ids (the reference's `updated` is a HashSet, core.rs:522)
+        uint32_t have = std::min(nt, h->touched_cap);
+        std::vector<uint32_t> tmp(have);
+        HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->d_touched, (size_t)have * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        nt = (uint32_t)tmp.size();
+        for (uint32_t i = 0; i < nt && i < touched_cap; ++i) touched[i] = tmp[i];
+    }
+    if (n_touched) *n_touched = nt;
+    return HNSW_OK;
+}
+
+hnsw_status hnsw_add_batch(hnsw_index *h, const float *V, uint32_t n, uint32_t dim, const int32_t *levels,
+                           uint32_t mode)
+{
+    if (!h || (!V && n)) return HNSW_ERR_INVALID;
+    if (dim != h->dim) {
+        char buf[96];
+        snprintf(buf, sizeof buf, "data dimension: %u does not match Index", dim);
+        return fail(h, HNSW_ERR_DIM_MISMATCH, buf);
+    }
+    if (n == 0) return HNSW_OK;
+    if (mode > 1) return fail(h, HNSW_ERR_INVALID, "mode must be 0 (exact) or 1 (fast)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hnsw_status s;
+    uint32_t done = 0;
+    // exact inserts: all of them (mode 0) or the seed prefix of the fast build
+    while (done < n && (mode == 0 || h->n < h->fast_seed)) {
+        if ((s = add_exact(h, V + (size_t)done * dim, nullptr, levels ? levels[done] : -1, nullptr, false, nullptr)) != HNSW_OK)
+            return s;
+        ++done;
+    }
+    if (done == n) return HNSW_OK;
+
+    // ---- fast build ---------------------------------------------------------
+    const uint32_t first = h->n, rest = n - done;
+    if (std::max(h->stride0, h->strideU) > 129) return fail(h, HNSW_ERR_INVALID, "fast build needs row strides <= 129");
+    std::vector<uint32_t> lv(rest);
+    for (uint32_t i = 0; i < rest; ++i) {
+        uint32_t l = levels ? (levels[done + i] >= 0 ? (uint32_t)levels[done + i] : draw_level(h)) : draw_level(h);
+        lv[i] = std::min(l, kMaxLayers - 1);
+    }
+    if ((s = ensure_node_cap(h, first + rest)) != HNSW_OK) return s;
+    uint32_t up_need = h->upper_used;
+    for (uint32_t i = 0; i < rest; ++i) up_need += lv[i];
+    if ((s = ensure_upper_cap(h, std::max(up_need, 1u))) != HNSW_OK) return s;
+    for (uint32_t i = 0; i < rest; ++i)
+        if ((s = reserve_node(h, first + i, lv[i])) != HNSW_OK) return s;
+    HIP_TRY(h, hipMemcpyAsync(h->d_vec + (size_t)first * dim, V + (size_t)done * dim, (size_t)rest * dim * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_levels + first, h->h_levels.data() + first, (size_t)rest * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_upper_base + first, h->h_upper_base.data() + first, (size_t)rest * 4, hipMemcpyHostToDevice, h->stream));
+    if ((s = ensure_spill(h)) != HNSW_OK) return s;
+    if ((s = ensure_plan(h, h->fast_batch_max)) != HNSW_OK) return s;
+    uint32_t *pending0 = nullptr, *pendingU = nullptr, *work_n = nullptr;
+    HIP_TRY(h, hipMalloc((void **)&pending0, (size_t)h->cap * 4));
+    HIP_TRY(h, hipMalloc((void **)&pendingU, (size_t)std::max(h->upper_cap, 1u) * 4));
+    HIP_TRY(h, hipMalloc((void **)&work_n, 4));
+    HIP_TRY(h, hipMemsetAsync(pending0, 0, (size_t)h->cap * 4, h->stream));
+    HIP_TRY(h, hipMemsetAsync(pendingU, 0, (size_t)std::max(h->upper_cap, 1u) * 4, h->stream));
+    HIP_TRY(h, hipMemsetAsync(work_n, 0, 4, h->stream));
+    const uint32_t want_work = h->fast_batch_max * (h->m + 1) * 2;
+    if (want_work > h->work_cap) {
+        dev_free(h, h->d_work, (size_t)h->work_cap * 2);
+        if ((s = dev_alloc(h, &h->d_work, (size_t)want_work * 2)) != HNSW_OK) return s;
+        h->work_cap = want_work;
+    }
+    uint32_t pos = 0;
+    while (pos < rest) {
+        uint32_t bs = std::min(h->fast_batch_max, std::max(1u, h->n / h->fast_batch_div));
+        bs = std::min(bs, rest - pos);
+        uint32_t new_max = h->max_layer;
+        int64_t new_ep = h->enterpoint;
+        // a node that raises max_layer closes its batch: the next batch must see it as the enterpoint
+        for (uint32_t i = 0; i < bs; ++i)
+            if (lv[pos + i] > new_max) { new_max = lv[pos + i]; new_ep = first + pos + i; bs = i + 1; break; }
+        if ((s = add_fast_batch(h, first + pos, bs, new_max, new_ep, pending0, pendingU, work_n)) != HNSW_OK) break;
+        pos += bs;
+    }
+    hipError_t e = hipStreamSynchronize(h->stream);
+    (void)hipFree(pending0); (void)hipFree(pendingU); (void)hipFree(work_n);
+    if (s != HNSW_OK) return s;
+    HIP_TRY(h, e);
+    DevHeader hd;
+    if ((s = pull_header(h, &hd)) != HNSW_OK) return s;
+    return check_dev_status(h, hd);
+}
+
+hnsw_status hnsw_search_batch_device(hnsw_index *h, const float *dQ, uint32_t B, uint32_t dim, uint32_t k,
+                                     uint32_t *d_ids, float *d_sims, uint32_t *d_n_out, void *stream)
+{
+    if (!h) return HNSW_ERR_INVALID;
+    if (dim != h->dim) {                         // core.rs:478-480
+        char buf[96];
+        snprintf(buf, sizeof buf, "data dimension: %u does not match Index", dim);
+        return fail(h, HNSW_ERR_DIM_MISMATCH, buf);
+    }
+    if (B == 0) return HNSW_OK;
+    if (k == 0) return fail(h, HNSW_ERR_INVALID, "k must be >= 1");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (h->n == 0 || h->enterpoint < 0) {        // core.rs:481-483
+        HIP_TRY(h, hipMemsetAsync(d_n_out, 0, (size_t)B * 4, st));
+        HIP_TRY(h, hipMemsetAsync(d_ids, 0xFF, (size_t)B * k * 4, st));
+        HIP_TRY(h, hipMemsetAsync(d_sims, 0xFF, (size_t)B * k * 4, st));
+        return HNSW_OK;
+    }
+    return launch_search(h, dQ, B, k, d_ids, d_sims, d_n_out, st);
+}
+
+hnsw_status hnsw_search_batch(hnsw_index *h, const float *Q, uint32_t B, uint32_t dim, uint32_t k,
+                              uint32_t *ids, float *sims, uint32_t *n_out)
+{
+    if (!h) return HNSW_ERR_INVALID;
+    if (dim != h->dim) {
+        char buf[96];
+        snprintf(buf, sizeof buf, "data dimension: %u does not match Index", dim);
+        return fail(h, HNSW_ERR_DIM_MISMATCH, buf);
+    }
+    if (B == 0) return HNSW_OK;
+    if (k == 0) return fail(h, HNSW_ERR_INVALID, "k must be >= 1");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->n == 0 || h->enterpoint < 0) {
+        for (uint32_t b = 0; b < B; ++b) n_out[b] = 0;
+        return HNSW_OK;
+    }
+    hnsw_status s = ensure_stage(h, B, k);
+    if (s != HNSW_OK) return s;
+    HIP_TRY(h, hipMemcpyAsync(h->d_Q, Q, (size_t)B * dim * 4, hipMemcpyHostToDevice, h->stream));
+    if ((s = launch_search(h, h->d_Q, B, k, h->d_ids, h->d_sims, h->d_nout, h->stream)) != HNSW_OK) return s;
+    HIP_TRY(h, hipMemcpyAsync(ids, h->d_ids, (size_t)B * k * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(sims, h->d_sims, (size_t)B * k * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(n_out, h->d_nout, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (uint32_t b = 0; b < B; ++b)
+        if (n_out[b] == kEmpty) return fail(h, HNSW_ERR_CAPACITY, "visited-set spill table overflow");
+    return HNSW_OK;
+}
+
+hnsw_status hnsw_search(hnsw_index *h, const float *q, uint32_t dim, uint32_t k, uint32_t *ids, float *sims,
+                        uint32_t *n_out)
+{
+    if (!h || !n_out) return HNSW_ERR_INVALID;
+    std::vector<uint32_t> tid(k ? k : 1);
+    std::vector<float> tsim(k ? k : 1);
+    uint32_t n = 0;
+    hnsw_status s = hnsw_search_batch(h, q, 1, dim, k, tid.data(), tsim.data(), &n);
+    if (s != HNSW_OK) return s;
+    for (uint32_t i = 0; i < n; ++i) { ids[i] = tid[i]; sims[i] = tsim[i]; }
+    *n_out = n;
+    return HNSW_OK;
+}
+
+hnsw_status hnsw_import(hnsw_index *h, uint32_t n, const float *vectors, const uint32_t *levels,
+                        int64_t enterpoint, uint32_t n_layers, const uint64_t *const *row_ptr,
+                        const uint32_t *const *col)
+{
+    if (!h) return HNSW_ERR_INVALID;
+    if (h->n != 0) return fail(h, HNSW_ERR_INVALID, "hnsw_import needs an empty index");
+    if (n == 0) return HNSW_OK;
+    if (enterpoint < 0 || enterpoint >= (int64_t)n || n_layers == 0 || n_layers > kMaxLayers)
+        return fail(h, HNSW_ERR_INVALID, "bad enterpoint / layer count");
+    HIP_TRY(h, hipSetDevice(h->device));
+    // degrees decide the row strides
+    uint32_t md0 = 0, mdU = 0;
+    for (uint32_t l = 0; l < n_layers; ++l)
+        for (uint32_t i = 0; i < n; ++i) {
+            uint64_t d = row_ptr[l][i + 1] - row_ptr[l][i];
+            if (d > 0 && levels[i] < l) return fail(h, HNSW_ERR_INVALID, "node has links above its level");
+            if (d > kAuxWords - 2) return fail(h, HNSW_ERR_INVALID, "degree > 510 is not supported");
+            if (l == 0) md0 = std::max<uint32_t>(md0, (uint32_t)d);
+            else mdU = std::max<uint32_t>(mdU, (uint32_t)d);
+        }
+    uint32_t ns0 = default_stride(h->m_max0, h->m, md0), nsU = default_stride(h->m_max, h->m, mdU);
+    hnsw_status s;
+    // (re)allocate at the right strides before any data lands
+    if (ns0 > h->stride0 || nsU > h->strideU) {
+        if ((s = restride(h, std::max(ns0, h->stride0), std::max(nsU, h->strideU))) != HNSW_OK) return s;
+    }
+    if ((s = ensure_node_cap(h, n)) != HNSW_OK) return s;
+    h->h_levels.assign(levels, levels + n);
+    h->h_upper_base.assign(n, kNoUpper);
+    uint32_t used = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (levels[i] >= kMaxLayers) return fail(h, HNSW_ERR_INVALID, "level too large");
+        if (levels[i] > 0) { h->h_upper_base[i] = used; used += levels[i]; }
+    }
+    if ((s = ensure_upper_cap(h, std::max(used, 1u))) != HNSW_OK) return s;
+    h->upper_used = used;
+    HIP_TRY(h, hipMemcpyAsync(h->d_vec, vectors, (size_t)n * h->dim * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_levels, levels, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_upper_base, h->h_upper_base.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    for (uint32_t l = 0; l < n_layers; ++l) {
+        uint64_t nnz = row_ptr[l][n];
+        uint64_t *d_rp = nullptr;
+        uint32_t *d_col = nullptr;
+        HIP_TRY(h, hipMalloc((void **)&d_rp, (size_t)(n + 1) * 8));
+        HIP_TRY(h, hipMalloc((void **)&d_col, (size_t)std::max<uint64_t>(nnz, 1) * 4));
+        HIP_TRY(h, hipMemcpyAsync(d_rp, row_ptr[l], (size_t)(n + 1) * 8, hipMemcpyHostToDevice, h->stream));
+        if (nnz) HIP_TRY(h, hipMemcpyAsync(d_col, col[l], (size_t)nnz * 4, hipMemcpyHostToDevice, h->stream));
+        uint32_t blocks = (uint32_t)(((uint64_t)n * 64 + 255) / 256);
+        if (l == 0)
+            hipLaunchKernelGGL(k_import_rows, dim3(blocks), dim3(256), 0, h->stream, h->d_adj0, h->stride0,
+                               (const uint32_t *)nullptr, 0u, h->d_levels, 0u, d_rp, d_col, n);
+        else
+            hipLaunchKernelGGL(k_import_rows, dim3(blocks), dim3(256), 0, h->stream, h->d_adjU, h->strideU,
+                               h->d_upper_base, l - 1, h->d_levels, l, d_rp, d_col, n);
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        (void)hipFree(d_rp);
+        (void)hipFree(d_col);
+    }
+    h->n = n;
+    h->enterpoint = enterpoint;
+    h->max_layer = levels[enterpoint];           // the enterpoint is the top node (core.rs:587-593)
+    h->max_deg0 = md0;
+    h->max_degU = mdU;
+    return push_header(h);
+}
+
+hnsw_status hnsw_get_info(hnsw_index *h, hnsw_info *info)
+{
+    if (!h || !info) return HNSW_ERR_INVALID;
+    info->dim = h->dim; info->m = h->m; info->m_max = h->m_max; info->m_max0 = h->m_max0;
+    info->ef_construction = h->efc;
+    info->node_count = h->n; info->max_layer = h->max_layer; info->enterpoint = h->enterpoint;
+    info->stride0 = h->stride0; info->stride_upper = h->strideU;
+    info->max_degree0 = h->max_deg0; info->max_degree_upper = h->max_degU;
+    info->hbm_bytes = h->hbm_bytes;
+    return HNSW_OK;
+}
+
+hnsw_status hnsw_get_levels(hnsw_index *h, uint32_t *levels)
+{
+    if (!h || !levels) return HNSW_ERR_INVALID;
+    std::copy(h->h_levels.begin(), h->h_levels.begin() + h->n, levels);
+    return HNSW_OK;
+}
+
+hnsw_status hnsw_get_vector(hnsw_index *h, uint32_t id, float *out)
+{
+    if (!h || !out) return HNSW_ERR_INVALID;
+    if (id >= h->n) return fail(h, HNSW_ERR_NOT_FOUND, "node id out of range");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(out, h->d_vec + (size_t)id * h->dim, (size_t)h->dim * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return HNSW_OK;
+}
+
+hnsw_status hnsw_get_neighbors(hnsw_index *h, uint32_t id, uint32_t layer, uint32_t *out, uint32_t cap,
+                               uint32_t *n)
+{
+    if (!h || !n) return HNSW_ERR_INVALID;
+    if (id >= h->n) return fail(h, HNSW_ERR_NOT_FOUND, "node id out of range");
+    *n = 0;
+    if (layer > h->h_levels[id]) return HNSW_OK; // push_levels: rows above the level are empty
+    HIP_TRY(h, hipSetDevice(h->device));
+    const uint32_t stride = layer ? h->strideU : h->stride0;
+    const uint32_t *row = layer ? h->d_adjU + (size_t)(h->h_upper_base[id] + layer - 1) * stride
+                                : h->d_adj0 + (size_t)id * stride;
+    std::vector<uint32_t> tmp(stride);
+    HIP_TRY(h, hipMemcpyAsync(tmp.data(), row, (size_t)stride * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    uint32_t cnt = std::min(tmp[0], stride - 1);
+    *n = cnt;
+    for (uint32_t i = 0; i < cnt && i < cap; ++i) out[i] = tmp[1 + i];
+    return HNSW_OK;
+}
+
+static hnsw_status layer_degrees(hnsw_index *h, uint32_t layer, std::vector<uint32_t> &deg)
+{
+    deg.assign(h->n, 0);
+    if (h->n == 0) return HNSW_OK;
+    uint32_t *d_deg = nullptr;
+    HIP_TRY(h, hipMalloc((void **)&d_deg, (size_t)h->n * 4));
+    uint32_t blocks = (h->n + 255) / 256;
+    if (layer == 0)
+        hipLaunchKernelGGL(k_degrees, dim3(blocks), dim3(256), 0, h->stream, h->d_adj0, h->stride0,
+                           (const uint32_t *)nullptr, 0u, h->d_levels, 0u, h->n, d_deg);
+    else
+        hipLaunchKernelGGL(k_degrees, dim3(blocks), dim3(256), 0, h->stream, h->d_adjU, h->strideU,
+                           h->d_upper_base, layer - 1, h->d_levels, layer, h->n, d_deg);
+    HIP_TRY(h, hipMemcpyAsync(deg.data(), d_deg, (size_t)h->n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(d_deg);
+    return HNSW_OK;
+}
+
+hnsw_status hnsw_layer_nnz(hnsw_index *h, uint32_t layer, uint64_t *nnz)
+{
+    if (!h || !nnz) return HNSW_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    std::vector<uint32_t> deg;
+    hnsw_status s = layer_degrees(h, layer, deg);
+    if (s != HNSW_OK) return s;
+    uint64_t t = 0;
+    for (uint32_t d : deg) t += d;
+    *nnz = t;
+    return HNSW_OK;
+}
+
+hnsw_status hnsw_export_layer(hnsw_index *h, uint32_t layer, uint64_t *row_ptr, uint32_t *col)
+{
+    if (!h || !row_ptr) return HNSW_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    std::vector<uint32_t> deg;
+    hnsw_status s = layer_degrees(h, layer, deg);
+    if (s != HNSW_OK) return s;
+    uint64_t t = 0;
+    for (uint32_t i = 0; i < h->n; ++i) { row_ptr[i] = t; t += deg[i]; }
+    row_ptr[h->n] = t;
+    if (t == 0 || h->n == 0) return HNSW_OK;
+    uint64_t *d_rp = nullptr;
+    uint32_t *d_col = nullptr;
+    HIP_TRY(h, hipMalloc((void **)&d_rp, (size_t)(h->n + 1) * 8));
+    HIP_TRY(h, hipMalloc((void **)&d_col, (size_t)t * 4));
+    HIP_TRY(h, hipMemcpyAsync(d_rp, row_ptr, (size_t)(h->n + 1) * 8, hipMemcpyHostToDevice, h->stream));
+    uint32_t blocks = (uint32_t)(((uint64_t)h->n * 64 + 255) / 256);
+    if (layer == 0)
+        hipLaunchKernelGGL(k_export_rows, dim3(blocks), dim3(256), 0, h->stream, h->d_adj0, h->stride0,
+                           (const uint32_t *)nullptr, 0u, h->d_levels, 0u, h->n, d_rp, d_col);
+    else
+        hipLaunchKernelGGL(k_export_rows, dim3(blocks), dim3(256), 0, h->stream, h->d_adjU, h->strideU,
+                           h->d_upper_base, layer - 1, h->d_levels, layer, h->n, d_rp, d_col);
+    HIP_TRY(h, hipMemcpyAsync(col, d_col, (size_t)t * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(d_rp);
+    (void)hipFree(d_col);
+    return HNSW_OK;
+}
+
+hnsw_status hnsw_get_counters(hnsw_index *h, hnsw_counters *search, hnsw_counters *insert)
+{
+    if (!h) return HNSW_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    DevHeader hd;
+    HIP_TRY(h, hipMemcpy(&hd, h->d_hdr, sizeof hd, hipMemcpyDeviceToHost));
+    if (search) { search->n_dist = hd.ctr_search[0]; search->n_ids = hd.ctr_search[1]; search->n_expand = hd.ctr_search[2]; search->n_spill = hd.ctr_search[3]; }
+    if (insert) { insert->n_dist = hd.ctr_insert[0]; insert->n_ids = hd.ctr_insert[1]; insert->n_expand = hd.ctr_insert[2]; insert->n_spill = hd.ctr_insert[3]; }
+    return HNSW_OK;
+}
+
+hnsw_status hnsw_reset_counters(hnsw_index *h)
+{
+    if (!h) return HNSW_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemset((char *)h->d_hdr + offsetof(DevHeader, ctr_search), 0, sizeof(unsigned long long) * 8));
+    return HNSW_OK;
+}
+
+hnsw_status hnsw_last_search_kernel_ms(hnsw_index *h, float *ms)
+{
+    if (!h || !ms) return HNSW_ERR_INVALID;
+    if (!h->ev_valid) return fail(h, HNSW_ERR_INVALID, "no search launched yet");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipEventSynchronize(h->ev1));
+    HIP_TRY(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return HNSW_OK;
+}
+
+hnsw_status hnsw_metric_pairs(int device, const float *a, const float *b, uint32_t n, uint32_t dim, float *sims)
+{
+    if (!a || !b || !sims || dim == 0) return HNSW_ERR_INVALID;
+    if (n == 0) return HNSW_OK;
+    if (hipSetDevice(device) != hipSuccess) return HNSW_ERR_DEVICE;
+    float *da = nullptr, *db = nullptr, *ds = nullptr;
+    size_t bytes = (size_t)n * dim * 4;
+    if (hipMalloc((void **)&da, bytes) != hipSuccess || hipMalloc((void **)&db, bytes) != hipSuccess ||
+        hipMalloc((void **)&ds, (size_t)n * 4) != hipSuccess)
+        return HNSW_ERR_DEVICE;
+    (void)hipMemcpy(da, a, bytes, hipMemcpyHostToDevice);
+    (void)hipMemcpy(db, b, bytes, hipMemcpyHostToDevice);
+    uint32_t grid = std::min(n, 1024u);
+    if (dim % 32 == 0 && (dim == 128 || dim == 768)) {
+        // the register-resident kernels the search uses for these dims
+        uint32_t g2 = std::min((n + 63) / 64, 1024u);
+        if (dim == 128) hipLaunchKernelGGL(k_metric_pairs_reg<4>, dim3(g2), dim3(64), 0, 0, da, db, n, ds);
+        else hipLaunchKernelGGL(k_metric_pairs_reg<24>, dim3(g2), dim3(64), 0, 0, da, db, n, ds);
+    } else {
+        size_t lds = (((size_t)dim * 4 + 15) & ~(size_t)15) + 64 * 8;
+        if (dim % 32 == 0)
+            hipLaunchKernelGGL(k_metric_pairs<MODE_AVX>, dim3(grid), dim3(64), lds, 0, da, db, n, dim, ds);
+        else
+            hipLaunchKernelGGL(k_metric_pairs<MODE_SCALAR>, dim3(grid), dim3(64), lds, 0, da, db, n, dim, ds);
+    }
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(sims, ds, (size_t)n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(ds);
+    return e == hipSuccess ? HNSW_OK : HNSW_ERR_DEVICE;
+}
+
+} // extern "C"

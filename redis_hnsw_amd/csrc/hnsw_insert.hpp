@@ -1,0 +1,431 @@
+// hnsw_insert.hpp -- HNSW.NODE.ADD on the GPU (core.rs:383-412, 489-599).
+//
+// An insert is two phases:
+//   plan    read-only: greedy descent, per-layer search_level(ef_construction)
+//           and select_neighbors(m) -> the link list of every layer
+//           (core.rs:511-531).  One wave per new node; many nodes per launch in
+//           the fast build.
+//   commit  connect_neighbors + the shrink loop + enterpoint promotion
+//           (core.rs:532-596).  The exact commit is one wave replaying the
+//           reference's serial order link for link; the fast build commits a
+//           whole batch with atomics and prunes over-full rows afterwards.
+// Layers are independent structures, so planning every layer before committing
+// any is equivalent to the reference's interleaving.
+#pragma once
+#include "hnsw_device.hpp"
+
+namespace hnsw {
+
+constexpr uint32_t kMaxLayers = 32;       // levels 0..31
+constexpr uint32_t kPlanStride = 1 + 64;  // per (slot, layer): count + up to 64 ids
+
+// ---------------------------------------------------------------------------
+// select_neighbors (core.rs:677-757) with extend_candidates = keep_pruned =
+// true, which is every call site (:528-529, :565-566).  The r / wd dance of
+// :724-754 returns exactly the m nearest of  C u N_lc(C) \ {query}  (the first
+// pop seeds r, every later pop fails the strict `>` at :733 and waits in wd,
+// keep_pruned then refills r nearest first), so that set is built directly:
+// S starts as the m nearest of C, then every unvisited neighbour of every
+// candidate is merged in.  cand[0..ncand) is sorted nearest first and is left
+// untouched.  Result in m.S[0..n), sorted; returns n.
+// ---------------------------------------------------------------------------
+template <int MODE, int T>
+__device__ uint32_t select_topm(const GraphView &g, const WaveMem &m, Visited &vis, const QReg<T> &qr,
+                                const uint64_t *cand, uint32_t ncand, uint32_t qid, uint32_t mcap,
+                                uint32_t lc, WorkCtr &ctr, int lane, bool &fail)
+{
+    visited_clear(vis, lane);                               // core.rs:692
+    for (uint32_t base = 0; base < ncand; base += 64) {     // core.rs:693-696
+        if (!visited_reserve(vis, lane, nullptr)) { fail = true; return 0; }
+        const uint32_t i = base + lane;
+        if (i < ncand) visited_insert(vis, key_id(cand[i]));
+        vis.count += ncand - base < 64 ? ncand - base : 64;
+    }
+    uint32_t nS = ncand < mcap ? ncand : mcap;              // core.rs:685 w = c.clone()
+    if ((uint32_t)lane < nS) m.S[lane] = cand[lane] & ~1ull;
+    __syncthreads();
+
+    const uint32_t stride = lc ? g.strideU : g.stride0;
+    // software prefetch: the next candidate's row is requested before the
+    // current one's distances are computed
+    uint32_t word_next = 0;
+    if (ncand) {
+        const uint32_t *r0 = row_ptr(g, key_id(cand[0]), lc);
+        word_next = (uint32_t)lane < stride ? r0[lane] : 0u;
+    }
+    for (uint32_t ci = 0; ci < ncand; ++ci) {               // core.rs:699-700 nearest first
+        const uint32_t e = key_id(cand[ci]);
+        const uint32_t *row = row_ptr(g, e, lc);
+        uint32_t word = word_next;
+        if (ci + 1 < ncand) {
+            const uint32_t *rn = row_ptr(g, key_id(cand[ci + 1]), lc);
+            word_next = (uint32_t)lane < stride ? rn[lane] : 0u;
+        }
+        uint32_t cnt = __builtin_amdgcn_readfirstlane(word);
+        if (cnt > stride - 1) cnt = stride - 1;
+        ctr.n_ids += cnt;
+        for (uint32_t wbase = 0; wbase <= cnt; wbase += 64) { // core.rs:702
+            const uint32_t wi = wbase + lane;
+            if (wbase) word = wi < stride ? row[wi] : 0u;
+            const bool valid = wi >= 1 && wi <= cnt && word != qid; // core.rs:704-708
+            if (!visited_reserve(vis, lane, nullptr)) { fail = true; return 0; }
+            const bool fresh = valid && visited_insert(vis, word);  // core.rs:710,718
+            const uint64_t fm = __ballot(fresh);
+            const uint32_t nf = __popcll(fm);
+            if (nf == 0) continue;
+            if (fresh) m.fresh[__popcll(fm & lanemask_lt(lane))] = word;
+            vis.count += nf;
+            ctr.n_dist += nf;
+            __syncthreads();
+            compute_dists<MODE, T>(g, qr, m, nf, lane);      // core.rs:711
+            __syncthreads();
+            const bool have = (uint32_t)lane < nf;
+            const uint64_t key = have ? pack_key(m.dsc[lane], m.fresh[lane]) : ~0ull;
+            const uint64_t worst = nS == mcap ? m.S[mcap - 1] : ~0ull;
+            nS = merge_sorted<1>(m.S, nS, mcap, key, have && key < worst, lane); // core.rs:717
+        }
+    }
+    __syncthreads();
+    return nS;
+}
+
+// ---------------------------------------------------------------------------
+// plan kernel: one wave per new node (ids first_id .. first_id+count-1, whose
+// vectors / levels / upper slots are already in HBM and whose rows are empty).
+// plan[(slot*kMaxLayers + lc)*kPlanStride] = n, then n ids nearest first.
+// ---------------------------------------------------------------------------
+template <int MODE, int T, int R>
+__global__ __launch_bounds__(64) void k_insert_plan(GraphView g, uint32_t first_id, uint32_t count, uint32_t ef,
+                                                    uint32_t mlinks, uint32_t lbits, uint32_t *__restrict__ gspill,
+                                                    uint32_t gbits, uint32_t *__restrict__ plan)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    WaveMem m;
+    Visited vis;
+    carve<R, T>(smem, g.dim, lbits, m, vis);
+    vis.glob = gspill + ((size_t)blockIdx.x << gbits);
+    vis.gbits = gbits;
+    vis.glob_dirty = false;
+    vis.spilled = false;
+    vis.count = 0;
+
+    WorkCtr ctr = {0, 0, 0};
+    const uint32_t lmax = g.hdr->max_layer;                 // core.rs:496
+    const uint32_t ep0 = (uint32_t)g.hdr->enterpoint;       // core.rs:508
+
+    for (uint32_t s = blockIdx.x; s < count; s += gridDim.x) {
+        const uint32_t id = first_id + s;
+        const uint32_t l = g.levels[id];
+        QReg<T> qr;
+        load_query<MODE, T>(g.vec + (size_t)id * g.dim, g.dim, qr, m.qlds, lane);
+        bool fail = false;
+        uint32_t ep = ep0;
+        for (uint32_t lc = lmax; lc > l && !fail; --lc) {   // core.rs:511-520
+            search_level<MODE, T, 1>(g, m, vis, qr, ep, 1, lc, ctr, lane, fail);
+            ep = key_id(m.W[0]);                            // core.rs:514
+            __syncthreads();
+        }
+        const uint32_t top = lmax < l ? lmax : l;
+        for (uint32_t lc1 = top + 1; lc1-- > 0 && !fail;) { // core.rs:523
+            const uint32_t lc = lc1;
+            const uint32_t nW = search_level<MODE, T, R>(g, m, vis, qr, ep, ef, lc, ctr, lane, fail); // :524
+            if (fail) break;
+            const uint32_t wnearest = key_id(m.W[0]);
+            const uint32_t nS = select_topm<MODE, T>(g, m, vis, qr, m.W, nW, id, mlinks, lc, ctr, lane, fail); // :531
+            if (fail) break;
+            uint32_t *pl = plan + ((size_t)s * kMaxLayers + lc) * kPlanStride;
+            if (lane == 0) pl[0] = nS;
+            if ((uint32_t)lane < nS) pl[1 + lane] = key_id(m.S[lane]);
+            ep = wnearest;                                  // core.rs:576
+            __syncthreads();
+        }
+        if (fail && lane == 0) atomicOr(&g.hdr->status, ST_VISITED_OVERFLOW);
+    }
+    if (vis.glob_dirty) visited_clear(vis, lane);
+    if (lane == 0) {
+        atomicAdd(&g.hdr->ctr_insert[0], (unsigned long long)ctr.n_dist);
+        atomicAdd(&g.hdr->ctr_insert[1], (unsigned long long)ctr.n_ids);
+        atomicAdd(&g.hdr->ctr_insert[2], (unsigned long long)ctr.n_expand);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// exact commit (one wave, one node): core.rs:532-596 in the reference's order
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void touch_push(uint32_t *touched, uint32_t cap, uint32_t &nt, uint32_t id, bool on,
+                                           int lane)
+{
+    const uint64_t b = __ballot(on);
+    if (on) {
+        uint32_t p = nt + __popcll(b & lanemask_lt(lane));
+        if (p < cap) touched[p] = id;
+    }
+    nt += __popcll(b);
+}
+
+template <int MODE, int T, int R>
+__global__ __launch_bounds__(64) void k_insert_commit_exact(GraphView g, uint32_t id, uint32_t mlinks,
+                                                            uint32_t lbits, uint32_t *__restrict__ gspill,
+                                                            uint32_t gbits, const uint32_t *__restrict__ plan,
+                                                            uint32_t *__restrict__ touched, uint32_t touched_cap)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    WaveMem m;
+    Visited vis;
+    carve<R, T>(smem, g.dim, lbits, m, vis);
+    vis.glob = gspill;
+    vis.gbits = gbits;
+    vis.glob_dirty = false;
+    vis.spilled = false;
+    vis.count = 0;
+
+    WorkCtr ctr = {0, 0, 0};
+    uint32_t skipped = 0;  // econn evaluations the reference makes but whose result it never uses (:549-557 when deg <= m_max)
+    uint32_t nt = 0;
+    bool fail = false;
+    const uint32_t lmax = g.hdr->max_layer;
+    const uint32_t l = g.levels[id];
+    const uint32_t top = lmax < l ? lmax : l;
+
+    for (uint32_t lc1 = top + 1; lc1-- > 0 && !fail;) {     // core.rs:523
+        const uint32_t lc = lc1;
+        const uint32_t stride = lc ? g.strideU : g.stride0;
+        const uint32_t mmax = lc ? mlinks : 2 * mlinks;     // core.rs:560
+        uint32_t *maxdeg = lc ? &g.hdr->max_degU : &g.hdr->max_deg0;
+        const uint32_t *pl = plan + (size_t)lc * kPlanStride;
+        const uint32_t nsel = pl[0];
+        const uint32_t myselid = (uint32_t)lane < nsel ? pl[1 + lane] : kEmpty;
+
+        // connect_neighbors (core.rs:759-774): nearest first
+        uint32_t *qrow = row_ptr(g, id, lc);
+        if (lane == 0) qrow[0] = nsel;
+        if ((uint32_t)lane < nsel) {
+            qrow[1 + lane] = myselid;                       // :770
+            uint32_t *nrow = row_ptr(g, myselid, lc);       // :771-772 (id is new: never present)
+            uint32_t c = nrow[0];
+            if (c + 1 > stride - 1) atomicOr(&g.hdr->status, ST_ROW_OVERFLOW);
+            else { nrow[1 + c] = id; nrow[0] = c + 1; atomicMax(maxdeg, c + 1); }
+        }
+        if (lane == 0) atomicMax(maxdeg, nsel);
+        touch_push(touched, touched_cap, nt, myselid, (uint32_t)lane < nsel, lane); // :535-537
+        __threadfence();
+        __syncthreads();
+
+        // shrink loop (core.rs:540-574), e nearest first
+        for (uint32_t si = 0; si < nsel && !fail; ++si) {
+            const uint32_t e = pl[1 + si];
+            uint32_t *erow = row_ptr(g, e, lc);
+            uint32_t cnt = erow[0];
+            if (cnt > stride - 1) cnt = stride - 1;
+            if (cnt <= mmax) { skipped += cnt; continue; }  // :561
+            ctr.n_ids += cnt;
+
+            // econn (core.rs:544-558): sims from e to each of its neighbours
+            QReg<T> qe;
+            load_query<MODE, T>(g.vec + (size_t)e * g.dim, g.dim, qe, m.qlds, lane);
+            uint32_t nE = 0;
+            for (uint32_t base = 0; base < cnt; base += 64) {
+                const uint32_t i = base + lane;
+                const uint32_t nf = cnt - base < 64 ? cnt - base : 64;
+                if (i < cnt) { uint32_t x = erow[1 + i]; m.fresh[lane] = x; m.aux[i] = x; }
+                __syncthreads();
+                compute_dists<MODE, T>(g, qe, m, nf, lane);  // :550
+                ctr.n_dist += nf;
+                __syncthreads();
+                const bool have = (uint32_t)lane < nf;
+                const uint64_t key = have ? pack_key(m.dsc[lane], m.fresh[lane]) : ~0ull;
+                nE = merge_sorted<R>(m.W, nE, R * 64, key, have, lane);
+            }
+            // select_neighbors(e, econn, m_max) (core.rs:568)
+            const uint32_t nS = select_topm<MODE, T>(g, m, vis, qe, m.W, nE, e, mmax, lc, ctr, lane, fail);
+            if (fail) break;
+
+            // update_node_connections (core.rs:776-822).  Final row(e) =
+            // old entries that survive, in their stored order (add_neighbor
+            // leaves them where they are, :793; rm_neighbor keeps order, :808)
+            // followed by the brand-new ones nearest first (:790-796).
+            uint32_t kept = 0;
+            for (uint32_t base = 0; base < cnt; base += 64) {
+                const uint32_t i = base + lane;
+                const uint32_t x = i < cnt ? m.aux[i] : kEmpty;
+                bool inS = false;
+                if (i < cnt)
+                    for (uint32_t j = 0; j < nS; ++j) inS |= key_id(m.S[j]) == x;
+                const uint64_t kb = __ballot(inS);
+                if (inS) erow[1 + kept + __popcll(kb & lanemask_lt(lane))] = x;
+                kept += __popcll(kb);
+                // bidirectionally remove old-but-not-new (:805-819)
+                const bool drop = i < cnt && !inS;
+                if (drop) {
+                    uint32_t *xrow = row_ptr(g, x, lc);
+                    uint32_t xc = xrow[0];
+                    if (xc > stride - 1) xc = stride - 1;
+                    uint32_t p = 0;
+                    while (p < xc && xrow[1 + p] != e) ++p;
+                    if (p == xc) atomicOr(&g.hdr->status, ST_ASYMMETRIC); // reference panics, :150
+                    else {
+                        for (; p + 1 < xc; ++p) xrow[1 + p] = xrow[2 + p];
+                        xrow[0] = xc - 1;
+                    }
+                }
+                touch_push(touched, touched_cap, nt, x, drop, lane); // :816
+            }
+            // new neighbours that were not adjacent before (:790-796)
+            {
+                const uint32_t x = (uint32_t)lane < nS ? key_id(m.S[lane]) : kEmpty;
+                bool isNew = (uint32_t)lane < nS;
+                if (isNew)
+                    for (uint32_t i = 0; i < cnt; ++i) isNew &= m.aux[i] != x;
+                const uint64_t nb = __ballot(isNew);
+                if (isNew) {
+                    erow[1 + kept + __popcll(nb & lanemask_lt(lane))] = x;
+                    uint32_t *xrow = row_ptr(g, x, lc);
+                    uint32_t xc = xrow[0];
+                    if (xc > stride - 1) xc = stride - 1;
+                    bool present = false;
+                    for (uint32_t p = 0; p < xc; ++p) present |= xrow[1 + p] == e;
+                    if (!present) {
+                        if (xc + 1 > stride - 1) atomicOr(&g.hdr->status, ST_ROW_OVERFLOW);
+                        else { xrow[1 + xc] = e; xrow[0] = xc + 1; atomicMax(maxdeg, xc + 1); }
+                    }
+                }
+                kept += __popcll(nb);
+                touch_push(touched, touched_cap, nt, x, (uint32_t)lane < nS, lane); // :796
+            }
+            if (lane == 0) erow[0] = kept;
+            touch_push(touched, touched_cap, nt, e, lane == 0, lane);               // :787
+            __threadfence();
+            __syncthreads();
+        }
+    }
+
+    if (fail && lane == 0) atomicOr(&g.hdr->status, ST_VISITED_OVERFLOW);
+    if (lane == 0) {
+        if (l > lmax) {                                     // core.rs:587-593
+            g.hdr->max_layer = l;
+            g.hdr->enterpoint = (int32_t)id;
+        }
+        g.hdr->node_count = id + 1;
+        g.hdr->n_touched = nt;
+        atomicAdd(&g.hdr->ctr_insert[0], (unsigned long long)ctr.n_dist);
+        atomicAdd(&g.hdr->ctr_insert[1], (unsigned long long)ctr.n_ids);
+        atomicAdd(&g.hdr->ctr_insert[3], (unsigned long long)skipped);
+    }
+    if (vis.glob_dirty) visited_clear(vis, lane);
+}
+
+// ---------------------------------------------------------------------------
+// fast build: commit a planned batch.  One wave per new node links it (both
+// directions, atomics on the row counters); rows pushed past m_max go to a
+// worklist and are pruned to their m_max nearest by k_shrink_batch.  This is
+// NOT the reference's serial order (see include/hnsw_mi355x.h, mode 1).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_link_batch(GraphView g, uint32_t first_id, uint32_t count,
+                                                   uint32_t mlinks, uint32_t lmax_snapshot,
+                                                   const uint32_t *__restrict__ plan, uint32_t *pending0,
+                                                   uint32_t *pendingU, uint32_t *worklist, uint32_t *work_n,
+                                                   uint32_t work_cap)
+{
+    const int lane = threadIdx.x;
+    for (uint32_t s = blockIdx.x; s < count; s += gridDim.x) {
+        const uint32_t id = first_id + s;
+        const uint32_t l = g.levels[id];
+        const uint32_t top = lmax_snapshot < l ? lmax_snapshot : l;
+        for (uint32_t lc = 0; lc <= top; ++lc) {
+            const uint32_t stride = lc ? g.strideU : g.stride0;
+            const uint32_t mmax = lc ? mlinks : 2 * mlinks;
+            const uint32_t *pl = plan + ((size_t)s * kMaxLayers + lc) * kPlanStride;
+            const uint32_t nsel = pl[0];
+            uint32_t *qrow = row_ptr(g, id, lc);
+            if (lane == 0) qrow[0] = nsel;
+            if ((uint32_t)lane < nsel) {
+                const uint32_t e = pl[1 + lane];
+                qrow[1 + lane] = e;
+                uint32_t *erow = row_ptr(g, e, lc);
+                const uint32_t c = atomicAdd(&erow[0], 1u);
+                if (c + 1 > stride - 1) {
+                    atomicSub(&erow[0], 1u);
+                    atomicOr(&g.hdr->status, ST_ROW_DROPPED);
+                } else {
+                    erow[1 + c] = id;
+                    if (c + 1 > mmax) {
+                        uint32_t *pend = lc ? &pendingU[g.upper_base[e] + lc - 1] : &pending0[e];
+                        if (atomicExch(pend, 1u) == 0u) {
+                            uint32_t w = atomicAdd(work_n, 1u);
+                            if (w < work_cap) { worklist[2 * w] = e; worklist[2 * w + 1] = lc; }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// prune row (e, lc) to its m_max nearest (by the engine's (dist, id) order)
+template <int MODE, int T>
+__global__ __launch_bounds__(64) void k_shrink_batch(GraphView g, uint32_t mlinks, const uint32_t *__restrict__ worklist,
+                                                     const uint32_t *__restrict__ work_n, uint32_t work_cap,
+                                                     uint32_t *pending0, uint32_t *pendingU)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    WaveMem m;
+    m.W = reinterpret_cast<uint64_t *>(smem);            // [128] keys
+    m.fresh = reinterpret_cast<uint32_t *>(smem + 128 * 8);
+    m.dsc = reinterpret_cast<float *>(smem + 128 * 8 + 64 * 4);
+    m.qlds = reinterpret_cast<float *>(smem + 128 * 8 + 64 * 8);
+    m.S = nullptr;
+    m.aux = nullptr;
+    uint32_t nwork = *work_n;
+    if (nwork > work_cap) nwork = work_cap;
+    unsigned long long ndist = 0;
+    for (uint32_t w = blockIdx.x; w < nwork; w += gridDim.x) {
+        const uint32_t e = worklist[2 * w], lc = worklist[2 * w + 1];
+        const uint32_t stride = lc ? g.strideU : g.stride0;
+        const uint32_t mmax = lc ? mlinks : 2 * mlinks;
+        uint32_t *erow = row_ptr(g, e, lc);
+        uint32_t cnt = erow[0];
+        if (cnt > stride - 1) cnt = stride - 1;
+        if (lane == 0) {
+            if (lc) pendingU[g.upper_base[e] + lc - 1] = 0u; else pending0[e] = 0u;
+        }
+        if (cnt <= mmax) continue;
+        QReg<T> qe;
+        __syncthreads();
+        load_query<MODE, T>(g.vec + (size_t)e * g.dim, g.dim, qe, m.qlds, lane);
+        uint32_t nE = 0;
+        for (uint32_t base = 0; base < cnt; base += 64) {
+            const uint32_t i = base + lane;
+            const uint32_t nf = cnt - base < 64 ? cnt - base : 64;
+            if (i < cnt) m.fresh[lane] = erow[1 + i];
+            __syncthreads();
+            compute_dists<MODE, T>(g, qe, m, nf, lane);
+            ndist += nf;
+            __syncthreads();
+            const bool have = (uint32_t)lane < nf;
+            const uint64_t key = have ? pack_key(m.dsc[lane], m.fresh[lane]) : ~0ull;
+            nE = merge_sorted<2>(m.W, nE, 128, key, have, lane);
+        }
+        const uint32_t keep = nE < mmax ? nE : mmax;
+        for (uint32_t i = lane; i < keep; i += 64) erow[1 + i] = key_id(m.W[i]);
+        if (lane == 0) {
+            erow[0] = keep;
+            atomicMax(lc ? &g.hdr->max_degU : &g.hdr->max_deg0, keep);
+        }
+        __syncthreads();
+    }
+    if (lane == 0 && ndist) atomicAdd(&g.hdr->ctr_insert[0], ndist);
+}
+
+__global__ void k_batch_finish(DevHeader *hdr, uint32_t node_count, uint32_t max_layer, int32_t enterpoint,
+                               uint32_t *work_n)
+{
+    hdr->node_count = node_count;
+    hdr->max_layer = max_layer;
+    hdr->enterpoint = enterpoint;
+    *work_n = 0;
+}
+
+} // namespace hnsw

@@ -1,0 +1,192 @@
+// hnsw_kernels.hpp -- __global__ kernels of the MI355X HNSW engine (gfx950).
+#pragma once
+#include "hnsw_device.hpp"
+
+namespace hnsw {
+
+// ---------------------------------------------------------------------------
+// HNSW.SEARCH (core.rs:477-486 -> search_knn_internal :865-892), one wave per
+// query, grid-stride over the batch.
+// ---------------------------------------------------------------------------
+template <int MODE, int T, int R>
+__global__ __launch_bounds__(64) void k_search(GraphView g, const float *__restrict__ Q, uint32_t B,
+                                               uint32_t k, uint32_t ef, uint32_t lbits,
+                                               uint32_t *__restrict__ gspill, uint32_t gbits,
+                                               uint32_t *__restrict__ out_ids, float *__restrict__ out_sims,
+                                               uint32_t *__restrict__ out_n)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    WaveMem m;
+    Visited vis;
+    carve<R, T>(smem, g.dim, lbits, m, vis);
+    vis.glob = gspill + ((size_t)blockIdx.x << gbits);
+    vis.gbits = gbits;
+    vis.glob_dirty = false;
+    vis.spilled = false;
+    vis.count = 0;
+
+    WorkCtr ctr = {0, 0, 0};
+    const int32_t ep0 = g.hdr->enterpoint;        // core.rs:866
+    const uint32_t lmax = g.hdr->max_layer;       // core.rs:867
+
+    for (uint32_t qi = blockIdx.x; qi < B; qi += gridDim.x) {
+        QReg<T> qr;
+        load_query<MODE, T>(Q + (size_t)qi * g.dim, g.dim, qr, m.qlds, lane);
+        bool fail = false;
+        uint32_t ep = (uint32_t)ep0;
+        for (uint32_t lc = lmax; lc >= 1 && !fail; --lc) {  // core.rs:870-874
+            search_level<MODE, T, 1>(g, m, vis, qr, ep, 1, lc, ctr, lane, fail);
+            ep = key_id(m.W[0]);                          // core.rs:872
+            __syncthreads();
+        }
+        uint32_t nW = 0;
+        if (!fail) nW = search_level<MODE, T, R>(g, m, vis, qr, ep, ef, 0, ctr, lane, fail); // core.rs:876
+        if (fail) {
+            nW = 0;
+            if (lane == 0) atomicOr(&g.hdr->status, ST_VISITED_OVERFLOW);
+        }
+        // core.rs:878-890: nearest first, min(k, |W|) results; sim = -dist (metrics.rs:75)
+        const uint32_t nres = nW < k ? nW : k;
+        for (uint32_t i = lane; i < k; i += 64) {
+            uint64_t key = i < nres ? m.W[i] : 0;
+            out_ids[(size_t)qi * k + i] = i < nres ? key_id(key) : kEmpty;
+            out_sims[(size_t)qi * k + i] = i < nres ? -key_dist(key) : -__builtin_inff();
+        }
+        if (lane == 0) out_n[qi] = fail ? kEmpty : nres;
+        __syncthreads();
+    }
+    // leave the HBM spill table clean for the next launch
+    if (vis.glob_dirty) visited_clear(vis, lane);
+    if (lane == 0) {
+        atomicAdd(&g.hdr->ctr_search[0], (unsigned long long)ctr.n_dist);
+        atomicAdd(&g.hdr->ctr_search[1], (unsigned long long)ctr.n_ids);
+        atomicAdd(&g.hdr->ctr_search[2], (unsigned long long)ctr.n_expand);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// the metric on its own (metrics.rs:14-23), for the known-answer tests
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(64) void k_metric_pairs(const float *__restrict__ a, const float *__restrict__ b,
+                                                     uint32_t n, uint32_t dim, float *__restrict__ sims)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    WaveMem m;
+    m.qlds = reinterpret_cast<float *>(smem);
+    m.fresh = reinterpret_cast<uint32_t *>(smem + (((size_t)dim * 4 + 15) & ~(size_t)15));
+    m.dsc = reinterpret_cast<float *>(m.fresh + 64);
+    GraphView g = {};
+    g.vec = b;
+    g.dim = dim;
+    QReg<0> qr;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        __syncthreads();
+        load_query<MODE, 0>(a + (size_t)i * dim, dim, qr, m.qlds, lane);
+        if (lane == 0) m.fresh[0] = i;
+        __syncthreads();
+        compute_dists<MODE, 0>(g, qr, m, 1, lane);
+        __syncthreads();
+        if (lane == 0) sims[i] = -m.dsc[0];
+    }
+}
+
+// same pair metric through the register-resident (T > 0) path the search uses
+template <int T>
+__global__ __launch_bounds__(64) void k_metric_pairs_reg(const float *__restrict__ a, const float *__restrict__ b,
+                                                         uint32_t n, float *__restrict__ sims)
+{
+    __shared__ uint32_t fresh[64];
+    __shared__ float dsc[64];
+    const int lane = threadIdx.x;
+    WaveMem m = {};
+    m.fresh = fresh;
+    m.dsc = dsc;
+    GraphView g = {};
+    g.vec = b;
+    g.dim = T * 32;
+    for (uint32_t base = blockIdx.x * 64; base < n; base += gridDim.x * 64) {
+        // 64 pairs per pass share nothing: recompute the query registers per pair group
+        for (uint32_t j = 0; j < 64 && base + j < n; ++j) {
+            QReg<T> qr;
+            load_query<MODE_AVX, T>(a + (size_t)(base + j) * g.dim, g.dim, qr, nullptr, lane);
+            __syncthreads();
+            // fill several slots with the same id so every 8-lane group position is exercised
+            uint32_t nf = 1 + (j % 19);
+            if ((uint32_t)lane < nf) fresh[lane] = base + j;
+            __syncthreads();
+            compute_dists<MODE_AVX, T>(g, qr, m, nf, lane);
+            __syncthreads();
+            if (lane == 0) sims[base + j] = -dsc[j % nf];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// bulk import: CSR rows -> fixed-stride rows
+// ---------------------------------------------------------------------------
+__global__ void k_import_rows(uint32_t *adj, uint32_t stride, const uint32_t *__restrict__ slot_of_node,
+                              uint32_t layer_off, const uint32_t *__restrict__ levels, uint32_t layer,
+                              const uint64_t *__restrict__ rp, const uint32_t *__restrict__ col, uint32_t n)
+{
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= n) return;
+    if (levels[wave] < layer) return;
+    const uint32_t slot = slot_of_node ? slot_of_node[wave] : wave;
+    if (slot_of_node && slot == kNoUpper) return;
+    const uint64_t b = rp[wave], e = rp[wave + 1];
+    uint32_t *row = adj + (size_t)(slot + layer_off) * stride;
+    uint32_t cnt = (uint32_t)(e - b);
+    if (cnt > stride - 1) cnt = stride - 1;
+    if (lane == 0) row[0] = cnt;
+    for (uint32_t i = lane; i < cnt; i += 64) row[1 + i] = col[b + i];
+}
+
+// re-stride an adjacency table (rows keep their content)
+__global__ void k_restride(const uint32_t *__restrict__ src, uint32_t sstride, uint32_t *__restrict__ dst,
+                           uint32_t dstride, uint64_t rows)
+{
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= rows) return;
+    const uint32_t *s = src + wave * sstride;
+    uint32_t *d = dst + wave * dstride;
+    const uint32_t n = sstride < dstride ? sstride : dstride;
+    for (uint32_t i = lane; i < dstride; i += 64) d[i] = i < n ? s[i] : 0u;
+}
+
+// per-row degrees of one layer (export)
+__global__ void k_degrees(const uint32_t *__restrict__ adj, uint32_t stride, const uint32_t *__restrict__ slot_of_node,
+                          uint32_t layer_off, const uint32_t *__restrict__ levels, uint32_t layer, uint32_t n,
+                          uint32_t *__restrict__ deg)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t d = 0;
+    if (levels[i] >= layer) {
+        uint32_t slot = slot_of_node ? slot_of_node[i] : i;
+        if (!(slot_of_node && slot == kNoUpper)) d = adj[(size_t)(slot + layer_off) * stride];
+    }
+    deg[i] = d;
+}
+
+__global__ void k_export_rows(const uint32_t *__restrict__ adj, uint32_t stride,
+                              const uint32_t *__restrict__ slot_of_node, uint32_t layer_off,
+                              const uint32_t *__restrict__ levels, uint32_t layer, uint32_t n,
+                              const uint64_t *__restrict__ rp, uint32_t *__restrict__ col)
+{
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= n) return;
+    if (levels[wave] < layer) return;
+    uint32_t slot = slot_of_node ? slot_of_node[wave] : wave;
+    if (slot_of_node && slot == kNoUpper) return;
+    const uint32_t *row = adj + (size_t)(slot + layer_off) * stride;
+    const uint32_t cnt = (uint32_t)(rp[wave + 1] - rp[wave]);
+    for (uint32_t i = lane; i < cnt; i += 64) col[rp[wave] + i] = row[1 + i];
+}
+
+} // namespace hnsw

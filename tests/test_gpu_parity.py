@@ -1,0 +1,241 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle.
+
+Bit-exact: ids, similarities (compared as raw f32 bits), work counters and --
+for the exact insert -- every adjacency row in stored order.
+"""
+import numpy as np
+import pytest
+
+from tests.util import brute_force_topk, build_oracle, graphs_equal, make_data, recall_at_k
+
+pytestmark = pytest.mark.gpu
+EPS = float(np.finfo(np.float32).eps)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import redis_hnsw_amd
+    from redis_hnsw_amd import index as idxmod
+    return idxmod
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+# ---- metric: metrics_tests.rs on the device ----------------------------------
+def test_metric_kats_on_device(eng):
+    z, o, big = np.zeros((1, 512), np.float32), np.ones((1, 512), np.float32), np.full((1, 512), 512.0, np.float32)
+    assert abs(eng.metric_pairs(o, o)[0] - 0.0) < EPS                 # diff_is_zero
+    assert abs(eng.metric_pairs(z, o)[0] - -512.0) < EPS              # diff_is_512
+    assert abs(eng.metric_pairs(z, big)[0] - -134217728.0) < EPS      # diff_is_512_2_x512
+    a, b = np.zeros((1, 33), np.float32), np.ones((1, 33), np.float32)
+    assert abs(eng.metric_pairs(a, b)[0] - -33.0) < EPS               # diff_non_x32 (scalar order)
+
+
+@pytest.mark.parametrize("dim", [32, 64, 128, 256, 768, 4, 33, 100])
+def test_metric_bit_exact(eng, oracle_mod, dim):
+    rng = np.random.default_rng(dim)
+    n = 300
+    a = rng.random((n, dim), dtype=np.float32)
+    b = rng.random((n, dim), dtype=np.float32)
+    # wide dynamic range + exact zeros + denormal-sized differences
+    a[:50] *= 1e3
+    b[50:60] = a[50:60]
+    a[60:70] = b[60:70] + np.float32(1e-22)
+    got = eng.metric_pairs(a, b)
+    want = np.array([oracle_mod.euclidean(a[i], b[i]) for i in range(n)], dtype=np.float32)
+    assert np.array_equal(_bits(got), _bits(want))
+
+
+# ---- search parity on an oracle-built graph -----------------------------------
+CONFIGS = [
+    # n, dim, m, ef, k, nq
+    (1200, 32, 5, 16, 5, 64),
+    (600, 4, 5, 16, 5, 64),       # scalar metric order (dim % 32 != 0)
+    (2000, 128, 16, 200, 10, 128),
+    (1500, 64, 8, 100, 10, 64),   # AVX order, generic dim
+    (900, 768, 32, 400, 100, 32),
+    (300, 128, 16, 200, 10, 16),  # index smaller than ef... reachable < ef
+]
+
+
+@pytest.fixture(scope="module")
+def built(oracle_mod):
+    cache = {}
+
+    def get(n, dim, m, ef):
+        key = (n, dim, m, ef)
+        if key not in cache:
+            V = make_data(n, dim, seed=1)
+            o, lv = build_oracle(oracle_mod, V, m, ef)
+            cache[key] = (V, o, lv)
+        return cache[key]
+    return get
+
+
+@pytest.mark.parametrize("n,dim,m,ef,k,nq", CONFIGS)
+def test_search_parity(eng, oracle_mod, built, n, dim, m, ef, k, nq):
+    V, o, lv = built(n, dim, m, ef)
+    g = o.export()
+    gi = eng.Index("foo", dim, m, ef)
+    gi.import_graph(g)
+    assert gi.node_count == n and gi.max_layer == o.max_layer and gi.enterpoint_id == o.enterpoint
+    Q = make_data(nq, dim, seed=2)
+    gi.reset_counters()
+    ids, sims, n_out = gi.search_batch(Q, k)
+    oids, osims, on, oct = o.search_batch(Q, k)
+    assert np.array_equal(n_out, on)
+    for i in range(nq):
+        c = int(on[i])
+        assert np.array_equal(ids[i, :c], oids[i, :c]), "query %d ids" % i
+        assert np.array_equal(_bits(sims[i, :c]), _bits(osims[i, :c])), "query %d sims" % i
+        assert np.all(ids[i, c:] == 0xFFFFFFFF)
+    sc, _ = gi.counters()
+    assert (sc.n_dist, sc.n_ids, sc.n_expand) == (oct.n_dist, oct.n_ids, oct.n_expand)
+    # identical recall@k by construction; check it anyway against brute force
+    kk = min(k, 10)
+    gt = brute_force_topk(V, Q, kk)
+    assert recall_at_k(ids, gt) == recall_at_k(oids, gt)
+    # single-query entry point agrees with the batch one
+    r = gi.search_knn(Q[0], k)
+    assert [x.id for x in r] == ids[0, : int(n_out[0])].tolist()
+    gi.close()
+
+
+def test_search_visited_spill_is_exact(eng, oracle_mod, built):
+    """A tiny LDS visited table forces the HBM spill path; results must not change."""
+    n, dim, m, ef, k, nq = 2000, 128, 16, 200, 10, 64
+    V, o, lv = built(n, dim, m, ef)
+    gi = eng.Index("foo", dim, m, ef)
+    gi.import_graph(o.export())
+    Q = make_data(nq, dim, seed=3)
+    gi.set_tuning("lds_hash_bits", 8)
+    gi.reset_counters()
+    ids, sims, n_out = gi.search_batch(Q, k)
+    sc, _ = gi.counters()
+    assert sc.n_spill > 0
+    oids, osims, on, oct = o.search_batch(Q, k)
+    assert np.array_equal(ids, oids) and np.array_equal(_bits(sims), _bits(osims))
+    assert sc.n_dist == oct.n_dist
+    # and a second launch on the same (now used) spill tables is still exact
+    ids2, sims2, _ = gi.search_batch(Q, k)
+    assert np.array_equal(ids2, oids)
+    gi.close()
+
+
+def test_export_round_trip(eng, oracle_mod, built):
+    V, o, lv = built(1200, 32, 5, 16)
+    g = o.export()
+    gi = eng.Index("foo", 32, 5, 16)
+    gi.import_graph(g)
+    g2 = gi.export_graph(with_vectors=False)
+    ok, why = graphs_equal(g, g2)
+    assert ok, why
+    assert gi.neighbors(0, 0).tolist() == o.neighbors(0, 0).tolist()
+    gi.close()
+
+
+# ---- core_tests.rs hnsw_test through the GPU ------------------------------------
+def test_hnsw_test_reference_kat(eng):
+    """core_tests.rs:12-53 with the engine in place of Index<f32,f32>."""
+    index = eng.Index("foo", 4, 5, 16, seed=3)
+    assert index.name == "foo" and index.data_dim == 4 and index.m == 5 and index.ef_construction == 16
+    assert index.node_count == 0 and index.max_layer == 0 and index.enterpoint is None
+    assert index.search_knn(np.zeros(4, np.float32), 5) == []       # core.rs:481-483
+    calls = []
+    for i in range(100):
+        index.add_node("node%d" % i, np.full(4, float(i), np.float32), lambda s, n: calls.append(s))
+    assert index.node_count == 100 and index.enterpoint is not None
+    res = index.search_knn(np.full(4, 10.0, np.float32), 5)
+    assert len(res) == 5
+    assert abs(res[0].sim - 0.0) < EPS and res[0].name == "node10"
+    for r, want in zip(res[1:], [-4.0, -4.0, -16.0, -16.0]):
+        assert abs(r.sim - want) < EPS
+    assert len(calls) > 0
+    index.close()
+
+
+def test_errors_match_reference(eng):
+    from redis_hnsw_amd import HNSWError
+    index = eng.Index("foo", 4, 5, 16)
+    with pytest.raises(HNSWError) as e:
+        index.add_node("a", np.zeros(3, np.float32))
+    assert e.value.error_string() == 'String("data dimension: 3 does not match Index")'   # core.rs:390
+    index.add_node("a", np.zeros(4, np.float32))
+    index.add_node("b", np.ones(4, np.float32))
+    with pytest.raises(HNSWError) as e:
+        index.add_node("b", np.ones(4, np.float32))
+    assert e.value.error_string() == 'String("Node: \\"b\\" already exists")'             # core.rs:408
+    with pytest.raises(HNSWError) as e:
+        index.search_knn(np.zeros(5, np.float32), 1)
+    assert e.value.error_string() == 'String("data dimension: 5 does not match Index")'   # core.rs:479
+    # k larger than the index: min(k, ef, reachable) results (core.rs:878-890)
+    assert len(index.search_knn(np.zeros(4, np.float32), 10)) == 2
+    index.close()
+
+
+# ---- exact insert: link-for-link identical graphs ---------------------------------
+@pytest.mark.parametrize("n,dim,m,ef", [(400, 32, 5, 16), (700, 128, 16, 200), (300, 4, 5, 16), (500, 64, 6, 40)])
+def test_exact_insert_builds_identical_graph(eng, oracle_mod, n, dim, m, ef):
+    V = make_data(n, dim, seed=11)
+    lv = oracle_mod.draw_levels(n, m, 5)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    gi = eng.Index("foo", dim, m, ef)
+    for i in range(n):
+        if i % 7 == 0:   # compare the touched sets on a sample
+            oid, ot = o.add(V[i], int(lv[i]), want_touched=True)
+            got = []
+            gi.add_node("node%d" % i, V[i], lambda s, nid: got.append(nid), level=int(lv[i]))
+            assert sorted(got) == sorted(ot.tolist()), "touched set of insert %d" % i
+        else:
+            o.add(V[i], int(lv[i]))
+            gi.add_node("node%d" % i, V[i], level=int(lv[i]))
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    # the work accounting matches too: evaluations done + the econn evaluations skipped
+    _, ic = gi.counters()
+    oc = o.insert_counters()
+    assert ic.n_dist + ic.n_spill == oc.n_dist
+    gi.close()
+
+
+def test_exact_batch_insert_equals_oracle(eng, oracle_mod):
+    n, dim, m, ef = 600, 128, 16, 200
+    V = make_data(n, dim, seed=12)
+    lv = oracle_mod.draw_levels(n, m, 9)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch(V, lv)
+    gi = eng.Index("foo", dim, m, ef)
+    gi.add_batch(V, levels=lv, mode="exact")
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    Q = make_data(32, dim, seed=2)
+    ids, sims, _ = gi.search_batch(Q, 10)
+    oids, osims, _, _ = o.search_batch(Q, 10)
+    assert np.array_equal(ids, oids) and np.array_equal(_bits(sims), _bits(osims))
+    gi.close()
+
+
+# ---- fast build: recall parity ------------------------------------------------------
+def test_fast_build_recall_parity(eng, oracle_mod, built):
+    n, dim, m, ef, k = 6000, 32, 16, 200, 10
+    V = make_data(n, dim, seed=1)
+    o, lv = build_oracle(oracle_mod, V, m, ef)
+    Q = make_data(256, dim, seed=2)
+    gt = brute_force_topk(V, Q, k)
+    oids, _, _, _ = o.search_batch(Q, k)
+    r_ref = recall_at_k(oids, gt)
+    gi = eng.Index("foo", dim, m, ef)
+    gi.add_batch(V, levels=lv, mode="fast")
+    assert gi.node_count == n
+    ids, sims, n_out = gi.search_batch(Q, k)
+    r_fast = recall_at_k(ids, gt)
+    assert r_fast >= r_ref - 0.02, (r_fast, r_ref)
+    # the GPU search on the GPU-built graph is still exactly what the oracle's search does on that graph
+    g = gi.export_graph(with_vectors=False)
+    g["vectors"] = V
+    o2 = oracle_mod.OracleIndex.from_graph(dim, m, ef, g)
+    oids2, osims2, _, _ = o2.search_batch(Q, k)
+    assert np.array_equal(ids, oids2) and np.array_equal(_bits(sims), _bits(osims2))
+    gi.close()
