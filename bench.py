@@ -70,6 +70,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    def log(msg):
+        if rank == 0:
+            print("[bench %.1fs] %s" % (time.time() - t00, msg), file=sys.stderr, flush=True)
+
+    t00 = time.time()
     from redis_hnsw_amd import Index
     N, dim, M, ef, k, B = args.nodes, args.dim, args.m, args.ef, args.k, args.batch
     t0 = time.time()
@@ -87,6 +92,7 @@ def main():
         index.add_batch(V, levels=levels, mode=args.build)
         torch.cuda.synchronize()
         t_build = time.time() - tb
+        log("built %d nodes in %.2f s (%s)" % (N, t_build, args.build))
         if world > 1 or not args.no_cpu_baseline:
             graph = index.export_graph(with_vectors=False)
     if world > 1:
@@ -133,6 +139,7 @@ def main():
             dist.all_gather_into_tensor(g_ids, d_ids)
             dist.all_gather_into_tensor(g_sims, d_sims)
 
+    log("inputs resident; warm-up")
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -155,6 +162,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_wall = float(tt.item())
     stream_ms = ev0.elapsed_time(ev1)
+    log("timed region done: %.3f ms/step" % (1e3 * t_wall / args.steps))
     sc, _ = index.counters()
 
     # ---- recall@k against brute force (rank 0's batches) ------------------------------
@@ -174,6 +182,7 @@ def main():
                 hits += len(set(a.tolist()) & set(bb.tolist()))
                 tot += k
         recall = hits / tot
+        log("recall@%d = %.4f" % (k, recall))
         del V_dev
 
     if rank != 0:

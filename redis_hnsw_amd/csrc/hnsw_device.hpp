@@ -274,28 +274,22 @@ __device__ __forceinline__ void visited_clear(Visited &v, int lane)
 }
 
 // true if id was not in the set (and is now).  Lanes of one wave may call this
-// concurrently with distinct ids.
+// concurrently with distinct ids.  Probing is bounded by the table size: a full
+// table reports "seen" instead of spinning (visited_reserve keeps tables <= 7/8
+// full, so this is a guard, not a code path).
 __device__ __forceinline__ bool visited_insert(const Visited &v, uint32_t id)
 {
-    if (!v.spilled) {
-        const uint32_t mask = (1u << v.lbits) - 1u;
-        uint32_t h = hash_slot(id, v.lbits);
-        for (;;) {
-            uint32_t old = atomicCAS(&v.lds[h], kEmpty, id);
-            if (old == kEmpty) return true;
-            if (old == id) return false;
-            h = (h + 1) & mask;
-        }
-    } else {
-        const uint32_t mask = (1u << v.gbits) - 1u;
-        uint32_t h = hash_slot(id, v.gbits);
-        for (;;) {
-            uint32_t old = atomicCAS(&v.glob[h], kEmpty, id);
-            if (old == kEmpty) return true;
-            if (old == id) return false;
-            h = (h + 1) & mask;
-        }
+    uint32_t *t = v.spilled ? v.glob : v.lds;
+    const uint32_t bits = v.spilled ? v.gbits : v.lbits;
+    const uint32_t mask = (1u << bits) - 1u;
+    uint32_t h = hash_slot(id, bits);
+    for (uint32_t probe = 0; probe <= mask; ++probe) {
+        uint32_t old = atomicCAS(&t[h], kEmpty, id);
+        if (old == kEmpty) return true;
+        if (old == id) return false;
+        h = (h + 1) & mask;
     }
+    return false;
 }
 
 __device__ __forceinline__ bool visited_contains(const Visited &v, uint32_t id)
@@ -304,29 +298,32 @@ __device__ __forceinline__ bool visited_contains(const Visited &v, uint32_t id)
     const uint32_t bits = v.spilled ? v.gbits : v.lbits;
     const uint32_t mask = (1u << bits) - 1u;
     uint32_t h = hash_slot(id, bits);
-    for (;;) {
+    for (uint32_t probe = 0; probe <= mask; ++probe) {
         uint32_t cur = t[h];
         if (cur == kEmpty) return false;
         if (cur == id) return true;
         h = (h + 1) & mask;
     }
+    return false;
 }
 
 // Make room for up to 64 more ids.  Returns false if even the HBM table is full.
 __device__ __forceinline__ bool visited_reserve(Visited &v, int lane, unsigned long long *spill_ctr)
 {
+    const uint32_t gcap = 1u << v.gbits;
     if (!v.spilled) {
         const uint32_t cap = 1u << v.lbits;
         if (v.count + 64 <= cap - (cap >> 3)) return true;
+        if (v.count + 64 > gcap - (gcap >> 3)) return false;   // would not fit there either
         // move every entry to the HBM table and continue there
-        const uint32_t gmask = (1u << v.gbits) - 1u;
+        const uint32_t gmask = gcap - 1u;
         for (uint32_t i = lane; i < cap; i += 64) {
             uint32_t id = v.lds[i];
             if (id != kEmpty) {
                 uint32_t h = hash_slot(id, v.gbits);
-                for (;;) {
+                for (uint32_t probe = 0; probe <= gmask; ++probe) {
                     uint32_t old = atomicCAS(&v.glob[h], kEmpty, id);
-                    if (old == kEmpty) break;
+                    if (old == kEmpty || old == id) break;
                     h = (h + 1) & gmask;
                 }
             }
@@ -337,7 +334,6 @@ __device__ __forceinline__ bool visited_reserve(Visited &v, int lane, unsigned l
         v.glob_dirty = true;
         if (lane == 0 && spill_ctr) atomicAdd(spill_ctr, 1ull);
     }
-    const uint32_t gcap = 1u << v.gbits;
     return v.count + 64 <= gcap - (gcap >> 3);
 }
 

@@ -44,7 +44,7 @@ struct hnsw_index {
     uint32_t *d_work = nullptr;     // fast build: shrink worklist
     uint32_t work_cap = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_sync = nullptr;
     bool ev_valid = false;
     int lds_bits_override = -1;
     int grid_override = -1;
@@ -248,11 +248,15 @@ uint32_t pick_lbits(const hnsw_index *h, int R, int T)
 
 hnsw_status ensure_spill(hnsw_index *h)
 {
+    // A visited set never holds more ids than the index has nodes, nor (much)
+    // more than ef * row width; twice the smaller bound keeps the load <= 1/2.
+    // Sized from the node CAPACITY so that it stays valid while the index grows.
     uint64_t want = 4ull * h->efc * std::max(h->stride0, 16u);
-    want = std::min<uint64_t>(want, 2ull * std::max(h->n, 1024u));
+    want = std::min<uint64_t>(want, 2ull * std::max(h->cap, 1024u));
     uint32_t gbits = std::max(10u, ceil_log2(want));
     const uint32_t slots = 2048;
     if (h->d_spill && h->spill_gbits >= gbits && h->spill_slots >= slots) return HNSW_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     dev_free(h, h->d_spill, (size_t)h->spill_slots << h->spill_gbits);
     hnsw_status s = dev_alloc(h, &h->d_spill, (size_t)slots << gbits, 0xFF);
     if (s != HNSW_OK) return s;
@@ -414,6 +418,7 @@ hnsw_status hnsw_create(uint32_t dim, uint32_t m, uint32_t ef_construction, uint
     HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIP_TRY(h, hipEventCreate(&h->ev0));
     HIP_TRY(h, hipEventCreate(&h->ev1));
+    HIP_TRY(h, hipEventCreateWithFlags(&h->ev_sync, hipEventDisableTiming));
     h->stride0 = default_stride(h->m_max0, m, 0);
     h->strideU = default_stride(h->m_max, m, 0);
     hnsw_status s;
@@ -438,6 +443,7 @@ void hnsw_destroy(hnsw_index *h)
     (void)hipFree(h->d_nout); (void)hipFree(h->d_plan); (void)hipFree(h->d_touched); (void)hipFree(h->d_work);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev_sync) (void)hipEventDestroy(h->ev_sync);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -571,6 +577,14 @@ hnsw_status hnsw_search_batch_device(hnsw_index *h, const float *dQ, uint32_t B,
     if (k == 0) return fail(h, HNSW_ERR_INVALID, "k must be >= 1");
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
+    hnsw_status s0 = ensure_spill(h);
+    if (s0 != HNSW_OK) return s0;
+    if (st != h->stream) {
+        // the index was written (build / import / scratch fills) on the engine's
+        // own stream: order the caller's stream after it
+        HIP_TRY(h, hipEventRecord(h->ev_sync, h->stream));
+        HIP_TRY(h, hipStreamWaitEvent(st, h->ev_sync, 0));
+    }
     if (h->n == 0 || h->enterpoint < 0) {        // core.rs:481-483
         HIP_TRY(h, hipMemsetAsync(d_n_out, 0, (size_t)B * 4, st));
         HIP_TRY(h, hipMemsetAsync(d_ids, 0xFF, (size_t)B * k * 4, st));
