@@ -58,7 +58,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB_PATH
+    path = os.environ.get("HNSW_MI355X_LIB", _build.LIB_PATH)  # override: instrumented dev builds
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} is missing: build it with `python -m redis_hnsw_amd.build` "

@@ -37,6 +37,7 @@ struct DevHeader {
     uint32_t pad;
     unsigned long long ctr_search[4]; // n_dist, n_ids, n_expand, n_spill
     unsigned long long ctr_insert[4];
+    unsigned long long prof[8];       // HNSW_PHASE_TIMERS builds: cycles per phase
 };
 
 struct GraphView {
@@ -434,7 +435,22 @@ __device__ __forceinline__ void carve(unsigned char *smem, uint32_t dim, uint32_
 
 struct WorkCtr {
     uint32_t n_dist, n_ids, n_expand;
+#ifdef HNSW_PHASE_TIMERS
+    unsigned long long ph[8];
+#endif
 };
+#ifdef HNSW_PHASE_TIMERS
+#define PH_T0() unsigned long long ph_t_ = __builtin_readcyclecounter()
+#define PH_MARK(ctr, i)                                              \
+    do {                                                             \
+        unsigned long long n_ = __builtin_readcyclecounter();        \
+        (ctr).ph[i] += n_ - ph_t_;                                   \
+        ph_t_ = n_;                                                  \
+    } while (0)
+#else
+#define PH_T0() do {} while (0)
+#define PH_MARK(ctr, i) do {} while (0)
+#endif
 
 // ---------------------------------------------------------------------------
 // search_level (core.rs:607-675).  W doubles as C: an entry is a live
@@ -462,6 +478,7 @@ __device__ uint32_t search_level(const GraphView &g, const WaveMem &m, Visited &
     __syncthreads();
     const uint32_t stride = lc ? g.strideU : g.stride0;
 
+    PH_T0();
     for (;;) {
         const int pos = find_unexpanded<R>(m.W, nW, lane); // core.rs:631
         if (pos < 0) break;                               // core.rs:630,635
@@ -476,6 +493,7 @@ __device__ uint32_t search_level(const GraphView &g, const WaveMem &m, Visited &
         uint32_t cnt = __builtin_amdgcn_readfirstlane(word);
         if (cnt > stride - 1) cnt = stride - 1;
         ctr.n_ids += cnt;
+        PH_MARK(ctr, 0);  // pop + adjacency row fetch
         for (uint32_t wbase = 0; wbase <= cnt; wbase += 64) { // core.rs:646 stored order
             const uint32_t wi = wbase + lane;
             if (wbase) word = wi < stride ? row[wi] : 0u;
@@ -484,6 +502,7 @@ __device__ uint32_t search_level(const GraphView &g, const WaveMem &m, Visited &
             const bool fresh = valid && visited_insert(vis, word); // core.rs:648-649
             const uint64_t fm = __ballot(fresh);
             const uint32_t nf = __popcll(fm);
+            PH_MARK(ctr, 1);  // visited filter
             if (nf == 0) continue;
             if (fresh) m.fresh[__popcll(fm & lanemask_lt(lane))] = word;
             vis.count += nf;
@@ -493,9 +512,11 @@ __device__ uint32_t search_level(const GraphView &g, const WaveMem &m, Visited &
             __syncthreads();
             const bool have = (uint32_t)lane < nf;
             const uint64_t key = have ? pack_key(m.dsc[lane], m.fresh[lane]) : ~0ull;
+            PH_MARK(ctr, 2);  // vector gather + distances
             const uint64_t worst = nW == ef ? m.W[ef - 1] : ~0ull; // core.rs:651
             const bool take = have && key < worst;          // core.rs:657
             nW = merge_sorted<R>(m.W, nW, ef, key, take, lane); // core.rs:659-664
+            PH_MARK(ctr, 3);  // merge into W
         }
         __syncthreads();
     }

@@ -830,7 +830,18 @@ hnsw_status hnsw_reset_counters(hnsw_index *h)
     if (!h) return HNSW_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipDeviceSynchronize());
-    HIP_TRY(h, hipMemset((char *)h->d_hdr + offsetof(DevHeader, ctr_search), 0, sizeof(unsigned long long) * 8));
+    HIP_TRY(h, hipMemset((char *)h->d_hdr + offsetof(DevHeader, ctr_search), 0, sizeof(unsigned long long) * 16));
+    return HNSW_OK;
+}
+
+// cycles per search phase (only filled by -DHNSW_PHASE_TIMERS builds; not in the public header)
+hnsw_status hnsw_debug_phase_cycles(hnsw_index *h, uint64_t *out8)
+{
+    if (!h || !out8) return HNSW_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    DevHeader hd;
+    HIP_TRY(h, hipMemcpy(&hd, h->d_hdr, sizeof hd, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; ++i) out8[i] = hd.prof[i];
     return HNSW_OK;
 }
 

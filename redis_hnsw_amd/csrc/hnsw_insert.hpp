@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64) void k_insert_plan(GraphView g, uint32_t first_
     vis.spilled = false;
     vis.count = 0;
 
-    WorkCtr ctr = {0, 0, 0};
+    WorkCtr ctr = {};
     const uint32_t lmax = g.hdr->max_layer;                 // core.rs:496
     const uint32_t ep0 = (uint32_t)g.hdr->enterpoint;       // core.rs:508
 
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64) void k_insert_commit_exact(GraphView g, uint32_
     vis.spilled = false;
     vis.count = 0;
 
-    WorkCtr ctr = {0, 0, 0};
+    WorkCtr ctr = {};
     uint32_t skipped = 0;  // econn evaluations the reference makes but whose result it never uses (:549-557 when deg <= m_max)
     uint32_t nt = 0;
     bool fail = false;

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(64) void k_search(GraphView g, const float *__restr
     vis.spilled = false;
     vis.count = 0;
 
-    WorkCtr ctr = {0, 0, 0};
+    WorkCtr ctr = {};
     const int32_t ep0 = g.hdr->enterpoint;        // core.rs:866
     const uint32_t lmax = g.hdr->max_layer;       // core.rs:867
 
@@ -62,6 +62,9 @@ __global__ __launch_bounds__(64) void k_search(GraphView g, const float *__restr
         atomicAdd(&g.hdr->ctr_search[0], (unsigned long long)ctr.n_dist);
         atomicAdd(&g.hdr->ctr_search[1], (unsigned long long)ctr.n_ids);
         atomicAdd(&g.hdr->ctr_search[2], (unsigned long long)ctr.n_expand);
+#ifdef HNSW_PHASE_TIMERS
+        for (int i = 0; i < 8; ++i) atomicAdd(&g.hdr->prof[i], ctr.ph[i]);
+#endif
     }
 }
 
