@@ -97,27 +97,10 @@ def main():
             graph = index.export_graph(with_vectors=False)
     if world > 1:
         # one-time index distribution: rank 0's graph to every replica over RCCL
-        meta = [None]
-        if rank == 0:
-            meta[0] = dict(enterpoint=graph["enterpoint"], max_layer=graph["max_layer"],
-                           nnz=[int(len(c)) for c in graph["col"]])
-        dist.broadcast_object_list(meta, src=0)
-        meta = meta[0]
-        L = meta["max_layer"] + 1
-        dev = torch.device("cuda", local_rank)
-        lv_t = torch.from_numpy(graph["levels"].astype(np.int64)).to(dev) if rank == 0 else torch.empty(N, dtype=torch.int64, device=dev)
-        dist.broadcast(lv_t, src=0)
-        rps, cols = [], []
-        for l in range(L):
-            rp_t = torch.from_numpy(graph["row_ptr"][l].astype(np.int64)).to(dev) if rank == 0 else torch.empty(N + 1, dtype=torch.int64, device=dev)
-            cl_t = torch.from_numpy(graph["col"][l].astype(np.int64)).to(dev) if rank == 0 else torch.empty(meta["nnz"][l], dtype=torch.int64, device=dev)
-            dist.broadcast(rp_t, src=0)
-            dist.broadcast(cl_t, src=0)
-            rps.append(rp_t.cpu().numpy().astype(np.uint64))
-            cols.append(cl_t.cpu().numpy().astype(np.uint32))
+        from redis_hnsw_amd import shard
+        g = shard.broadcast_graph(dist, graph, N, src=0, device=torch.device("cuda", local_rank))
         if rank != 0:
-            g = dict(vectors=V, levels=lv_t.cpu().numpy().astype(np.uint32), enterpoint=meta["enterpoint"],
-                     max_layer=meta["max_layer"], row_ptr=rps, col=cols)
+            g["vectors"] = V
             index.import_graph(g)
         dist.barrier()
 
@@ -136,8 +119,7 @@ def main():
         index.search_batch_device(q.data_ptr(), B, k, d_ids.data_ptr(), d_sims.data_ptr(), d_n.data_ptr(),
                                   stream.cuda_stream)
         if world > 1:   # the path's one real exchange: gather every shard's top-k
-            dist.all_gather_into_tensor(g_ids, d_ids)
-            dist.all_gather_into_tensor(g_sims, d_sims)
+            shard.gather_topk(dist, d_ids, d_sims, world, g_ids, g_sims)
 
     log("inputs resident; warm-up")
     for i in range(args.warmup):

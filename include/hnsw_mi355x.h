@@ -119,8 +119,8 @@ hnsw_status hnsw_layer_nnz(hnsw_index *h, uint32_t layer, uint64_t *nnz);
 hnsw_status hnsw_export_layer(hnsw_index *h, uint32_t layer, uint64_t *row_ptr /*[n+1]*/,
                               uint32_t *col);
 
-/* Engine knobs (not part of the reference surface): "lds_hash_bits" (log2 of
- * the per-query LDS visited table), "grid" (cap on resident query waves),
+/* Engine knobs (not part of the reference surface): "lds_buckets" (32-byte
+ * buckets of the per-query LDS visited table), "grid" (cap on resident query waves),
  * "fast_seed" / "fast_batch_max" / "fast_batch_div" (fast build schedule).   */
 hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value);
 

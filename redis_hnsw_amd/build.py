@@ -41,3 +41,21 @@ def build_library(force=False, extra_flags=()):
 
 if __name__ == "__main__":
     print(build_library(force=True))
+
+
+HOST_TEST_SRC = os.path.join(_HERE, "..", "tests", "cpp", "hnsw_test.cpp")
+HOST_TEST_BIN = os.path.join(LIB_DIR, "hnsw_test")
+
+
+def build_host_test(force=False):
+    """g++ build of tests/cpp/hnsw_test.cpp (the reference's core_tests.rs over the
+    C++ host mirror), linked against the in-tree library."""
+    src = os.path.abspath(HOST_TEST_SRC)
+    hdr = os.path.join(_HERE, "host", "hnsw_index.hpp")
+    if (not force and os.path.exists(HOST_TEST_BIN)
+            and os.path.getmtime(HOST_TEST_BIN) > max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(LIB_PATH))):
+        return HOST_TEST_BIN
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-o", HOST_TEST_BIN, src, "-L" + LIB_DIR, "-lhnsw_mi355x",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + "/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"]
+    subprocess.check_call(cmd)
+    return HOST_TEST_BIN

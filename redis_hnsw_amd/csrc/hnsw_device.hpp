@@ -240,32 +240,92 @@ __device__ __forceinline__ void compute_dists(const GraphView &g, const QReg<T> 
 }
 
 // ---------------------------------------------------------------------------
-// exact visited set: LDS open addressing, spilling to an HBM table
+// exact visited set (core.rs:614 HashSet): bucketed hash in LDS, spilling to an
+// HBM table when it fills.  A bucket is 8 words = 32 bytes: word 0 counts the
+// arrivals, words 1..7 hold ids.  Lookup = two ds_read_b128 + 7 compares;
+// insert = one ds_add_rtn on the counter (which hands concurrent lanes distinct
+// slots, so there is no retry) + one ds_write.  A bucket that has seen 7
+// arrivals is full: later ids for it chain into the next bucket, and a lookup
+// follows the chain only through full buckets.  Any bucket count works (the
+// host sizes the table to the LDS budget, not to a power of two).
 // ---------------------------------------------------------------------------
 struct Visited {
     uint32_t *lds;
     uint32_t *glob;
-    uint32_t lbits, gbits;
-    uint32_t count;   // wave-uniform
-    bool spilled;     // wave-uniform
-    bool glob_dirty;  // wave-uniform
+    uint32_t lnb, gnb;       // buckets in the LDS / HBM table
+    uint32_t lcap;           // ids the LDS table may hold before the set moves to HBM
+    uint32_t count;          // ids held (wave-uniform)
+    bool spilled;            // wave-uniform
+    bool glob_dirty;         // wave-uniform
 };
+constexpr uint32_t kBucketIds = 7;
 
-__device__ __forceinline__ uint32_t hash_slot(uint32_t id, uint32_t bits)
+__device__ __forceinline__ uint32_t hash_bucket(uint32_t id, uint32_t nb)
 {
-    return (id * 0x9E3779B1u) >> (32u - bits);
+    return __umulhi(id * 0x9E3779B1u, nb);
+}
+__device__ __forceinline__ bool any_eq7(const uint4 &lo, const uint4 &hi, uint32_t id)
+{
+    // min over the xors is 0 iff some slot equals id
+    uint32_t a = min(min(lo.y ^ id, lo.z ^ id), lo.w ^ id);
+    uint32_t c = min(min(hi.x ^ id, hi.y ^ id), min(hi.z ^ id, hi.w ^ id));
+    return min(a, c) == 0u;
 }
 
+// true if id was not in the table (and is now).  Lanes of one wave call this
+// concurrently with distinct ids; visited_reserve keeps the table <= ~7/8 full,
+// the iteration cap only guards against a corrupted table.
+__device__ __forceinline__ bool lds_set_insert(uint32_t *tab, uint32_t nb, uint32_t id)
+{
+    uint32_t b = hash_bucket(id, nb);
+    for (uint32_t it = 0; it < nb; ++it) {
+        uint32_t *bp = tab + (b << 3);
+        const uint4 *p4 = reinterpret_cast<const uint4 *>(bp);
+        const uint4 lo = p4[0], hi = p4[1];
+        if (any_eq7(lo, hi, id)) return false;
+        if (lo.x < kBucketIds) {
+            const uint32_t pos = atomicAdd(bp, 1u);
+            if (pos < kBucketIds) { bp[1 + pos] = id; return true; }
+        }
+        b = b + 1 == nb ? 0 : b + 1;   // full: the id lives further down the chain
+    }
+    return false;
+}
+
+// Same protocol on the HBM spill table.  Loads are agent-scope atomics so they
+// are served by L2, where the atomic adds execute (a plain load could hit a
+// stale L1 line); stores are atomic stores for the same reason.
+__device__ __forceinline__ bool glob_set_insert(uint32_t *tab, uint32_t nb, uint32_t id)
+{
+    uint32_t b = hash_bucket(id, nb);
+    for (uint32_t it = 0; it < nb; ++it) {
+        uint32_t *bp = tab + ((size_t)b << 3);
+        uint32_t w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = __hip_atomic_load(bp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint4 lo = make_uint4(w[0], w[1], w[2], w[3]), hi = make_uint4(w[4], w[5], w[6], w[7]);
+        if (any_eq7(lo, hi, id)) return false;
+        if (w[0] < kBucketIds) {
+            const uint32_t pos = atomicAdd(bp, 1u);
+            if (pos < kBucketIds) {
+                __hip_atomic_store(bp + 1 + pos, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return true;
+            }
+        }
+        b = b + 1 == nb ? 0 : b + 1;
+    }
+    return false;
+}
+
+// empty bucket = {0, kEmpty x 7}
 __device__ __forceinline__ void visited_clear(Visited &v, int lane)
 {
     uint4 *t4 = reinterpret_cast<uint4 *>(v.lds);
-    const uint32_t n4 = (1u << v.lbits) >> 2;
-    const uint4 e = make_uint4(kEmpty, kEmpty, kEmpty, kEmpty);
-    for (uint32_t i = lane; i < n4; i += 64) t4[i] = e;
+    const uint4 e0 = make_uint4(0u, kEmpty, kEmpty, kEmpty), e1 = make_uint4(kEmpty, kEmpty, kEmpty, kEmpty);
+    for (uint32_t i = lane; i < 2 * v.lnb; i += 64) t4[i] = (i & 1) ? e1 : e0;
     if (v.glob_dirty) {
         uint4 *g4 = reinterpret_cast<uint4 *>(v.glob);
-        const uint32_t m4 = (1u << v.gbits) >> 2;
-        for (uint32_t i = lane; i < m4; i += 64) g4[i] = e;
+        for (uint32_t i = lane; i < 2 * v.gnb; i += 64) g4[i] = (i & 1) ? e1 : e0;
         __threadfence();
         v.glob_dirty = false;
     }
@@ -274,60 +334,23 @@ __device__ __forceinline__ void visited_clear(Visited &v, int lane)
     __syncthreads();
 }
 
-// true if id was not in the set (and is now).  Lanes of one wave may call this
-// concurrently with distinct ids.  Probing is bounded by the table size: a full
-// table reports "seen" instead of spinning (visited_reserve keeps tables <= 7/8
-// full, so this is a guard, not a code path).
 __device__ __forceinline__ bool visited_insert(const Visited &v, uint32_t id)
 {
-    uint32_t *t = v.spilled ? v.glob : v.lds;
-    const uint32_t bits = v.spilled ? v.gbits : v.lbits;
-    const uint32_t mask = (1u << bits) - 1u;
-    uint32_t h = hash_slot(id, bits);
-    for (uint32_t probe = 0; probe <= mask; ++probe) {
-        uint32_t old = atomicCAS(&t[h], kEmpty, id);
-        if (old == kEmpty) return true;
-        if (old == id) return false;
-        h = (h + 1) & mask;
-    }
-    return false;
-}
-
-__device__ __forceinline__ bool visited_contains(const Visited &v, uint32_t id)
-{
-    const uint32_t *t = v.spilled ? v.glob : v.lds;
-    const uint32_t bits = v.spilled ? v.gbits : v.lbits;
-    const uint32_t mask = (1u << bits) - 1u;
-    uint32_t h = hash_slot(id, bits);
-    for (uint32_t probe = 0; probe <= mask; ++probe) {
-        uint32_t cur = t[h];
-        if (cur == kEmpty) return false;
-        if (cur == id) return true;
-        h = (h + 1) & mask;
-    }
-    return false;
+    if (!v.spilled) return lds_set_insert(v.lds, v.lnb, id);
+    return glob_set_insert(v.glob, v.gnb, id);
 }
 
 // Make room for up to 64 more ids.  Returns false if even the HBM table is full.
 __device__ __forceinline__ bool visited_reserve(Visited &v, int lane, unsigned long long *spill_ctr)
 {
-    const uint32_t gcap = 1u << v.gbits;
+    const uint32_t gcap = v.gnb * 6u;                  // ids at ~6/7 of the slots
     if (!v.spilled) {
-        const uint32_t cap = 1u << v.lbits;
-        if (v.count + 64 <= cap - (cap >> 3)) return true;
-        if (v.count + 64 > gcap - (gcap >> 3)) return false;   // would not fit there either
-        // move every entry to the HBM table and continue there
-        const uint32_t gmask = gcap - 1u;
-        for (uint32_t i = lane; i < cap; i += 64) {
-            uint32_t id = v.lds[i];
-            if (id != kEmpty) {
-                uint32_t h = hash_slot(id, v.gbits);
-                for (uint32_t probe = 0; probe <= gmask; ++probe) {
-                    uint32_t old = atomicCAS(&v.glob[h], kEmpty, id);
-                    if (old == kEmpty || old == id) break;
-                    h = (h + 1) & gmask;
-                }
-            }
+        if (v.count + 64 <= v.lcap) return true;
+        if (v.count + 64 > gcap) return false;         // would not fit there either
+        // move every id to the HBM table and continue there
+        for (uint32_t i = lane; i < v.lnb * 8u; i += 64) {
+            const uint32_t id = v.lds[i];
+            if ((i & 7u) != 0u && id != kEmpty) glob_set_insert(v.glob, v.gnb, id);
         }
         __threadfence();
         __syncthreads();
@@ -335,7 +358,7 @@ __device__ __forceinline__ bool visited_reserve(Visited &v, int lane, unsigned l
         v.glob_dirty = true;
         if (lane == 0 && spill_ctr) atomicAdd(spill_ctr, 1ull);
     }
-    return v.count + 64 <= gcap - (gcap >> 3);
+    return v.count + 64 <= gcap;
 }
 
 // ---------------------------------------------------------------------------
@@ -408,29 +431,39 @@ __device__ __forceinline__ int find_unexpanded(const uint64_t *W, uint32_t nW, i
 
 constexpr uint32_t kAuxWords = 512; // insert scratch: one adjacency row (degree <= 511)
 
-// LDS carve-up shared by the search and insert kernels.
-// [W: R*64*8][S: 64*8][fresh: 64*4][dsc: 64*4][aux: kAuxWords*4][qlds: dim*4 (T==0)][hash: 4<<lbits]
-__host__ __device__ inline size_t lds_bytes(int R, int T, uint32_t dim, uint32_t lbits)
+// LDS carve-up.  Search: [W: R*64*8][fresh: 64*4][dsc: 64*4][qlds (T==0)][hash: nb*32].
+// The insert kernels add [S: 64*8][aux: kAuxWords*4] after dsc.
+__host__ __device__ inline size_t lds_fixed_bytes(int R, int T, uint32_t dim, bool ins)
 {
-    size_t b = (size_t)R * 64 * 8 + 64 * 8 + 64 * 4 + 64 * 4 + kAuxWords * 4;
+    size_t b = (size_t)R * 64 * 8 + 64 * 4 + 64 * 4;
+    if (ins) b += 64 * 8 + kAuxWords * 4;
     if (T == 0) b += ((size_t)dim * 4 + 15) & ~(size_t)15;
-    b += (size_t)4 << lbits;
     return b;
 }
+__host__ __device__ inline size_t lds_bytes(int R, int T, uint32_t dim, uint32_t nbuckets, bool ins)
+{
+    return lds_fixed_bytes(R, T, dim, ins) + (size_t)nbuckets * 32;
+}
 
-template <int R, int T>
-__device__ __forceinline__ void carve(unsigned char *smem, uint32_t dim, uint32_t lbits, WaveMem &m, Visited &vis)
+template <int R, int T, bool INS>
+__device__ __forceinline__ void carve(unsigned char *smem, uint32_t dim, uint32_t nbuckets, uint32_t lcap, WaveMem &m,
+                                      Visited &vis)
 {
     unsigned char *p = smem;
     m.W = reinterpret_cast<uint64_t *>(p); p += (size_t)R * 64 * 8;
-    m.S = reinterpret_cast<uint64_t *>(p); p += 64 * 8;
     m.fresh = reinterpret_cast<uint32_t *>(p); p += 64 * 4;
     m.dsc = reinterpret_cast<float *>(p); p += 64 * 4;
-    m.aux = reinterpret_cast<uint32_t *>(p); p += kAuxWords * 4;
+    m.S = nullptr;
+    m.aux = nullptr;
+    if (INS) {
+        m.S = reinterpret_cast<uint64_t *>(p); p += 64 * 8;
+        m.aux = reinterpret_cast<uint32_t *>(p); p += kAuxWords * 4;
+    }
     m.qlds = reinterpret_cast<float *>(p);
     if (T == 0) p += ((size_t)dim * 4 + 15) & ~(size_t)15;
     vis.lds = reinterpret_cast<uint32_t *>(p);
-    vis.lbits = lbits;
+    vis.lnb = nbuckets;
+    vis.lcap = lcap;
 }
 
 struct WorkCtr {
@@ -479,11 +512,23 @@ __device__ uint32_t search_level(const GraphView &g, const WaveMem &m, Visited &
     const uint32_t stride = lc ? g.strideU : g.stride0;
 
     PH_T0();
+#ifdef HNSW_PHASE_TIMERS
+    uint32_t predicted = kEmpty;
+#endif
     for (;;) {
         const int pos = find_unexpanded<R>(m.W, nW, lane); // core.rs:631
         if (pos < 0) break;                               // core.rs:630,635
         const uint64_t ckey = m.W[pos];
         const uint32_t c = key_id(ckey);
+#ifdef HNSW_PHASE_TIMERS
+        if (ef > 1) {
+            ctr.ph[4] += (c == predicted);
+            // the runner-up: next unexpanded entry after pos (what a prefetcher would guess)
+            predicted = kEmpty;
+            for (uint32_t j = pos + 1; j < nW; ++j)
+                if (!(m.W[j] & 1ull)) { predicted = key_id(m.W[j]); break; }
+        }
+#endif
         __syncthreads();
         if (lane == 0) m.W[pos] = ckey | 1ull;
         ctr.n_expand += 1;

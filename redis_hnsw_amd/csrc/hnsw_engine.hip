@@ -31,7 +31,7 @@ struct hnsw_index {
     std::vector<uint32_t> h_levels, h_upper_base;
     // search scratch
     uint32_t *d_spill = nullptr;
-    uint32_t spill_gbits = 0, spill_slots = 0;
+    uint32_t spill_gnb = 0, spill_slots = 0;
     float *d_Q = nullptr;
     uint32_t *d_ids = nullptr, *d_nout = nullptr;
     float *d_sims = nullptr;
@@ -46,7 +46,8 @@ struct hnsw_index {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_sync = nullptr;
     bool ev_valid = false;
-    int lds_bits_override = -1;
+    int lds_buckets_override = -1;
+    uint32_t lds_fill_x2 = 13;       // LDS visited table holds lnb * fill/2 ids (of 7 per bucket) before spilling
     int grid_override = -1;
     uint32_t fast_seed = 512, fast_batch_max = 4096, fast_batch_div = 8;
     uint64_t rng[4] = {0, 0, 0, 0};
@@ -234,16 +235,34 @@ int pick_R(uint32_t need)
     return 0;
 }
 
-uint32_t pick_lbits(const hnsw_index *h, int R, int T)
+// Visited-table size (in 32-byte buckets of 7 ids) for one wave.  LDS is what
+// limits residency (160 KiB per CU, one wave per query), and a launch ends with
+// its slowest wave, so the table takes the whole LDS share of the residency the
+// batch needs: all `nwaves` queries resident at once if that is possible at
+// <= 4 waves per CU (256 CUs), else 4 per CU.  A query whose set outgrows the
+// table continues in HBM (slower, exact).  Expected ids of a layer-0 search
+// ~ 0.8 * ef * m_max0 (measured 3.9 k at ef 200 / m_max0 32 on 20 k nodes,
+// 5.9 k on 1 M); there is no point in more than 3x that.
+uint32_t pick_lnb(const hnsw_index *h, int R, int T, bool ins, uint32_t nwaves)
 {
-    if (h->lds_bits_override >= 4) return (uint32_t)h->lds_bits_override;
-    // expected visited-set size of one layer-0 search: ~0.8 * ef * m_max0
-    // (measured: 3.9 k at ef 200 / m_max0 32); 1.5x head room, then
-    // whatever keeps four waves resident per CU when that is possible.
-    double est = 0.8 * (double)h->efc * (double)h->m_max0 * 1.5;
-    uint32_t bits = std::max(8u, ceil_log2((uint64_t)est));
-    while (bits > 8 && lds_bytes(R, T, h->dim, bits) > 150 * 1024) --bits;
-    return bits;
+    const size_t fixed = lds_fixed_bytes(R, T, h->dim, ins);
+    if (h->lds_buckets_override >= 2) return (uint32_t)h->lds_buckets_override;
+    // measured on MI355X: 40448 B per 64-thread block still gives 4 blocks per CU, 40960 B does not
+    const size_t tiers[4] = {160 * 1024 - 2048, 80896, 53760, 40448};   // 1, 2, 3, 4 waves per CU
+    uint32_t per_cu = (nwaves + 255) / 256;
+    per_cu = std::min(std::max(per_cu, 1u), 4u);
+    size_t budget = tiers[per_cu - 1];
+    while (budget <= fixed + 64 && per_cu > 1) budget = tiers[--per_cu - 1];
+    const uint32_t fit = (uint32_t)((budget - fixed) / 32);
+    const uint32_t useful = (uint32_t)(0.8 * (double)h->efc * (double)h->m_max0 * 3.0 / 6.0) + 2;
+    return std::max(std::min(fit, useful), 2u);
+}
+
+__global__ void k_fill_buckets(uint4 *t, size_t n16)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint4 e0 = make_uint4(0u, kEmpty, kEmpty, kEmpty), e1 = make_uint4(kEmpty, kEmpty, kEmpty, kEmpty);
+    for (; i < n16; i += (size_t)gridDim.x * blockDim.x) t[i] = (i & 1) ? e1 : e0;
 }
 
 hnsw_status ensure_spill(hnsw_index *h)
@@ -253,14 +272,17 @@ hnsw_status ensure_spill(hnsw_index *h)
     // Sized from the node CAPACITY so that it stays valid while the index grows.
     uint64_t want = 4ull * h->efc * std::max(h->stride0, 16u);
     want = std::min<uint64_t>(want, 2ull * std::max(h->cap, 1024u));
-    uint32_t gbits = std::max(10u, ceil_log2(want));
+    uint32_t gnb = (uint32_t)(want / 6) + 16;           // 6 of the 7 id slots per bucket
     const uint32_t slots = 2048;
-    if (h->d_spill && h->spill_gbits >= gbits && h->spill_slots >= slots) return HNSW_OK;
+    if (h->d_spill && h->spill_gnb >= gnb && h->spill_slots >= slots) return HNSW_OK;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    dev_free(h, h->d_spill, (size_t)h->spill_slots << h->spill_gbits);
-    hnsw_status s = dev_alloc(h, &h->d_spill, (size_t)slots << gbits, 0xFF);
+    dev_free(h, h->d_spill, (size_t)h->spill_slots * h->spill_gnb * 8);
+    hnsw_status s = dev_alloc(h, &h->d_spill, (size_t)slots * gnb * 8);
     if (s != HNSW_OK) return s;
-    h->spill_gbits = gbits;
+    hipLaunchKernelGGL(k_fill_buckets, dim3(4096), dim3(256), 0, h->stream, reinterpret_cast<uint4 *>(h->d_spill),
+                       (size_t)slots * gnb * 2);
+    HIP_TRY(h, hipGetLastError());
+    h->spill_gnb = gnb;
     h->spill_slots = slots;
     return HNSW_OK;
 }
@@ -269,16 +291,16 @@ template <int MODE, int T, int R>
 hnsw_status launch_search_t(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t *d_ids,
                             float *d_sims, uint32_t *d_nout, hipStream_t st)
 {
-    const uint32_t lbits = pick_lbits(h, R, T);
-    const size_t lds = lds_bytes(R, T, h->dim, lbits);
+    const uint32_t lnb = pick_lnb(h, R, T, false, B);
+    const size_t lds = lds_bytes(R, T, h->dim, lnb, false);
     auto kern = k_search<MODE, T, R>;
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     uint32_t grid = std::min(B, h->spill_slots);
     if (h->grid_override > 0) grid = std::min<uint32_t>(grid, (uint32_t)h->grid_override);
     HIP_TRY(h, hipEventRecord(h->ev0, st));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, st, view(h), dQ, B, k, h->efc, lbits, h->d_spill,
-                       h->spill_gbits, d_ids, d_sims, d_nout);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, st, view(h), dQ, B, k, h->efc, lnb, lnb * h->lds_fill_x2 / 2, h->d_spill,
+                       h->spill_gnb, d_ids, d_sims, d_nout);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->ev1, st));
     h->ev_valid = true;
@@ -453,7 +475,9 @@ const char *hnsw_last_error(const hnsw_index *h) { return h ? h->err.c_str() : "
 hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
 {
     if (!h || !key) return HNSW_ERR_INVALID;
-    if (!std::strcmp(key, "lds_hash_bits")) { h->lds_bits_override = (int)value; return HNSW_OK; }
+    if (!std::strcmp(key, "lds_fill_x2")) { h->lds_fill_x2 = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 2), 13); return HNSW_OK; }
+    if (!std::strcmp(key, "lds_buckets")) { h->lds_buckets_override = (int)value; return HNSW_OK; }
+    if (!std::strcmp(key, "lds_hash_bits")) { h->lds_buckets_override = std::max<int>(2, (int)((1ll << value) / 8)); return HNSW_OK; }
     if (!std::strcmp(key, "grid")) { h->grid_override = (int)value; return HNSW_OK; }
     if (!std::strcmp(key, "fast_seed")) { h->fast_seed = (uint32_t)std::max<int64_t>(value, 1); return HNSW_OK; }
     if (!std::strcmp(key, "fast_batch_max")) { h->fast_batch_max = (uint32_t)std::max<int64_t>(value, 1); return HNSW_OK; }

@@ -96,16 +96,16 @@ __device__ uint32_t select_topm(const GraphView &g, const WaveMem &m, Visited &v
 // ---------------------------------------------------------------------------
 template <int MODE, int T, int R>
 __global__ __launch_bounds__(64) void k_insert_plan(GraphView g, uint32_t first_id, uint32_t count, uint32_t ef,
-                                                    uint32_t mlinks, uint32_t lbits, uint32_t *__restrict__ gspill,
-                                                    uint32_t gbits, uint32_t *__restrict__ plan)
+                                                    uint32_t mlinks, uint32_t lnb, uint32_t lcap, uint32_t *__restrict__ gspill,
+                                                    uint32_t gnb, uint32_t *__restrict__ plan)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
     WaveMem m;
     Visited vis;
-    carve<R, T>(smem, g.dim, lbits, m, vis);
-    vis.glob = gspill + ((size_t)blockIdx.x << gbits);
-    vis.gbits = gbits;
+    carve<R, T, true>(smem, g.dim, lnb, lcap, m, vis);
+    vis.glob = gspill + (size_t)blockIdx.x * gnb * 8;
+    vis.gnb = gnb;
     vis.glob_dirty = false;
     vis.spilled = false;
     vis.count = 0;
@@ -166,17 +166,17 @@ __device__ __forceinline__ void touch_push(uint32_t *touched, uint32_t cap, uint
 
 template <int MODE, int T, int R>
 __global__ __launch_bounds__(64) void k_insert_commit_exact(GraphView g, uint32_t id, uint32_t mlinks,
-                                                            uint32_t lbits, uint32_t *__restrict__ gspill,
-                                                            uint32_t gbits, const uint32_t *__restrict__ plan,
+                                                            uint32_t lnb, uint32_t lcap, uint32_t *__restrict__ gspill,
+                                                            uint32_t gnb, const uint32_t *__restrict__ plan,
                                                             uint32_t *__restrict__ touched, uint32_t touched_cap)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
     WaveMem m;
     Visited vis;
-    carve<R, T>(smem, g.dim, lbits, m, vis);
+    carve<R, T, true>(smem, g.dim, lnb, lcap, m, vis);
     vis.glob = gspill;
-    vis.gbits = gbits;
+    vis.gnb = gnb;
     vis.glob_dirty = false;
     vis.spilled = false;
     vis.count = 0;

@@ -10,8 +10,8 @@ namespace hnsw {
 // ---------------------------------------------------------------------------
 template <int MODE, int T, int R>
 __global__ __launch_bounds__(64) void k_search(GraphView g, const float *__restrict__ Q, uint32_t B,
-                                               uint32_t k, uint32_t ef, uint32_t lbits,
-                                               uint32_t *__restrict__ gspill, uint32_t gbits,
+                                               uint32_t k, uint32_t ef, uint32_t lnb, uint32_t lcap,
+                                               uint32_t *__restrict__ gspill, uint32_t gnb,
                                                uint32_t *__restrict__ out_ids, float *__restrict__ out_sims,
                                                uint32_t *__restrict__ out_n)
 {
@@ -19,14 +19,18 @@ __global__ __launch_bounds__(64) void k_search(GraphView g, const float *__restr
     const int lane = threadIdx.x;
     WaveMem m;
     Visited vis;
-    carve<R, T>(smem, g.dim, lbits, m, vis);
-    vis.glob = gspill + ((size_t)blockIdx.x << gbits);
-    vis.gbits = gbits;
+    carve<R, T, false>(smem, g.dim, lnb, lcap, m, vis);
+    vis.glob = gspill + (size_t)blockIdx.x * gnb * 8;
+    vis.gnb = gnb;
     vis.glob_dirty = false;
     vis.spilled = false;
     vis.count = 0;
 
     WorkCtr ctr = {};
+#ifdef HNSW_PHASE_TIMERS
+    const unsigned long long wave_t0 = __builtin_readcyclecounter();
+    const unsigned long long real_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int32_t ep0 = g.hdr->enterpoint;        // core.rs:866
     const uint32_t lmax = g.hdr->max_layer;       // core.rs:867
 
@@ -63,7 +67,11 @@ __global__ __launch_bounds__(64) void k_search(GraphView g, const float *__restr
         atomicAdd(&g.hdr->ctr_search[1], (unsigned long long)ctr.n_ids);
         atomicAdd(&g.hdr->ctr_search[2], (unsigned long long)ctr.n_expand);
 #ifdef HNSW_PHASE_TIMERS
-        for (int i = 0; i < 8; ++i) atomicAdd(&g.hdr->prof[i], ctr.ph[i]);
+        for (int i = 0; i < 5; ++i) atomicAdd(&g.hdr->prof[i], ctr.ph[i]);
+        const unsigned long long dt = __builtin_readcyclecounter() - wave_t0;
+        atomicAdd(&g.hdr->prof[5], dt);                       // sum of wave lifetimes (cycles)
+        atomicMax(&g.hdr->prof[6], dt);                       // longest wave (cycles)
+        atomicMax(&g.hdr->prof[7], __builtin_amdgcn_s_memrealtime() - real_t0); // longest wave (100 MHz ticks)
 #endif
     }
 }

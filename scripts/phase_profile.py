@@ -41,10 +41,14 @@ lib = _capi.load()
 if hasattr(lib, "hnsw_debug_phase_cycles"):
     out = (C.c_uint64 * 8)()
     lib.hnsw_debug_phase_cycles(gi._h, out)
-    tot = sum(out)
+    tot = sum(out[:4])
     if tot:
         names = ["pop+row fetch", "visited filter", "gather+dist", "merge W"]
         per_step = sc.n_expand
         for i, nm in enumerate(names):
             print("  %-16s %6.1f%%  %8.0f cycles/expansion" % (nm, 100.0 * out[i] / tot, out[i] / per_step))
+        print("  runner-up prediction hit rate %.3f" % (out[4] / per_step))
+        waves = reps * min(B, 2048)
+        print("  wave lifetime: mean %.0f cycles, max-of-run %.0f cycles, max %.1f us (memrealtime) -> clock ~%.2f GHz" % (
+            out[5] / waves, out[6], out[7] / 100.0, out[6] / (out[7] * 10.0)))
         print("  total cycles/expansion %.0f ; cycles/query %.0f" % (tot / per_step, tot / (reps * B)))

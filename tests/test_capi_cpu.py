@@ -49,3 +49,9 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dp, f), errors="ignore").read()
                 for needle in ("import oracle", "from oracle", "hnsw_oracle", "oracle/"):
                     assert needle not in src, "%s references the oracle (%s)" % (f, needle)
+
+
+def test_cpp_host_mirror_builds(capi):
+    from redis_hnsw_amd import build
+    exe = build.build_host_test()
+    assert os.path.exists(exe)

@@ -239,6 +239,37 @@ def test_fast_build_with_spilling_visited_sets(eng, oracle_mod):
     gi.close()
 
 
+def test_cpp_host_mirror_runs_reference_tests():
+    """tests/cpp/hnsw_test.cpp = core_tests.rs + metrics_tests.rs over the C++ host mirror"""
+    import subprocess
+    from redis_hnsw_amd import build
+    exe = build.build_host_test()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "hnsw_test ok" in r.stdout
+
+
+# ---- committed golden vectors -------------------------------------------------------
+from tests.golden_util import golden_cases, load_golden  # noqa: E402
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_engine_reproduces_golden(eng, name):
+    """exact GPU insert -> the golden graph; GPU search -> golden ids / similarity bits / counters"""
+    c = load_golden(name)
+    gi = eng.Index("g", c["dim"], c["m"], c["ef"])
+    gi.add_batch(c["V"], levels=c["levels"], mode="exact")
+    ok, why = graphs_equal(c["graph"], gi.export_graph())
+    assert ok, why
+    gi.reset_counters()
+    ids, sims, n_out = gi.search_batch(c["Q"], c["k"])
+    assert np.array_equal(ids, c["ids"]) and np.array_equal(_bits(sims), c["sims_bits"])
+    assert np.array_equal(n_out, c["n_out"])
+    sc, _ = gi.counters()
+    assert [sc.n_dist, sc.n_ids, sc.n_expand] == c["search_counters"].tolist()
+    gi.close()
+
+
 # ---- fast build: recall parity ------------------------------------------------------
 def test_fast_build_recall_parity(eng, oracle_mod, built):
     n, dim, m, ef, k = 6000, 32, 16, 200, 10
