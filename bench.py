@@ -173,13 +173,30 @@ def main():
             dist.destroy_process_group()
         return
 
+    # ---- the same batch through the host-buffer entry point (PCIe in and out); informational
+    Qh = Qall[:B]
+    index.search_batch(Qh, k)
+    th = time.perf_counter()
+    for _ in range(5):
+        index.search_batch(Qh, k)
+    host_qps = 5 * B / (time.perf_counter() - th)
+
     # ---- roofline of the dominant kernel (k_search) -------------------------------------
     launches = args.steps
     bytes_per_launch = (sc.n_dist * 4 * dim + sc.n_ids * 4) / launches + B * (4 * dim + 8 * k)
     kernel_ms = stream_ms / launches     # HIP events on the launch stream around the timed region
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
+    # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, see profiles/); null for other workloads
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if all(tj["config"].get(kk) == vv for kk, vv in dict(nodes=N, dim=dim, M=M, ef=ef, k=k, batch=B).items()):
+            traffic = tj["k_search_hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
     roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                     kernel="k_search", kernel_ms=round(kernel_ms, 4),
                     algorithmic_bytes_per_launch=int(bytes_per_launch),
                     n_dist_per_query=round(sc.n_dist / (launches * B), 1),
@@ -228,6 +245,7 @@ def main():
                    "parallelism": "replica x%d, query batch sharded" % world},
         "recall_at_10": None if recall is None else round(recall, 4),
         "build_seconds": None if t_build is None else round(t_build, 2),
+        "host_buffers_qps": round(host_qps, 1),
         "setup_seconds": round(time.time() - t0, 1),
         "roofline": roofline,
         "cpu_baseline": cpu,
