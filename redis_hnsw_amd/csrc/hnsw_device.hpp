@@ -317,15 +317,16 @@ __device__ __forceinline__ bool glob_set_insert(uint32_t *tab, uint32_t nb, uint
     return false;
 }
 
-// empty bucket = {0, kEmpty x 7}
+// empty bucket = {0, kEmpty x 7}.  16-byte piece i is the head of a bucket iff i
+// is even; i = lane + 64k keeps the lane's parity, so each lane stores one constant.
 __device__ __forceinline__ void visited_clear(Visited &v, int lane)
 {
     uint4 *t4 = reinterpret_cast<uint4 *>(v.lds);
-    const uint4 e0 = make_uint4(0u, kEmpty, kEmpty, kEmpty), e1 = make_uint4(kEmpty, kEmpty, kEmpty, kEmpty);
-    for (uint32_t i = lane; i < 2 * v.lnb; i += 64) t4[i] = (i & 1) ? e1 : e0;
+    const uint4 e = make_uint4((lane & 1) ? kEmpty : 0u, kEmpty, kEmpty, kEmpty);
+    for (uint32_t i = lane; i < 2 * v.lnb; i += 64) t4[i] = e;
     if (v.glob_dirty) {
         uint4 *g4 = reinterpret_cast<uint4 *>(v.glob);
-        for (uint32_t i = lane; i < 2 * v.gnb; i += 64) g4[i] = (i & 1) ? e1 : e0;
+        for (uint32_t i = lane; i < 2 * v.gnb; i += 64) g4[i] = e;
         __threadfence();
         v.glob_dirty = false;
     }
@@ -493,7 +494,7 @@ struct WorkCtr {
 // one is popped.  Leaves W[0..n) sorted nearest first; returns n.
 // ---------------------------------------------------------------------------
 template <int MODE, int T, int R>
-__device__ uint32_t search_level(const GraphView &g, const WaveMem &m, Visited &vis, const QReg<T> &qr,
+__device__ uint32_t search_level_v1(const GraphView &g, const WaveMem &m, Visited &vis, const QReg<T> &qr,
                                  uint32_t ep, uint32_t ef, uint32_t lc, WorkCtr &ctr, int lane, bool &fail)
 {
     visited_clear(vis, lane);                    // core.rs:614
@@ -566,6 +567,242 @@ __device__ uint32_t search_level(const GraphView &g, const WaveMem &m, Visited &
         __syncthreads();
     }
     return nW;
+}
+
+// ---------------------------------------------------------------------------
+// search_level, second generation: W lives in registers (lane L owns entries
+// L, 64+L, ...), LDS only carries the scatter of the merge; neighbour ids reach
+// the 8-lane gather groups with ds_bpermute instead of an LDS compaction, and
+// each distance is kept by the lane that will own its key, so no LDS staging of
+// ids / distances is left.  While the current candidate's vectors are in
+// flight, the adjacency row and the vectors of the runner-up (the candidate the
+// next expansion will take unless this one uncovers a nearer node) are pulled
+// towards L2: about half of all expansions then start from a register-resident
+// row and L2-resident vectors.  The prefetch touches no state: results are
+// identical to v1 and to the reference.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t bperm(uint32_t v, int src_lane)
+{
+    return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
+}
+
+template <int R>
+__device__ __forceinline__ uint32_t merge_regs(uint64_t (&w)[R], uint64_t *Wbuf, uint32_t nW, uint32_t cap,
+                                               uint64_t nk, bool take, int lane)
+{
+    const uint64_t tmask = __ballot(take);
+    if (tmask == 0) return nW;
+    uint32_t up[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) up[r] = 0;
+    uint32_t mypos = 0;
+    uint64_t mm = tmask;
+    while (mm) {
+        const int j = __ffsll((unsigned long long)mm) - 1;
+        mm &= mm - 1;
+        const uint64_t s = readlane64(nk, j);
+        uint32_t rank = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool below = w[r] < s;          // slots past nW hold ~0: never below
+            rank += __popcll(__ballot(below));
+            up[r] += below ? 0u : 1u;
+        }
+        rank += __popcll(__ballot(take && nk < s));
+        if (lane == j) mypos = rank;
+    }
+    uint32_t total = nW + (uint32_t)__popcll(tmask);
+    if (total > cap) total = cap;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t i = r * 64 + lane;
+        if (i < nW) {
+            const uint32_t np = i + up[r];
+            if (np < cap) Wbuf[np] = w[r];
+        }
+    }
+    if (take && mypos < cap) Wbuf[mypos] = nk;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t i = r * 64 + lane;
+        w[r] = i < total ? Wbuf[i] : ~0ull;
+    }
+    __syncthreads();
+    return total;
+}
+
+// first entry whose expanded bit is clear (slots past nW hold ~0, bit set)
+template <int R>
+__device__ __forceinline__ bool first_unexpanded(const uint64_t (&w)[R], uint64_t &key, int &rsel, int &lsel)
+{
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint64_t b = __ballot(!(w[r] & 1ull));
+        if (b) {
+            lsel = __ffsll((unsigned long long)b) - 1;
+            rsel = r;
+            key = readlane64(w[r], lsel);
+            return true;
+        }
+    }
+    return false;
+}
+
+template <int R>
+__device__ __forceinline__ uint64_t w_at(const uint64_t (&w)[R], uint32_t idx)
+{
+    uint64_t v = ~0ull;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if ((idx >> 6) == (uint32_t)r) v = readlane64(w[r], idx & 63);
+    return v;
+}
+
+template <int MODE, int T, int R>
+__device__ uint32_t search_level_v2(const GraphView &g, const WaveMem &m, Visited &vis, const QReg<T> &qr,
+                                    uint32_t ep, uint32_t ef, uint32_t lc, WorkCtr &ctr, int lane, bool &fail)
+{
+    static_assert(MODE == MODE_AVX && T > 0, "register-resident path");
+    constexpr bool kPrefetch = (T <= 8);
+    const int grp = lane >> 3, pp = piece_of_lane(lane), sub = lane & 7;
+    const float4 *vec4 = reinterpret_cast<const float4 *>(g.vec);
+    const uint32_t row4 = g.dim >> 2;                 // float4 per vector row
+
+    visited_clear(vis, lane);                          // core.rs:614
+    if (lane == 0) visited_insert(vis, ep);            // core.rs:617
+    vis.count = 1;
+    uint64_t w[R];
+    {
+        float4 v[T];
+        const float4 *p = vec4 + (size_t)ep * row4 + pp;
+#pragma unroll
+        for (int t = 0; t < T; ++t) v[t] = p[t * 8];
+        const float d = avx_reduce(avx_accumulate<T>(qr.q, v)); // core.rs:621
+        ctr.n_dist += 1;
+#pragma unroll
+        for (int r = 0; r < R; ++r) w[r] = ~0ull;
+        if (lane == 0) w[0] = pack_key(d, ep);         // core.rs:627-628
+    }
+    uint32_t nW = 1;
+    const uint32_t stride = lc ? g.strideU : g.stride0;
+    uint32_t pf_id = kEmpty, pf_word = 0;              // runner-up row fetched last step
+    uint32_t pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0;
+    __syncthreads();
+
+    for (;;) {
+        uint64_t ckey;
+        int rsel, lsel;
+        if (!first_unexpanded<R>(w, ckey, rsel, lsel)) break;   // core.rs:630-635
+        const uint32_t c = key_id(ckey);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (r == rsel && lane == lsel) w[r] |= 1ull;
+        ctr.n_expand += 1;
+        if (kPrefetch) asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2), "v"(pf3));   // retire last step's touches
+
+        // adjacency row of c: already in registers if last step's guess was right
+        const uint32_t *row = row_ptr(g, c, lc);         // core.rs:645
+        uint32_t word;
+        if (kPrefetch && c == pf_id) word = pf_word;
+        else word = (uint32_t)lane < stride ? row[lane] : 0u;
+        // runner-up = next unexpanded entry; fetch its row now
+        uint32_t rid = kEmpty, wordr = 0;
+        if (kPrefetch && ef > 1) {
+            uint64_t rkey;
+            int r2, l2;
+            if (first_unexpanded<R>(w, rkey, r2, l2)) {
+                rid = key_id(rkey);
+                const uint32_t *rrow = row_ptr(g, rid, lc);
+                wordr = (uint32_t)lane < stride ? rrow[lane] : 0u;
+            }
+        }
+        uint32_t cnt = __builtin_amdgcn_readfirstlane(word);
+        if (cnt > stride - 1) cnt = stride - 1;
+        ctr.n_ids += cnt;
+
+        for (uint32_t wbase = 0; wbase <= cnt; wbase += 64) {   // core.rs:646 stored order
+            const uint32_t wi = wbase + lane;
+            if (wbase) word = wi < stride ? row[wi] : 0u;
+            const bool valid = wi >= 1 && wi <= cnt;
+            if (!visited_reserve(vis, lane, &g.hdr->ctr_search[3])) { fail = true; return nW; }
+            const bool fresh = valid && visited_insert(vis, word); // core.rs:648-649
+            const uint64_t fm = __ballot(fresh);
+            const uint32_t nf = __popcll(fm);
+            if (nf == 0) continue;
+            vis.count += nf;
+            ctr.n_dist += nf;
+            // Slot s of this chunk is lane s; for the first chunk lane 0 holds the degree, so slots are
+            // taken from lane s+1 to keep 32 neighbours in 4 rounds.
+            const int shift = wbase ? 0 : 1;
+            const uint64_t fms = fm >> shift;
+            for (int pass = 0; pass < 2; ++pass) {
+                const uint32_t pm = (uint32_t)(fms >> (32 * pass));
+                if (pm == 0) continue;
+                constexpr int RB = (T <= 4) ? 4 : (T <= 8 ? 2 : 1);   // rounds of 8 vectors in flight
+                uint64_t key = ~0ull;
+                bool have = false;
+#pragma unroll
+                for (int r0 = 0; r0 < 4; r0 += RB) {
+                    float4 v[RB][T];
+                    uint32_t idr[RB];
+#pragma unroll
+                    for (int rr = 0; rr < RB; ++rr) {
+                        const int r = r0 + rr;
+                        const int s = pass * 32 + r * 8 + grp;
+                        idr[rr] = bperm(word, (s + shift) & 63);
+                        if ((pm >> (r * 8 + grp)) & 1u) {
+                            const float4 *p = vec4 + (size_t)idr[rr] * row4 + pp;
+#pragma unroll
+                            for (int t = 0; t < T; ++t) v[rr][t] = p[t * 8];
+                        }
+                    }
+                    if (kPrefetch && pass == 0 && r0 == 0 && wbase == 0 && rid != kEmpty) {
+                        // touch one dword per 128-B line of every neighbour vector of the runner-up
+                        uint32_t cr = __builtin_amdgcn_readfirstlane(wordr);
+                        if (cr > stride - 1) cr = stride - 1;
+                        if (lane >= 1 && (uint32_t)lane <= cr) {
+                            const uint32_t *pv = reinterpret_cast<const uint32_t *>(g.vec + (size_t)wordr * g.dim);
+                            pf0 = pv[0];
+                            if (T > 1) pf1 = pv[32];
+                            if (T > 2) pf2 = pv[64];
+                            if (T > 3) pf3 = pv[96];
+                        }
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < RB; ++rr) {
+                        const int r = r0 + rr;
+                        if ((pm >> (r * 8 + grp)) & 1u) {
+                            const float d = avx_reduce(avx_accumulate<T>(qr.q, v[rr])); // core.rs:652
+                            if (sub == r) { key = pack_key(d, idr[rr]); have = true; }
+                        }
+                    }
+                }
+                const uint64_t worst = nW == ef ? w_at<R>(w, ef - 1) : ~0ull;     // core.rs:651
+                nW = merge_regs<R>(w, m.W, nW, ef, key, have && key < worst, lane); // core.rs:657-664
+            }
+        }
+        pf_id = rid;
+        pf_word = wordr;
+    }
+    if (kPrefetch) asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2), "v"(pf3));
+    // leave W in LDS for the callers (top-k output, select_neighbors)
+#pragma unroll
+    for (int r = 0; r < R; ++r) m.W[r * 64 + lane] = w[r];
+    __syncthreads();
+    return nW;
+}
+
+template <int MODE, int T, int R>
+__device__ __forceinline__ uint32_t search_level(const GraphView &g, const WaveMem &m, Visited &vis,
+                                                 const QReg<T> &qr, uint32_t ep, uint32_t ef, uint32_t lc,
+                                                 WorkCtr &ctr, int lane, bool &fail)
+{
+#ifndef HNSW_SEARCH_V1
+    if constexpr (MODE == MODE_AVX && T > 0) return search_level_v2<MODE, T, R>(g, m, vis, qr, ep, ef, lc, ctr, lane, fail);
+    else
+#endif
+        return search_level_v1<MODE, T, R>(g, m, vis, qr, ep, ef, lc, ctr, lane, fail);
 }
 
 } // namespace hnsw
