@@ -48,6 +48,7 @@ struct GraphView {
     const uint32_t *levels;     // [cap]
     DevHeader *hdr;
     uint32_t dim, stride0, strideU;
+    uint32_t flags;             // bit 0: runner-up prefetch in search_level
 };
 
 __device__ __forceinline__ uint32_t *row_ptr(const GraphView &g, uint32_t id, uint32_t lc)
@@ -622,13 +623,16 @@ __device__ __forceinline__ uint32_t merge_regs(uint64_t (&w)[R], uint64_t *Wbuf,
         }
     }
     if (take && mypos < cap) Wbuf[mypos] = nk;
-    __syncthreads();
+    // One wave owns Wbuf and the LDS serves a wave's requests in issue order, so the reads below see
+    // the scatter above; only the compiler has to be kept from reordering them.  (A __syncthreads()
+    // here would also drain the vector loads this merge is meant to run under.)
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t i = r * 64 + lane;
         w[r] = i < total ? Wbuf[i] : ~0ull;
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     return total;
 }
 
@@ -664,15 +668,19 @@ __device__ uint32_t search_level_v2(const GraphView &g, const WaveMem &m, Visite
                                     uint32_t ep, uint32_t ef, uint32_t lc, WorkCtr &ctr, int lane, bool &fail)
 {
     static_assert(MODE == MODE_AVX && T > 0, "register-resident path");
-    constexpr bool kPrefetch = (T <= 8);
     const int grp = lane >> 3, pp = piece_of_lane(lane), sub = lane & 7;
     const float4 *vec4 = reinterpret_cast<const float4 *>(g.vec);
     const uint32_t row4 = g.dim >> 2;                 // float4 per vector row
+    const uint32_t stride = lc ? g.strideU : g.stride0;
 
     visited_clear(vis, lane);                          // core.rs:614
     if (lane == 0) visited_insert(vis, ep);            // core.rs:617
     vis.count = 1;
+    // the entry point's row is requested before its distance is computed
+    const uint32_t *row = row_ptr(g, ep, lc);
+    uint32_t word = (uint32_t)lane < stride ? row[lane] : 0u;
     uint64_t w[R];
+    uint64_t ckey;
     {
         float4 v[T];
         const float4 *p = vec4 + (size_t)ep * row4 + pp;
@@ -682,44 +690,35 @@ __device__ uint32_t search_level_v2(const GraphView &g, const WaveMem &m, Visite
         ctr.n_dist += 1;
 #pragma unroll
         for (int r = 0; r < R; ++r) w[r] = ~0ull;
-        if (lane == 0) w[0] = pack_key(d, ep);         // core.rs:627-628
+        ckey = pack_key(d, ep);
+        if (lane == 0) w[0] = ckey | 1ull;             // core.rs:627-628; popped right away (:631)
     }
     uint32_t nW = 1;
-    const uint32_t stride = lc ? g.strideU : g.stride0;
-    uint32_t pf_id = kEmpty, pf_word = 0;              // runner-up row fetched last step
-    uint32_t pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0;
+    // keys of the previous expansion's last gather, not merged yet: the merge runs after the next
+    // expansion's vector loads have been issued, i.e. under their latency
+    uint64_t pkey = ~0ull;
+    bool ptake = false;
     __syncthreads();
+    PH_T0();
 
     for (;;) {
-        uint64_t ckey;
-        int rsel, lsel;
-        if (!first_unexpanded<R>(w, ckey, rsel, lsel)) break;   // core.rs:630-635
+        // ckey is the candidate being expanded (already marked), `word` its adjacency row (core.rs:631-645)
         const uint32_t c = key_id(ckey);
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            if (r == rsel && lane == lsel) w[r] |= 1ull;
+        (void)c;
         ctr.n_expand += 1;
-        if (kPrefetch) asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2), "v"(pf3));   // retire last step's touches
-
-        // adjacency row of c: already in registers if last step's guess was right
-        const uint32_t *row = row_ptr(g, c, lc);         // core.rs:645
-        uint32_t word;
-        if (kPrefetch && c == pf_id) word = pf_word;
-        else word = (uint32_t)lane < stride ? row[lane] : 0u;
-        // runner-up = next unexpanded entry; fetch its row now
-        uint32_t rid = kEmpty, wordr = 0;
-        if (kPrefetch && ef > 1) {
-            uint64_t rkey;
-            int r2, l2;
-            if (first_unexpanded<R>(w, rkey, r2, l2)) {
-                rid = key_id(rkey);
-                const uint32_t *rrow = row_ptr(g, rid, lc);
-                wordr = (uint32_t)lane < stride ? rrow[lane] : 0u;
-            }
-        }
         uint32_t cnt = __builtin_amdgcn_readfirstlane(word);
         if (cnt > stride - 1) cnt = stride - 1;
         ctr.n_ids += cnt;
+        PH_MARK(ctr, 0);  // pop + adjacency row fetch
+
+        // The next candidate is known BEFORE the last merge of this expansion: it is the nearest
+        // accepted new key if that beats the runner-up (the first unexpanded entry of W), else the
+        // runner-up, which no new key can displace in that case.  Its row is requested first and the
+        // merge runs under that latency.
+        bool next_issued = false, have_next = false;
+        uint64_t nkey = ~0ull;
+        uint32_t word_next = 0;
+        const uint32_t *row_next = row;
 
         for (uint32_t wbase = 0; wbase <= cnt; wbase += 64) {   // core.rs:646 stored order
             const uint32_t wi = wbase + lane;
@@ -729,19 +728,25 @@ __device__ uint32_t search_level_v2(const GraphView &g, const WaveMem &m, Visite
             const bool fresh = valid && visited_insert(vis, word); // core.rs:648-649
             const uint64_t fm = __ballot(fresh);
             const uint32_t nf = __popcll(fm);
+            PH_MARK(ctr, 1);  // visited filter
             if (nf == 0) continue;
             vis.count += nf;
             ctr.n_dist += nf;
-            // Slot s of this chunk is lane s; for the first chunk lane 0 holds the degree, so slots are
+            // Slot s of this chunk is lane s; in the first chunk lane 0 holds the degree, so slots are
             // taken from lane s+1 to keep 32 neighbours in 4 rounds.
             const int shift = wbase ? 0 : 1;
             const uint64_t fms = fm >> shift;
+            const bool last_chunk = wbase + 64 > cnt;
             for (int pass = 0; pass < 2; ++pass) {
                 const uint32_t pm = (uint32_t)(fms >> (32 * pass));
                 if (pm == 0) continue;
                 constexpr int RB = (T <= 4) ? 4 : (T <= 8 ? 2 : 1);   // rounds of 8 vectors in flight
                 uint64_t key = ~0ull;
                 bool have = false;
+                // Slots without a fresh neighbour re-read the first fresh one (same lines, already in
+                // flight): the four rounds then form one straight-line block the compiler interleaves.
+                const uint32_t safe_id =
+                    (uint32_t)__builtin_amdgcn_readlane((int)word, __ffsll((unsigned long long)fm) - 1);
 #pragma unroll
                 for (int r0 = 0; r0 < 4; r0 += RB) {
                     float4 v[RB][T];
@@ -750,42 +755,80 @@ __device__ uint32_t search_level_v2(const GraphView &g, const WaveMem &m, Visite
                     for (int rr = 0; rr < RB; ++rr) {
                         const int r = r0 + rr;
                         const int s = pass * 32 + r * 8 + grp;
-                        idr[rr] = bperm(word, (s + shift) & 63);
-                        if ((pm >> (r * 8 + grp)) & 1u) {
-                            const float4 *p = vec4 + (size_t)idr[rr] * row4 + pp;
+                        const uint32_t got = bperm(word, (s + shift) & 63);
+                        idr[rr] = ((pm >> (r * 8 + grp)) & 1u) ? got : safe_id;
+                        const float4 *p = vec4 + (size_t)idr[rr] * row4 + pp;
 #pragma unroll
-                            for (int t = 0; t < T; ++t) v[rr][t] = p[t * 8];
-                        }
+                        for (int t = 0; t < T; ++t) v[rr][t] = p[t * 8];
                     }
-                    if (kPrefetch && pass == 0 && r0 == 0 && wbase == 0 && rid != kEmpty) {
-                        // touch one dword per 128-B line of every neighbour vector of the runner-up
-                        uint32_t cr = __builtin_amdgcn_readfirstlane(wordr);
-                        if (cr > stride - 1) cr = stride - 1;
-                        if (lane >= 1 && (uint32_t)lane <= cr) {
-                            const uint32_t *pv = reinterpret_cast<const uint32_t *>(g.vec + (size_t)wordr * g.dim);
-                            pf0 = pv[0];
-                            if (T > 1) pf1 = pv[32];
-                            if (T > 2) pf2 = pv[64];
-                            if (T > 3) pf3 = pv[96];
-                        }
+                    if (r0 == 0 && __ballot(ptake)) {          // deferred merge, under the loads just issued
+                        nW = merge_regs<R>(w, m.W, nW, ef, pkey, ptake, lane);
+                        ptake = false;
+                        PH_MARK(ctr, 3);
                     }
 #pragma unroll
                     for (int rr = 0; rr < RB; ++rr) {
                         const int r = r0 + rr;
-                        if ((pm >> (r * 8 + grp)) & 1u) {
-                            const float d = avx_reduce(avx_accumulate<T>(qr.q, v[rr])); // core.rs:652
-                            if (sub == r) { key = pack_key(d, idr[rr]); have = true; }
-                        }
+                        const float d = avx_reduce(avx_accumulate<T>(qr.q, v[rr]));    // core.rs:652
+                        if (sub == r && ((pm >> (r * 8 + grp)) & 1u)) { key = pack_key(d, idr[rr]); have = true; }
                     }
                 }
+                PH_MARK(ctr, 2);  // vector gather + distances
                 const uint64_t worst = nW == ef ? w_at<R>(w, ef - 1) : ~0ull;     // core.rs:651
-                nW = merge_regs<R>(w, m.W, nW, ef, key, have && key < worst, lane); // core.rs:657-664
+                const bool take = have && key < worst;                            // core.rs:657
+                if (last_chunk && (pass == 1 || (fms >> 32) == 0)) {
+                    // last merge of this expansion: choose the next candidate now
+                    uint64_t rkey = ~0ull;
+                    int r2, l2;
+                    const bool have_r = first_unexpanded<R>(w, rkey, r2, l2);
+                    if (!have_r) rkey = ~0ull;
+                    uint64_t bm = __ballot(take && key < rkey);
+                    nkey = rkey;
+                    while (bm) {
+                        const int j = __ffsll((unsigned long long)bm) - 1;
+                        bm &= bm - 1;
+                        const uint64_t kj = readlane64(key, j);
+                        if (kj < nkey) nkey = kj;
+                    }
+                    have_next = nkey != ~0ull;
+                    if (have_next) {
+                        row_next = row_ptr(g, key_id(nkey), lc);
+                        word_next = (uint32_t)lane < stride ? row_next[lane] : 0u;
+                    }
+                    next_issued = true;
+                    pkey = key;                                                   // merged next expansion
+                    ptake = take;
+                    PH_MARK(ctr, 4);  // choose next + request its row
+                } else {
+                    nW = merge_regs<R>(w, m.W, nW, ef, key, take, lane);          // core.rs:659-664
+                    PH_MARK(ctr, 3);  // merge into W
+                }
             }
         }
-        pf_id = rid;
-        pf_word = wordr;
+        if (!next_issued) {
+            // the last chunk had no unvisited neighbour: nothing is in flight to hide a merge under
+            if (__ballot(ptake)) {
+                nW = merge_regs<R>(w, m.W, nW, ef, pkey, ptake, lane);
+                ptake = false;
+            }
+            int r2, l2;
+            have_next = first_unexpanded<R>(w, nkey, r2, l2);
+            if (have_next) {
+                row_next = row_ptr(g, key_id(nkey), lc);
+                word_next = (uint32_t)lane < stride ? row_next[lane] : 0u;
+            }
+        }
+        if (!have_next) break;                                   // core.rs:630,635
+        // mark the chosen entry expanded (core.rs:631 pop)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (w[r] == nkey) w[r] |= 1ull;
+        if (ptake && pkey == nkey) pkey |= 1ull;
+        ckey = nkey;
+        row = row_next;
+        word = word_next;
     }
-    if (kPrefetch) asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2), "v"(pf3));
+    if (__ballot(ptake)) nW = merge_regs<R>(w, m.W, nW, ef, pkey, ptake, lane);
     // leave W in LDS for the callers (top-k output, select_neighbors)
 #pragma unroll
     for (int r = 0; r < R; ++r) m.W[r * 64 + lane] = w[r];

@@ -47,6 +47,7 @@ struct hnsw_index {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_sync = nullptr;
     bool ev_valid = false;
     int lds_buckets_override = -1;
+    bool prefetch = true;
     uint32_t lds_fill_x2 = 13;       // LDS visited table holds lnb * fill/2 ids (of 7 per bucket) before spilling
     int grid_override = -1;
     uint32_t fast_seed = 512, fast_batch_max = 4096, fast_batch_div = 8;
@@ -135,6 +136,7 @@ GraphView view(const hnsw_index *h)
     g.dim = h->dim;
     g.stride0 = h->stride0;
     g.strideU = h->strideU;
+    g.flags = h->prefetch ? 1u : 0u;
     return g;
 }
 
@@ -475,6 +477,7 @@ const char *hnsw_last_error(const hnsw_index *h) { return h ? h->err.c_str() : "
 hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
 {
     if (!h || !key) return HNSW_ERR_INVALID;
+    if (!std::strcmp(key, "prefetch")) { h->prefetch = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "lds_fill_x2")) { h->lds_fill_x2 = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 2), 13); return HNSW_OK; }
     if (!std::strcmp(key, "lds_buckets")) { h->lds_buckets_override = (int)value; return HNSW_OK; }
     if (!std::strcmp(key, "lds_hash_bits")) { h->lds_buckets_override = std::max<int>(2, (int)((1ll << value) / 8)); return HNSW_OK; }

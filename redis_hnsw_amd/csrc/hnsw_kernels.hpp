@@ -35,6 +35,10 @@ __global__ __launch_bounds__(64) void k_search(GraphView g, const float *__restr
     const uint32_t lmax = g.hdr->max_layer;       // core.rs:867
 
     for (uint32_t qi = blockIdx.x; qi < B; qi += gridDim.x) {
+#ifdef HNSW_PHASE_TIMERS
+        const unsigned long long q_t0 = __builtin_readcyclecounter();
+        const uint32_t q_e0 = ctr.n_expand, q_d0 = ctr.n_dist;
+#endif
         QReg<T> qr;
         load_query<MODE, T>(Q + (size_t)qi * g.dim, g.dim, qr, m.qlds, lane);
         bool fail = false;
@@ -58,6 +62,15 @@ __global__ __launch_bounds__(64) void k_search(GraphView g, const float *__restr
             out_sims[(size_t)qi * k + i] = i < nres ? -key_dist(key) : -__builtin_inff();
         }
         if (lane == 0) out_n[qi] = fail ? kEmpty : nres;
+#ifdef HNSW_PHASE_TIMERS
+        // profiling builds only: per-query (kilo-cycles, expansions, distance evals) in the last result slots
+        if (lane == 0 && k >= 4) {
+            out_ids[(size_t)qi * k + k - 1] = (uint32_t)((__builtin_readcyclecounter() - q_t0) >> 10);
+            out_ids[(size_t)qi * k + k - 2] = ctr.n_expand - q_e0;
+            out_ids[(size_t)qi * k + k - 3] = ctr.n_dist - q_d0;
+            out_ids[(size_t)qi * k + k - 4] = (uint32_t)__builtin_amdgcn_s_getreg(((1 - 1) << 11) | (0 << 6) | 20); // XCC_ID
+        }
+#endif
         __syncthreads();
     }
     // leave the HBM spill table clean for the next launch

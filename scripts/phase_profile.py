@@ -52,3 +52,16 @@ if hasattr(lib, "hnsw_debug_phase_cycles"):
         print("  wave lifetime: mean %.0f cycles, max-of-run %.0f cycles, max %.1f us (memrealtime) -> clock ~%.2f GHz" % (
             out[5] / waves, out[6], out[7] / 100.0, out[6] / (out[7] * 10.0)))
         print("  total cycles/expansion %.0f ; cycles/query %.0f" % (tot / per_step, tot / (reps * B)))
+
+if hasattr(lib, "hnsw_debug_phase_cycles") and sum(out[:4]):
+    run(0); torch.cuda.synchronize()
+    a = ids.cpu().numpy().astype(np.int64)
+    kc, ne, nd = a[:, k - 1], a[:, k - 2], a[:, k - 3]
+    print("per-query kcycles: mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % (kc.mean(), np.percentile(kc, 50), np.percentile(kc, 90), np.percentile(kc, 99), kc.max()))
+    print("per-query expansions: mean %.0f p99 %.0f max %d ; dist: mean %.0f p99 %.0f max %d" % (ne.mean(), np.percentile(ne, 99), ne.max(), nd.mean(), np.percentile(nd, 99), nd.max()))
+    print("cycles per expansion by query: p50 %.0f p99 %.0f max %.0f" % tuple(np.percentile(kc * 1024.0 / ne, [50, 99, 100])))
+    order = np.argsort(kc)[-8:]
+    print("slowest queries (idx, kcycles, expansions, dist):", [(int(i), int(kc[i]), int(ne[i]), int(nd[i])) for i in order])
+    print("corr(kcycles, dist) = %.3f" % np.corrcoef(kc, nd)[0, 1])
+    blk = np.arange(B)
+    print("mean kcycles by block%%8 (XCD):", [int(kc[blk % 8 == x].mean()) for x in range(8)])
