@@ -587,17 +587,21 @@ __device__ __forceinline__ uint32_t bperm(uint32_t v, int src_lane)
     return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
 }
 
+// Merge of up to 64 keys (one per lane flagged `take`) into the register-resident sorted list, in
+// two halves so that each can run under a different memory wait:
+//   merge_rank   how far every old entry moves up (number of new keys below it) and where every
+//                new key lands (#old below + #new below)
+//   merge_apply  scatter through LDS + read back
+// The result equals the reference pushing the neighbours one by one (core.rs:657-664): the list
+// ends as the top-`cap` of the union.
 template <int R>
-__device__ __forceinline__ uint32_t merge_regs(uint64_t (&w)[R], uint64_t *Wbuf, uint32_t nW, uint32_t cap,
-                                               uint64_t nk, bool take, int lane)
+__device__ __forceinline__ void merge_rank(const uint64_t (&w)[R], uint64_t nk, bool take, uint32_t (&up)[R],
+                                           uint32_t &mypos, int lane)
 {
-    const uint64_t tmask = __ballot(take);
-    if (tmask == 0) return nW;
-    uint32_t up[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) up[r] = 0;
-    uint32_t mypos = 0;
-    uint64_t mm = tmask;
+    mypos = 0;
+    uint64_t mm = __ballot(take);
     while (mm) {
         const int j = __ffsll((unsigned long long)mm) - 1;
         mm &= mm - 1;
@@ -605,14 +609,21 @@ __device__ __forceinline__ uint32_t merge_regs(uint64_t (&w)[R], uint64_t *Wbuf,
         uint32_t rank = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const bool below = w[r] < s;          // slots past nW hold ~0: never below
+            const bool below = w[r] < s;          // slots past the end hold ~0: never below
             rank += __popcll(__ballot(below));
             up[r] += below ? 0u : 1u;
         }
         rank += __popcll(__ballot(take && nk < s));
         if (lane == j) mypos = rank;
     }
-    uint32_t total = nW + (uint32_t)__popcll(tmask);
+}
+
+template <int R>
+__device__ __forceinline__ uint32_t merge_apply(uint64_t (&w)[R], uint64_t *Wbuf, uint32_t nW, uint32_t cap,
+                                                uint64_t nk, bool take, const uint32_t (&up)[R], uint32_t mypos,
+                                                int lane)
+{
+    uint32_t total = nW + (uint32_t)__popcll(__ballot(take));
     if (total > cap) total = cap;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -634,6 +645,16 @@ __device__ __forceinline__ uint32_t merge_regs(uint64_t (&w)[R], uint64_t *Wbuf,
     }
     __builtin_amdgcn_wave_barrier();
     return total;
+}
+
+template <int R>
+__device__ __forceinline__ uint32_t merge_regs(uint64_t (&w)[R], uint64_t *Wbuf, uint32_t nW, uint32_t cap,
+                                               uint64_t nk, bool take, int lane)
+{
+    if (__ballot(take) == 0) return nW;
+    uint32_t up[R], mypos;
+    merge_rank<R>(w, nk, take, up, mypos, lane);
+    return merge_apply<R>(w, Wbuf, nW, cap, nk, take, up, mypos, lane);
 }
 
 // first entry whose expanded bit is clear (slots past nW hold ~0, bit set)
@@ -698,6 +719,9 @@ __device__ uint32_t search_level_v2(const GraphView &g, const WaveMem &m, Visite
     // expansion's vector loads have been issued, i.e. under their latency
     uint64_t pkey = ~0ull;
     bool ptake = false;
+    uint32_t pup[R], ppos = 0;     // its ranks, computed under the row-fetch latency
+#pragma unroll
+    for (int r = 0; r < R; ++r) pup[r] = 0;
     __syncthreads();
     PH_T0();
 
@@ -761,8 +785,8 @@ __device__ uint32_t search_level_v2(const GraphView &g, const WaveMem &m, Visite
 #pragma unroll
                         for (int t = 0; t < T; ++t) v[rr][t] = p[t * 8];
                     }
-                    if (r0 == 0 && __ballot(ptake)) {          // deferred merge, under the loads just issued
-                        nW = merge_regs<R>(w, m.W, nW, ef, pkey, ptake, lane);
+                    if (r0 == 0 && __ballot(ptake)) {          // deferred scatter, under the loads just issued
+                        nW = merge_apply<R>(w, m.W, nW, ef, pkey, ptake, pup, ppos, lane);
                         ptake = false;
                         PH_MARK(ctr, 3);
                     }
@@ -808,7 +832,7 @@ __device__ uint32_t search_level_v2(const GraphView &g, const WaveMem &m, Visite
         if (!next_issued) {
             // the last chunk had no unvisited neighbour: nothing is in flight to hide a merge under
             if (__ballot(ptake)) {
-                nW = merge_regs<R>(w, m.W, nW, ef, pkey, ptake, lane);
+                nW = merge_apply<R>(w, m.W, nW, ef, pkey, ptake, pup, ppos, lane);
                 ptake = false;
             }
             int r2, l2;
@@ -824,10 +848,16 @@ __device__ uint32_t search_level_v2(const GraphView &g, const WaveMem &m, Visite
         for (int r = 0; r < R; ++r)
             if (w[r] == nkey) w[r] |= 1ull;
         if (ptake && pkey == nkey) pkey |= 1ull;
+        // ranks of the pending keys: pure ALU work, runs while the row just requested is in flight
+        if (__ballot(ptake)) {
+            merge_rank<R>(w, pkey, ptake, pup, ppos, lane);
+            PH_MARK(ctr, 5);
+        }
         ckey = nkey;
         row = row_next;
         word = word_next;
     }
+    // the last expansion's keys were never ranked (the loop ended before that point)
     if (__ballot(ptake)) nW = merge_regs<R>(w, m.W, nW, ef, pkey, ptake, lane);
     // leave W in LDS for the callers (top-k output, select_neighbors)
 #pragma unroll

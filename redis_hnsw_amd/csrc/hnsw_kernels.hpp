@@ -80,11 +80,9 @@ __global__ __launch_bounds__(64) void k_search(GraphView g, const float *__restr
         atomicAdd(&g.hdr->ctr_search[1], (unsigned long long)ctr.n_ids);
         atomicAdd(&g.hdr->ctr_search[2], (unsigned long long)ctr.n_expand);
 #ifdef HNSW_PHASE_TIMERS
-        for (int i = 0; i < 5; ++i) atomicAdd(&g.hdr->prof[i], ctr.ph[i]);
-        const unsigned long long dt = __builtin_readcyclecounter() - wave_t0;
-        atomicAdd(&g.hdr->prof[5], dt);                       // sum of wave lifetimes (cycles)
-        atomicMax(&g.hdr->prof[6], dt);                       // longest wave (cycles)
+        for (int i = 0; i < 7; ++i) atomicAdd(&g.hdr->prof[i], ctr.ph[i]);
         atomicMax(&g.hdr->prof[7], __builtin_amdgcn_s_memrealtime() - real_t0); // longest wave (100 MHz ticks)
+        (void)wave_t0;
 #endif
     }
 }

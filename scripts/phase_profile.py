@@ -47,10 +47,10 @@ if hasattr(lib, "hnsw_debug_phase_cycles"):
         per_step = sc.n_expand
         for i, nm in enumerate(names):
             print("  %-16s %6.1f%%  %8.0f cycles/expansion" % (nm, 100.0 * out[i] / tot, out[i] / per_step))
-        print("  runner-up prediction hit rate %.3f" % (out[4] / per_step))
-        waves = reps * min(B, 2048)
-        print("  wave lifetime: mean %.0f cycles, max-of-run %.0f cycles, max %.1f us (memrealtime) -> clock ~%.2f GHz" % (
-            out[5] / waves, out[6], out[7] / 100.0, out[6] / (out[7] * 10.0)))
+        print("  choose next + row request   %8.0f cycles/expansion" % (out[4] / per_step))
+        print("  deferred merges: %.2f accepted keys/expansion, rank loop %.0f cycles/expansion (%.0f per key)" % (
+            out[5] / per_step, out[6] / per_step, out[6] / max(out[5], 1)))
+        print("  longest wave %.1f us" % (out[7] / 100.0))
         print("  total cycles/expansion %.0f ; cycles/query %.0f" % (tot / per_step, tot / (reps * B)))
 
 if hasattr(lib, "hnsw_debug_phase_cycles") and sum(out[:4]):
