@@ -30,8 +30,13 @@ struct hnsw_index {
     DevHeader *d_hdr = nullptr;
     std::vector<uint32_t> h_levels, h_upper_base;
     // search scratch
+    // HBM spill tables of the visited sets: kSpillRegions regions, handed out round-robin so that
+    // launches overlapping on different streams never share one (an event per region orders reuse)
     uint32_t *d_spill = nullptr;
     uint32_t spill_gnb = 0, spill_slots = 0;
+    hipEvent_t spill_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool spill_busy[4] = {false, false, false, false};
+    uint32_t spill_rr = 0;
     float *d_Q = nullptr;
     uint32_t *d_ids = nullptr, *d_nout = nullptr;
     float *d_sims = nullptr;
@@ -260,6 +265,32 @@ uint32_t pick_lnb(const hnsw_index *h, int R, int T, bool ins, uint32_t nwaves)
     return std::max(std::min(fit, useful), 2u);
 }
 
+constexpr uint32_t kSpillRegions = 4;
+
+// Pick the next spill region for a launch on `st`; the stream first waits for the launch that used
+// that region last.  Call spill_release() right after enqueueing the kernel.
+hnsw_status spill_acquire(hnsw_index *h, hipStream_t st, uint32_t *region, uint32_t **base)
+{
+    const uint32_t r = h->spill_rr++ % kSpillRegions;
+    if (h->spill_busy[r]) HIP_TRY(h, hipStreamWaitEvent(st, h->spill_ev[r], 0));
+    *region = r;
+    *base = h->d_spill + (size_t)r * h->spill_slots * h->spill_gnb * 8;
+    return HNSW_OK;
+}
+hnsw_status spill_release(hnsw_index *h, hipStream_t st, uint32_t region)
+{
+    HIP_TRY(h, hipEventRecord(h->spill_ev[region], st));
+    h->spill_busy[region] = true;
+    return HNSW_OK;
+}
+// an insert must not start while searches enqueued on other streams are still reading the graph
+hnsw_status wait_inflight_searches(hnsw_index *h)
+{
+    for (uint32_t r = 0; r < kSpillRegions; ++r)
+        if (h->spill_busy[r]) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->spill_ev[r], 0));
+    return HNSW_OK;
+}
+
 __global__ void k_fill_buckets(uint4 *t, size_t n16)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -277,13 +308,14 @@ hnsw_status ensure_spill(hnsw_index *h)
     uint32_t gnb = (uint32_t)(want / 6) + 16;           // 6 of the 7 id slots per bucket
     const uint32_t slots = 2048;
     if (h->d_spill && h->spill_gnb >= gnb && h->spill_slots >= slots) return HNSW_OK;
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    dev_free(h, h->d_spill, (size_t)h->spill_slots * h->spill_gnb * 8);
-    hnsw_status s = dev_alloc(h, &h->d_spill, (size_t)slots * gnb * 8);
+    HIP_TRY(h, hipDeviceSynchronize());          // nothing may still be using the old tables
+    dev_free(h, h->d_spill, (size_t)kSpillRegions * h->spill_slots * h->spill_gnb * 8);
+    hnsw_status s = dev_alloc(h, &h->d_spill, (size_t)kSpillRegions * slots * gnb * 8);
     if (s != HNSW_OK) return s;
     hipLaunchKernelGGL(k_fill_buckets, dim3(4096), dim3(256), 0, h->stream, reinterpret_cast<uint4 *>(h->d_spill),
-                       (size_t)slots * gnb * 2);
+                       (size_t)kSpillRegions * slots * gnb * 2);
     HIP_TRY(h, hipGetLastError());
+    for (uint32_t r = 0; r < kSpillRegions; ++r) h->spill_busy[r] = false;
     h->spill_gnb = gnb;
     h->spill_slots = slots;
     return HNSW_OK;
@@ -300,11 +332,15 @@ hnsw_status launch_search_t(hnsw_index *h, const float *dQ, uint32_t B, uint32_t
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     uint32_t grid = std::min(B, h->spill_slots);
     if (h->grid_override > 0) grid = std::min<uint32_t>(grid, (uint32_t)h->grid_override);
+    uint32_t region, *spill;
+    hnsw_status ss = spill_acquire(h, st, &region, &spill);
+    if (ss != HNSW_OK) return ss;
     HIP_TRY(h, hipEventRecord(h->ev0, st));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, st, view(h), dQ, B, k, h->efc, lnb, lnb * h->lds_fill_x2 / 2, h->d_spill,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, st, view(h), dQ, B, k, h->efc, lnb, lnb * h->lds_fill_x2 / 2, spill,
                        h->spill_gnb, d_ids, d_sims, d_nout);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->ev1, st));
+    if ((ss = spill_release(h, st, region)) != HNSW_OK) return ss;
     h->ev_valid = true;
     return HNSW_OK;
 }
@@ -443,6 +479,7 @@ hnsw_status hnsw_create(uint32_t dim, uint32_t m, uint32_t ef_construction, uint
     HIP_TRY(h, hipEventCreate(&h->ev0));
     HIP_TRY(h, hipEventCreate(&h->ev1));
     HIP_TRY(h, hipEventCreateWithFlags(&h->ev_sync, hipEventDisableTiming));
+    for (uint32_t r = 0; r < kSpillRegions; ++r) HIP_TRY(h, hipEventCreateWithFlags(&h->spill_ev[r], hipEventDisableTiming));
     h->stride0 = default_stride(h->m_max0, m, 0);
     h->strideU = default_stride(h->m_max, m, 0);
     hnsw_status s;
@@ -468,6 +505,7 @@ void hnsw_destroy(hnsw_index *h)
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_sync) (void)hipEventDestroy(h->ev_sync);
+    for (uint32_t r = 0; r < kSpillRegions; ++r) if (h->spill_ev[r]) (void)hipEventDestroy(h->spill_ev[r]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
