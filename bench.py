@@ -233,14 +233,18 @@ def main():
                    sample="%d queries of the same 1024-query batch on the same graph, 1 thread, %.1f s" % (done, t1),
                    all_cores=dict(value=round(reps * B / tN, 1), cores=cores))
 
+    known = {(1_000_000, 128, 16, 200, 10, 1024): "C2", (1_000_000, 768, 32, 400, 100, 4096): "C3",
+             (10_000_000, 128, 16, 200, 10, 1024): "C4"}
+    cfg_name = known.get((N, dim, M, ef, k, B), "custom")
     qps = world * B * args.steps / t_wall
     out = {
-        "metric": "HNSW.SEARCH QPS + recall@10, 1M x 128 f32, ef=200",
+        "metric": "HNSW.SEARCH QPS + recall@10, 1M x 128 f32, ef=200" if cfg_name == "C2" else
+                  "HNSW.SEARCH QPS + recall@%d (%s)" % (k, cfg_name),
         "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * t_wall / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "C2: %d nodes x dim %d, M=%d, ef=%d, k=%d, batch=%d queries/GPU, uniform[0,1) f32, replicated index"
-                               % (N, dim, M, ef, k, B),
+        "config": {"workload": "%s: %d nodes x dim %d, M=%d, ef=%d, k=%d, batch=%d queries/GPU, uniform[0,1) f32, replicated index"
+                               % (cfg_name, N, dim, M, ef, k, B),
                    "nodes": N, "dim": dim, "M": M, "ef": ef, "k": k, "batch": B, "build": args.build,
                    "parallelism": "replica x%d, query batch sharded" % world},
         "recall_at_10": None if recall is None else round(recall, 4),

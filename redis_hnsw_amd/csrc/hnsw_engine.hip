@@ -53,6 +53,7 @@ struct hnsw_index {
     bool ev_valid = false;
     int lds_buckets_override = -1;
     bool prefetch = true;
+    bool fast_built = false;        // the fast build prunes one-directionally: links may be asymmetric
     uint32_t lds_fill_x2 = 13;       // LDS visited table holds lnb * fill/2 ids (of 7 per bucket) before spilling
     int grid_override = -1;
     uint32_t fast_seed = 512, fast_batch_max = 4096, fast_batch_div = 8;
@@ -432,8 +433,10 @@ hnsw_status check_dev_status(hnsw_index *h, const DevHeader &hd)
              (hd.status & ST_ROW_OVERFLOW) ? " adjacency row overflow" : "",
              (hd.status & ST_ROW_DROPPED) ? " reverse link dropped" : "",
              (hd.status & ST_ASYMMETRIC) ? " asymmetric link" : "");
-    // ROW_DROPPED is informational for the fast build
-    if ((hd.status & ~ST_ROW_DROPPED) == 0) return HNSW_OK;
+    // ROW_DROPPED is informational for the fast build, and so is a missing back link on a graph the
+    // fast build produced (the reference would panic there, core.rs:150; its own graphs are symmetric)
+    uint32_t benign = ST_ROW_DROPPED | (h->fast_built ? ST_ASYMMETRIC : 0u);
+    if ((hd.status & ~benign) == 0) return HNSW_OK;
     return fail(h, HNSW_ERR_CAPACITY, buf);
 }
 
@@ -577,6 +580,7 @@ hnsw_status hnsw_add_batch(hnsw_index *h, const float *V, uint32_t n, uint32_t d
     if (done == n) return HNSW_OK;
 
     // ---- fast build ---------------------------------------------------------
+    h->fast_built = true;
     const uint32_t first = h->n, rest = n - done;
     if (std::max(h->stride0, h->strideU) > 129) return fail(h, HNSW_ERR_INVALID, "fast build needs row strides <= 129");
     std::vector<uint32_t> lv(rest);

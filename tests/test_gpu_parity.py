@@ -292,3 +292,105 @@ def test_fast_build_recall_parity(eng, oracle_mod, built):
     oids2, osims2, _, _ = o2.search_batch(Q, k)
     assert np.array_equal(ids, oids2) and np.array_equal(_bits(sims), _bits(osims2))
     gi.close()
+
+
+# ---- edge cases --------------------------------------------------------------------------
+def test_search_edge_cases(eng, oracle_mod, built):
+    n, dim, m, ef = 1200, 32, 5, 16
+    V, o, lv = built(n, dim, m, ef)
+    gi = eng.Index("foo", dim, m, ef)
+    gi.import_graph(o.export())
+    # k larger than ef: min(k, ef, reachable) results (core.rs:878-890), padded rows
+    Q = make_data(5, dim, seed=9)
+    ids, sims, n_out = gi.search_batch(Q, 40)
+    oids, osims, on, _ = o.search_batch(Q, 40)
+    assert np.array_equal(n_out, on) and int(n_out.max()) <= ef
+    for i in range(5):
+        c = int(on[i])
+        assert np.array_equal(ids[i, :c], oids[i, :c]) and np.all(ids[i, c:] == 0xFFFFFFFF)
+        assert np.all(np.isneginf(sims[i, c:]))
+    # a query equal to a stored vector: similarity is -0.0 exactly like -(+0.0) on the CPU (metrics.rs:75)
+    ids, sims, n_out = gi.search_batch(V[17:18], 3)
+    oids, osims, _, _ = o.search_batch(V[17:18], 3)
+    assert ids[0, 0] == 17 and np.array_equal(_bits(sims), _bits(osims))
+    assert _bits(sims)[0, 0] == 0x80000000
+    # batch sizes that are not multiples of anything, and larger than the resident grid
+    for B in (1, 3, 65, 2500):
+        Qb = make_data(B, dim, seed=20 + B)
+        ids, sims, n_out = gi.search_batch(Qb, 5)
+        oids, osims, on, _ = o.search_batch(Qb, 5)
+        assert np.array_equal(n_out, on)
+        # some nodes of this M=5 graph end up with an empty layer-0 row (the reference's shrink can strip
+        # a node bare), so a few queries reach fewer than k results: compare the valid prefix only
+        valid = np.arange(5)[None, :] < on[:, None]
+        assert np.array_equal(ids[valid], oids[valid]) and np.array_equal(_bits(sims)[valid], _bits(osims)[valid])
+        assert np.all(ids[~valid] == 0xFFFFFFFF)
+    gi.close()
+
+
+def test_import_then_exact_insert_continues_identically(eng, oracle_mod):
+    """make_index-style bulk load (src/lib.rs:252-315) followed by HNSW.NODE.ADD: same graph as the oracle doing both"""
+    n0, n1, dim, m, ef = 500, 150, 32, 6, 24
+    V = make_data(n0 + n1, dim, seed=31)
+    lv = oracle_mod.draw_levels(n0 + n1, m, 8)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch(V[:n0], lv[:n0])
+    gi = eng.Index("foo", dim, m, ef)
+    gi.import_graph(o.export())
+    for i in range(n0, n0 + n1):
+        o.add(V[i], int(lv[i]))
+        gi.add_node("node%d" % i, V[i], level=int(lv[i]))
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    gi.close()
+
+
+def test_exact_insert_with_duplicate_vectors_and_ties(eng, oracle_mod):
+    """every vector stored three times: all similarities tie in triples; the (sim, id) order decides"""
+    base = make_data(120, 8, seed=41)
+    V = np.concatenate([base, base, base])
+    n, dim, m, ef = V.shape[0], 8, 4, 12
+    lv = oracle_mod.draw_levels(n, m, 2)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch(V, lv)
+    gi = eng.Index("foo", dim, m, ef)
+    gi.add_batch(V, levels=lv, mode="exact")
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    ids, sims, n_out = gi.search_batch(base[:32], 6)
+    oids, osims, on, _ = o.search_batch(base[:32], 6)
+    assert np.array_equal(ids, oids) and np.array_equal(_bits(sims), _bits(osims))
+    gi.close()
+
+
+def test_exact_insert_after_fast_build(eng, oracle_mod):
+    """HNSW.NODE.ADD on a fast-built (not necessarily symmetric) graph must work and stay searchable"""
+    n, dim, m, ef = 3000, 32, 8, 64
+    V = make_data(n + 50, dim, seed=51)
+    gi = eng.Index("foo", dim, m, ef)
+    gi.add_batch(V[:n], mode="fast")
+    for i in range(n, n + 50):
+        gi.add_node("node%d" % i, V[i])
+    assert gi.node_count == n + 50
+    res = gi.search_knn(V[n + 7], 1)
+    assert res[0].id == n + 7 and res[0].sim == 0.0
+    gi.close()
+
+
+def test_many_layers_small_m(eng, oracle_mod):
+    """M=2 gives level_mult = 1/ln 2: tall hierarchies (10+ layers) and tiny rows"""
+    n, dim, m, ef = 600, 32, 2, 8
+    V = make_data(n, dim, seed=61)
+    lv = oracle_mod.draw_levels(n, m, 3)
+    assert lv.max() >= 7
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch(V, lv)
+    gi = eng.Index("foo", dim, m, ef)
+    gi.add_batch(V, levels=lv, mode="exact")
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    Q = make_data(40, dim, seed=2)
+    ids, sims, _ = gi.search_batch(Q, 5)
+    oids, osims, _, _ = o.search_batch(Q, 5)
+    assert np.array_equal(ids, oids) and np.array_equal(_bits(sims), _bits(osims))
+    gi.close()
