@@ -63,12 +63,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    if os.environ.get("HNSW_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
+    # HNSW_BENCH_BACKEND=gloo + HNSW_BENCH_ONE_DEVICE=1 let the N>1 control flow be exercised on a
+    # single-GPU box (every rank on cuda:0, collectives on host copies); the driver's runs use RCCL.
+    backend = os.environ.get("HNSW_BENCH_BACKEND", "nccl")
+    coll_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     def log(msg):
         if rank == 0:
@@ -98,7 +107,7 @@ def main():
     if world > 1:
         # one-time index distribution: rank 0's graph to every replica over RCCL
         from redis_hnsw_amd import shard
-        g = shard.broadcast_graph(dist, graph, N, src=0, device=torch.device("cuda", local_rank))
+        g = shard.broadcast_graph(dist, graph, N, src=0, device=coll_dev)
         if rank != 0:
             g["vectors"] = V
             index.import_graph(g)
@@ -110,8 +119,8 @@ def main():
     d_ids = torch.empty((B, k), dtype=torch.int32, device=dev)
     d_sims = torch.empty((B, k), dtype=torch.float32, device=dev)
     d_n = torch.empty((B,), dtype=torch.int32, device=dev)
-    g_ids = torch.empty((world * B, k), dtype=torch.int32, device=dev) if world > 1 else None
-    g_sims = torch.empty((world * B, k), dtype=torch.float32, device=dev) if world > 1 else None
+    g_ids = torch.empty((world * B, k), dtype=torch.int32, device=coll_dev) if world > 1 else None
+    g_sims = torch.empty((world * B, k), dtype=torch.float32, device=coll_dev) if world > 1 else None
     stream = torch.cuda.current_stream()
 
     def step(i):
@@ -119,7 +128,10 @@ def main():
         index.search_batch_device(q.data_ptr(), B, k, d_ids.data_ptr(), d_sims.data_ptr(), d_n.data_ptr(),
                                   stream.cuda_stream)
         if world > 1:   # the path's one real exchange: gather every shard's top-k
-            shard.gather_topk(dist, d_ids, d_sims, world, g_ids, g_sims)
+            if backend == "nccl":
+                shard.gather_topk(dist, d_ids, d_sims, world, g_ids, g_sims)
+            else:
+                shard.gather_topk(dist, d_ids.cpu(), d_sims.cpu(), world, g_ids, g_sims)
 
     log("inputs resident; warm-up")
     for i in range(args.warmup):
@@ -140,7 +152,7 @@ def main():
         dist.barrier()
     t_wall = time.perf_counter() - t_start
     if world > 1:
-        tt = torch.tensor([t_wall], dtype=torch.float64, device=dev)
+        tt = torch.tensor([t_wall], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_wall = float(tt.item())
     stream_ms = ev0.elapsed_time(ev1)
