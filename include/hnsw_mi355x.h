@@ -57,6 +57,7 @@ typedef struct {
     uint32_t stride0, stride_upper; /* words per adjacency row (slot 0 = count) */
     uint32_t max_degree0, max_degree_upper;
     uint64_t hbm_bytes;        /* device memory held by the handle           */
+    uint32_t allocated_ids;    /* ids handed out so far (deleted ids are not reused) */
 } hnsw_info;
 
 /* Index::new (core.rs:322-347): m_max = m, m_max0 = 2m, level_mult = 1/ln m.
@@ -84,6 +85,14 @@ hnsw_status hnsw_add(hnsw_index *h, const float *v, uint32_t dim, int32_t level,
  * reference's serial order; judged by recall parity only.  levels may be NULL. */
 hnsw_status hnsw_add_batch(hnsw_index *h, const float *V, uint32_t n, uint32_t dim,
                            const int32_t *levels, uint32_t mode);
+
+/* Index::delete_node (core.rs:414-475 -> delete_node_from_neighbors :824-863), executed on the GPU
+ * in the reference's serial order.  The id becomes a tombstone (never reused); node_count drops.
+ * If the node was the enterpoint, the new one is the smallest id of the highest non-empty layer
+ * (the reference takes an arbitrary node of that layer, core.rs:453).  HNSW_ERR_NOT_FOUND if id is
+ * not a live node (core.rs:421).  touched as for hnsw_add.                                        */
+hnsw_status hnsw_delete(hnsw_index *h, uint32_t id, uint32_t *touched, uint32_t touched_cap,
+                        uint32_t *n_touched);
 
 /* Index::search_knn (core.rs:477-486 -> :865-892); ef = ef_construction
  * (core.rs:485).  Writes min(k, ef, reachable) results, nearest first; an empty

@@ -203,6 +203,8 @@ struct hnsw_oracle {                                   /* core.rs:303-319  */
     int64_t enterpoint;
     float *data; uint32_t cap;
     onode *nodes;
+    uint8_t *dead;                                     /* tombstones: ids are never reused      */
+    uint32_t n_dead;
     uint64_t rng[4];
     scratch sc;
     uint32_t *touch; uint32_t n_touch, touch_cap;      /* `updated` sets    */
@@ -507,7 +509,7 @@ void hnsw_oracle_free(hnsw_oracle *o)
             free(nd->rows);
         }
     }
-    free(o->nodes); free(o->data); free(o->touch); free(o->touch_stamp);
+    free(o->nodes); free(o->data); free(o->touch); free(o->touch_stamp); free(o->dead);
     scratch_free(&o->sc);
     free(o);
 }
@@ -528,6 +530,8 @@ static void ensure_cap(hnsw_oracle *o)
     o->cap = o->cap ? o->cap * 2 : 1024;
     o->data = (float *)realloc(o->data, (size_t)o->cap * o->dim * sizeof(float));
     o->nodes = (onode *)realloc(o->nodes, (size_t)o->cap * sizeof(onode));
+    o->dead = (uint8_t *)realloc(o->dead, (size_t)o->cap);
+    memset(o->dead + o->node_count, 0, (size_t)(o->cap - o->node_count));
 }
 
 static uint32_t store_node(hnsw_oracle *o, const float *v, uint32_t level)
@@ -601,7 +605,7 @@ int64_t hnsw_oracle_add(hnsw_oracle *o, const float *v, int32_t level,
                         uint32_t *touched, uint32_t touched_cap, uint32_t *n_touched)
 {
     if (n_touched) *n_touched = 0;
-    if (o->node_count == 0) {                           /* :393-405 */
+    if (o->node_count - o->n_dead == 0) {               /* :393-405 (node_count is the live count there) */
         uint32_t id = store_node(o, v, 0);
         o->enterpoint = id;
         return id;
@@ -651,7 +655,7 @@ uint32_t hnsw_oracle_search(const hnsw_oracle *o, const float *q, uint32_t k,
                             uint32_t *ids, float *sims, hnsw_oracle_counters *ctrs)
 {
     hnsw_oracle_counters local = { 0, 0, 0 };
-    if (o->enterpoint < 0 || o->node_count == 0) {      /* :481-483 */
+    if (o->enterpoint < 0 || o->node_count - o->n_dead == 0) { /* :481-483 */
         if (ctrs) *ctrs = local;
         return 0;
     }
@@ -707,6 +711,76 @@ void hnsw_oracle_search_batch(const hnsw_oracle *o, const float *Q, uint32_t B,
 }
 
 /* ========================================================================= */
+/* core.rs:414-475 delete_node, :824-863 delete_node_from_neighbors            */
+/* ========================================================================= */
+/* core.rs:824-863: every neighbour n of `node` at layer lc re-selects its links
+ * from its own neighbourhood (two hops) with `node` ignored.                  */
+static void delete_node_from_neighbors(hnsw_oracle *o, scratch *s, uint32_t node, uint32_t lc,
+                                       hnsw_oracle_counters *ct)
+{
+    /* the reference iterates a borrowed view of node's row (:826,829); the row is not
+     * modified during the loop (node is `ignored` everywhere), copy it for safety      */
+    const nrow *nr = row_of(o, node, lc);
+    uint32_t cnt = nr->n;
+    uint32_t *nbrs = (uint32_t *)malloc((size_t)(cnt ? cnt : 1) * 4);
+    memcpy(nbrs, nr->ids, (size_t)cnt * 4);
+    for (uint32_t k = 0; k < cnt; k++) {                /* :829 stored order   */
+        uint32_t n = nbrs[k];
+        heap *nconn = &s->econn;                        /* :832-844 */
+        heap_clear(nconn); nconn->furthest_top = 0;
+        const nrow *r = row_of(o, n, lc);
+        const float *nv = vec(o, n);
+        for (uint32_t i = 0; i < r->n; i++) {
+            simpair p = { hnsw_oracle_euclidean(nv, vec(o, r->ids[i]), o->dim), r->ids[i] }; /* :840-841 */
+            ct->n_dist++;
+            ct->n_ids++;
+            heap_push(nconn, p);
+        }
+        uint32_t m_max = lc == 0 ? o->m_max0 : o->m_max; /* :846 */
+        select_neighbors(o, s, n, nconn, m_max, lc, (int64_t)node, &s->enew, ct); /* :853 */
+        touch_add(o, n);                                /* :855 */
+        update_node_connections(o, s, n, &s->enew, nconn, lc, (int64_t)node); /* :856 */
+    }
+    free(nbrs);
+}
+
+/* core.rs:414-475.  Enterpoint re-election (:449-472) takes `layers[lc].iter().next()` of a
+ * HashSet in the reference, i.e. an arbitrary node of the highest non-empty layer; the oracle
+ * (and the engine) take the one with the SMALLEST ID.  Returns 0, or -1 if id is not a live node
+ * ("Node: {:?} does not exist", :421).                                                         */
+int hnsw_oracle_delete(hnsw_oracle *o, uint32_t id, uint32_t *touched, uint32_t touched_cap,
+                       uint32_t *n_touched)
+{
+    if (n_touched) *n_touched = 0;
+    if (id >= o->node_count || o->dead[id]) return -1;  /* :419-422 */
+    touch_reset(o);
+    uint32_t top = o->nodes[id].level;                  /* :434 node.neighbors.len() rows */
+    for (uint32_t lc = 0; lc <= top; lc++)              /* :434-439 ascending         */
+        delete_node_from_neighbors(o, &o->sc, id, lc, &o->ins);
+    o->dead[id] = 1;                                    /* :419 nodes.remove, :424     */
+    o->n_dead++;
+    for (uint32_t lc = 0; lc <= top; lc++) o->nodes[id].rows[lc].n = 0;
+    if (touched) {
+        uint32_t n = o->n_touch < touched_cap ? o->n_touch : touched_cap;
+        memcpy(touched, o->touch, (size_t)n * 4);
+    }
+    if (n_touched) *n_touched = o->n_touch;
+    if (o->enterpoint == (int64_t)id) {                 /* :449-472 */
+        int64_t best = -1;
+        uint32_t best_level = 0;
+        for (uint32_t i = 0; i < o->node_count; i++)
+            if (!o->dead[i] && (best < 0 || o->nodes[i].level > best_level)) { best = i; best_level = o->nodes[i].level; }
+        o->enterpoint = best;
+        /* empty top layers are popped and max_layer decremented, never below 0 (:458-465) */
+        o->max_layer = best >= 0 ? best_level : 0;
+    }
+    return 0;
+}
+
+uint32_t hnsw_oracle_live_count(const hnsw_oracle *o) { return o->node_count - o->n_dead; }
+int hnsw_oracle_is_live(const hnsw_oracle *o, uint32_t id) { return id < o->node_count && !o->dead[id]; }
+
+/* ========================================================================= */
 /* introspection / bulk transfer                                             */
 /* ========================================================================= */
 uint32_t hnsw_oracle_node_count(const hnsw_oracle *o) { return o->node_count; }
@@ -755,6 +829,7 @@ hnsw_oracle *hnsw_oracle_import(uint32_t dim, uint32_t m, uint32_t ef_constructi
     o->cap = n ? n : 1;
     o->data = (float *)malloc((size_t)o->cap * dim * sizeof(float));
     o->nodes = (onode *)calloc(o->cap, sizeof(onode));
+    o->dead = (uint8_t *)calloc(o->cap, 1);
     memcpy(o->data, vectors, (size_t)n * dim * sizeof(float));
     o->node_count = n;
     for (uint32_t i = 0; i < n; i++) {

@@ -83,6 +83,15 @@ void hnsw_oracle_search_batch(const hnsw_oracle *o, const float *Q, uint32_t B,
                               uint32_t *n_out, uint32_t threads,
                               hnsw_oracle_counters *ctrs);
 
+/* core.rs:414-475 + 824-863 (HNSW.NODE.DEL).  Ids are never reused; node_count() keeps counting
+ * allocated ids, live_count() is the reference's node_count.  The new enterpoint, which the
+ * reference picks arbitrarily from the highest non-empty layer (HashSet order, core.rs:453), is the
+ * smallest id of that layer.  Returns 0, -1 if id is not a live node.                          */
+int hnsw_oracle_delete(hnsw_oracle *o, uint32_t id, uint32_t *touched, uint32_t touched_cap,
+                       uint32_t *n_touched);
+uint32_t hnsw_oracle_live_count(const hnsw_oracle *o);
+int hnsw_oracle_is_live(const hnsw_oracle *o, uint32_t id);
+
 /* ---- introspection / bulk transfer --------------------------------------- */
 uint32_t hnsw_oracle_node_count(const hnsw_oracle *o);
 uint32_t hnsw_oracle_max_layer(const hnsw_oracle *o);

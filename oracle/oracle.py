@@ -45,6 +45,12 @@ def lib():
     L.hnsw_oracle_free.argtypes = [C.c_void_p]
     L.hnsw_oracle_add.restype = C.c_int64
     L.hnsw_oracle_add.argtypes = [C.c_void_p, fp, C.c_int32, u32p, C.c_uint32, u32p]
+    L.hnsw_oracle_delete.restype = C.c_int
+    L.hnsw_oracle_delete.argtypes = [C.c_void_p, C.c_uint32, u32p, C.c_uint32, u32p]
+    L.hnsw_oracle_live_count.restype = C.c_uint32
+    L.hnsw_oracle_live_count.argtypes = [C.c_void_p]
+    L.hnsw_oracle_is_live.restype = C.c_int
+    L.hnsw_oracle_is_live.argtypes = [C.c_void_p, C.c_uint32]
     L.hnsw_oracle_search.restype = C.c_uint32
     L.hnsw_oracle_search.argtypes = [C.c_void_p, fp, C.c_uint32, u32p, fp, C.POINTER(Counters)]
     L.hnsw_oracle_search_batch.restype = None
@@ -148,6 +154,23 @@ class OracleIndex:
         V = _f32(V)
         for i in range(V.shape[0]):
             self.add(V[i], -1 if levels is None else int(levels[i]))
+
+    # -- delete (core.rs:414-475) ----------------------------------------------
+    def delete(self, i, want_touched=False):
+        cap = 8192
+        t = np.empty(cap, dtype=np.uint32)
+        n = C.c_uint32(0)
+        rc = lib().hnsw_oracle_delete(self._h, int(i), _u32p(t), cap, C.byref(n))
+        if rc != 0:
+            raise KeyError("Node: %r does not exist" % (i,))
+        return t[: n.value].copy() if want_touched else None
+
+    @property
+    def live_count(self):
+        return int(lib().hnsw_oracle_live_count(self._h))
+
+    def is_live(self, i):
+        return bool(lib().hnsw_oracle_is_live(self._h, int(i)))
 
     # -- search --------------------------------------------------------------
     def search(self, q, k, counters=False):

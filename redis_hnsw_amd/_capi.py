@@ -16,7 +16,8 @@ class Info(C.Structure):
     _fields_ = [("dim", C.c_uint32), ("m", C.c_uint32), ("m_max", C.c_uint32), ("m_max0", C.c_uint32),
                 ("ef_construction", C.c_uint32), ("node_count", C.c_uint32), ("max_layer", C.c_uint32),
                 ("enterpoint", C.c_int64), ("stride0", C.c_uint32), ("stride_upper", C.c_uint32),
-                ("max_degree0", C.c_uint32), ("max_degree_upper", C.c_uint32), ("hbm_bytes", C.c_uint64)]
+                ("max_degree0", C.c_uint32), ("max_degree_upper", C.c_uint32), ("hbm_bytes", C.c_uint64),
+                ("allocated_ids", C.c_uint32)]
 
 
 fp = C.POINTER(C.c_float)
@@ -32,6 +33,7 @@ SIGNATURES = {
     "hnsw_last_error": (C.c_char_p, [H]),
     "hnsw_add": (C.c_int, [H, fp, C.c_uint32, C.c_int32, u32p, u32p, C.c_uint32, u32p]),
     "hnsw_add_batch": (C.c_int, [H, fp, C.c_uint32, C.c_uint32, i32p, C.c_uint32]),
+    "hnsw_delete": (C.c_int, [H, C.c_uint32, u32p, C.c_uint32, u32p]),
     "hnsw_search": (C.c_int, [H, fp, C.c_uint32, C.c_uint32, u32p, fp, u32p]),
     "hnsw_search_batch": (C.c_int, [H, fp, C.c_uint32, C.c_uint32, C.c_uint32, u32p, fp, u32p]),
     "hnsw_search_batch_device": (C.c_int, [H, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,

@@ -29,6 +29,8 @@ struct hnsw_index {
     uint32_t *d_adj0 = nullptr, *d_adjU = nullptr, *d_upper_base = nullptr, *d_levels = nullptr;
     DevHeader *d_hdr = nullptr;
     std::vector<uint32_t> h_levels, h_upper_base;
+    std::vector<uint8_t> h_dead;   // tombstones (HNSW.NODE.DEL); ids are never reused
+    uint32_t n_dead = 0;
     // search scratch
     // HBM spill tables of the visited sets: kSpillRegions regions, handed out round-robin so that
     // launches overlapping on different streams never share one (an event per region orders reuse)
@@ -633,6 +635,36 @@ hnsw_status hnsw_add_batch(hnsw_index *h, const float *V, uint32_t n, uint32_t d
     return check_dev_status(h, hd);
 }
 
+hnsw_status hnsw_delete(hnsw_index *h, uint32_t id, uint32_t *touched, uint32_t touched_cap, uint32_t *n_touched)
+{
+    if (!h) return HNSW_ERR_INVALID;
+    if (n_touched) *n_touched = 0;
+    if (id >= h->n || h->h_dead[id]) {                          // core.rs:419-422
+        char buf[64];
+        snprintf(buf, sizeof buf, "Node: %u does not exist", id);
+        return fail(h, HNSW_ERR_NOT_FOUND, buf);
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    hnsw_status s = delete_exact(h, id);
+    if (s != HNSW_OK) return s;
+    DevHeader hd;
+    if ((s = pull_header(h, &hd)) != HNSW_OK) return s;
+    if ((s = check_dev_status(h, hd)) != HNSW_OK) return s;
+    uint32_t nt = hd.n_touched;
+    if (touched && nt) {
+        uint32_t have = std::min(nt, h->touched_cap);
+        std::vector<uint32_t> tmp(have);
+        HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->d_touched, (size_t)have * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        nt = (uint32_t)tmp.size();
+        for (uint32_t i = 0; i < nt && i < touched_cap; ++i) touched[i] = tmp[i];
+    }
+    if (n_touched) *n_touched = nt;
+    return HNSW_OK;
+}
+
 hnsw_status hnsw_search_batch_device(hnsw_index *h, const float *dQ, uint32_t B, uint32_t dim, uint32_t k,
                                      uint32_t *d_ids, float *d_sims, uint32_t *d_n_out, void *stream)
 {
@@ -654,7 +686,7 @@ hnsw_status hnsw_search_batch_device(hnsw_index *h, const float *dQ, uint32_t B,
         HIP_TRY(h, hipEventRecord(h->ev_sync, h->stream));
         HIP_TRY(h, hipStreamWaitEvent(st, h->ev_sync, 0));
     }
-    if (h->n == 0 || h->enterpoint < 0) {        // core.rs:481-483
+    if (h->n == h->n_dead || h->enterpoint < 0) { // core.rs:481-483
         HIP_TRY(h, hipMemsetAsync(d_n_out, 0, (size_t)B * 4, st));
         HIP_TRY(h, hipMemsetAsync(d_ids, 0xFF, (size_t)B * k * 4, st));
         HIP_TRY(h, hipMemsetAsync(d_sims, 0xFF, (size_t)B * k * 4, st));
@@ -675,7 +707,7 @@ hnsw_status hnsw_search_batch(hnsw_index *h, const float *Q, uint32_t B, uint32_
     if (B == 0) return HNSW_OK;
     if (k == 0) return fail(h, HNSW_ERR_INVALID, "k must be >= 1");
     HIP_TRY(h, hipSetDevice(h->device));
-    if (h->n == 0 || h->enterpoint < 0) {
+    if (h->n == h->n_dead || h->enterpoint < 0) {
         for (uint32_t b = 0; b < B; ++b) n_out[b] = 0;
         return HNSW_OK;
     }
@@ -735,6 +767,8 @@ hnsw_status hnsw_import(hnsw_index *h, uint32_t n, const float *vectors, const u
     if ((s = ensure_node_cap(h, n)) != HNSW_OK) return s;
     h->h_levels.assign(levels, levels + n);
     h->h_upper_base.assign(n, kNoUpper);
+    h->h_dead.assign(n, 0);
+    h->n_dead = 0;
     uint32_t used = 0;
     for (uint32_t i = 0; i < n; ++i) {
         if (levels[i] >= kMaxLayers) return fail(h, HNSW_ERR_INVALID, "level too large");
@@ -777,7 +811,9 @@ hnsw_status hnsw_get_info(hnsw_index *h, hnsw_info *info)
     if (!h || !info) return HNSW_ERR_INVALID;
     info->dim = h->dim; info->m = h->m; info->m_max = h->m_max; info->m_max0 = h->m_max0;
     info->ef_construction = h->efc;
-    info->node_count = h->n; info->max_layer = h->max_layer; info->enterpoint = h->enterpoint;
+    info->node_count = h->n - h->n_dead;        // the reference's node_count: live nodes
+    info->allocated_ids = h->n;
+    info->max_layer = h->max_layer; info->enterpoint = h->enterpoint;
     info->stride0 = h->stride0; info->stride_upper = h->strideU;
     info->max_degree0 = h->max_deg0; info->max_degree_upper = h->max_degU;
     info->hbm_bytes = h->hbm_bytes;

@@ -32,7 +32,7 @@ constexpr uint32_t kPlanStride = 1 + 64;  // per (slot, layer): count + up to 64
 template <int MODE, int T>
 __device__ uint32_t select_topm(const GraphView &g, const WaveMem &m, Visited &vis, const QReg<T> &qr,
                                 const uint64_t *cand, uint32_t ncand, uint32_t qid, uint32_t mcap,
-                                uint32_t lc, WorkCtr &ctr, int lane, bool &fail)
+                                uint32_t lc, WorkCtr &ctr, int lane, bool &fail, uint32_t ignored = kEmpty)
 {
     visited_clear(vis, lane);                               // core.rs:692
     for (uint32_t base = 0; base < ncand; base += 64) {     // core.rs:693-696
@@ -41,8 +41,19 @@ __device__ uint32_t select_topm(const GraphView &g, const WaveMem &m, Visited &v
         if (i < ncand) visited_insert(vis, key_id(cand[i]));
         vis.count += ncand - base < 64 ? ncand - base : 64;
     }
-    uint32_t nS = ncand < mcap ? ncand : mcap;              // core.rs:685 w = c.clone()
-    if ((uint32_t)lane < nS) m.S[lane] = cand[lane] & ~1ull;
+    // core.rs:685 w = c.clone(): S starts as the nearest mcap candidates, minus `ignored`
+    // (core.rs:728-731 skips it when popping; HNSW.NODE.DEL passes the node being removed)
+    uint32_t nS;
+    {
+        const uint32_t take = ncand < mcap + 1 ? ncand : mcap + 1;
+        const bool in = (uint32_t)lane < take;
+        const uint64_t ck = in ? cand[lane] : ~0ull;
+        const uint64_t ign = __ballot(in && key_id(ck) == ignored);
+        const uint32_t dst = (uint32_t)lane - (uint32_t)__popcll(ign & lanemask_lt(lane));
+        if (in && !((ign >> lane) & 1ull) && dst < mcap) m.S[dst] = ck & ~1ull;
+        nS = take - (uint32_t)__popcll(ign);
+        if (nS > mcap) nS = mcap;
+    }
     __syncthreads();
 
     const uint32_t stride = lc ? g.strideU : g.stride0;
@@ -67,7 +78,7 @@ __device__ uint32_t select_topm(const GraphView &g, const WaveMem &m, Visited &v
         for (uint32_t wbase = 0; wbase <= cnt; wbase += 64) { // core.rs:702
             const uint32_t wi = wbase + lane;
             if (wbase) word = wi < stride ? row[wi] : 0u;
-            const bool valid = wi >= 1 && wi <= cnt && word != qid; // core.rs:704-708
+            const bool valid = wi >= 1 && wi <= cnt && word != qid && word != ignored; // core.rs:704-708
             if (!visited_reserve(vis, lane, nullptr)) { fail = true; return 0; }
             const bool fresh = valid && visited_insert(vis, word);  // core.rs:710,718
             const uint64_t fm = __ballot(fresh);
@@ -148,6 +159,75 @@ __global__ __launch_bounds__(64) void k_insert_plan(GraphView g, uint32_t first_
         atomicAdd(&g.hdr->ctr_insert[1], (unsigned long long)ctr.n_ids);
         atomicAdd(&g.hdr->ctr_insert[2], (unsigned long long)ctr.n_expand);
     }
+}
+
+// ---------------------------------------------------------------------------
+// update_node_connections (core.rs:776-822) for node e whose old row (cnt ids, stored order) is in
+// m.aux and whose new neighbour set is m.S[0..nS) (nearest first).  Final row(e) = old entries that
+// survive, in their stored order (add_neighbor leaves them where they are, :793; rm_neighbor keeps
+// order, :808), followed by the brand-new ones nearest first (:790-796).  Brand-new neighbours get
+// e appended; dropped ones lose e -- except `ignored` (the node HNSW.NODE.DEL is removing), whose
+// rows are left alone (:810-813).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void touch_push(uint32_t *touched, uint32_t cap, uint32_t &nt, uint32_t id, bool on,
+                                           int lane);
+
+__device__ void update_connections(const GraphView &g, const WaveMem &m, uint32_t e, uint32_t *erow, uint32_t cnt,
+                                   uint32_t nS, uint32_t lc, uint32_t stride, uint32_t *maxdeg, uint32_t ignored,
+                                   uint32_t *touched, uint32_t touched_cap, uint32_t &nt, int lane)
+{
+    uint32_t kept = 0;
+    for (uint32_t base = 0; base < cnt; base += 64) {
+        const uint32_t i = base + lane;
+        const uint32_t x = i < cnt ? m.aux[i] : kEmpty;
+        bool inS = false;
+        if (i < cnt)
+            for (uint32_t j = 0; j < nS; ++j) inS |= key_id(m.S[j]) == x;
+        const uint64_t kb = __ballot(inS);
+        if (inS) erow[1 + kept + __popcll(kb & lanemask_lt(lane))] = x;
+        kept += __popcll(kb);
+        // bidirectionally remove old-but-not-new (:805-819)
+        const bool drop = i < cnt && !inS && x != ignored;
+        if (drop) {
+            uint32_t *xrow = row_ptr(g, x, lc);
+            uint32_t xc = xrow[0];
+            if (xc > stride - 1) xc = stride - 1;
+            uint32_t p = 0;
+            while (p < xc && xrow[1 + p] != e) ++p;
+            if (p == xc) atomicOr(&g.hdr->status, ST_ASYMMETRIC); // reference panics, :150
+            else {
+                for (; p + 1 < xc; ++p) xrow[1 + p] = xrow[2 + p];
+                xrow[0] = xc - 1;
+            }
+        }
+        touch_push(touched, touched_cap, nt, x, drop, lane); // :816
+    }
+    // new neighbours that were not adjacent before (:790-796)
+    {
+        const uint32_t x = (uint32_t)lane < nS ? key_id(m.S[lane]) : kEmpty;
+        bool isNew = (uint32_t)lane < nS;
+        if (isNew)
+            for (uint32_t i = 0; i < cnt; ++i) isNew &= m.aux[i] != x;
+        const uint64_t nb = __ballot(isNew);
+        if (isNew) {
+            erow[1 + kept + __popcll(nb & lanemask_lt(lane))] = x;
+            uint32_t *xrow = row_ptr(g, x, lc);
+            uint32_t xc = xrow[0];
+            if (xc > stride - 1) xc = stride - 1;
+            bool present = false;
+            for (uint32_t p = 0; p < xc; ++p) present |= xrow[1 + p] == e;
+            if (!present) {
+                if (xc + 1 > stride - 1) atomicOr(&g.hdr->status, ST_ROW_OVERFLOW);
+                else { xrow[1 + xc] = e; xrow[0] = xc + 1; atomicMax(maxdeg, xc + 1); }
+            }
+        }
+        kept += __popcll(nb);
+        touch_push(touched, touched_cap, nt, x, (uint32_t)lane < nS, lane); // :796
+    }
+    if (lane == 0) erow[0] = kept;
+    touch_push(touched, touched_cap, nt, e, lane == 0, lane);               // :787
+    __threadfence();
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------
@@ -242,62 +322,7 @@ __global__ __launch_bounds__(64) void k_insert_commit_exact(GraphView g, uint32_
             const uint32_t nS = select_topm<MODE, T>(g, m, vis, qe, m.W, nE, e, mmax, lc, ctr, lane, fail);
             if (fail) break;
 
-            // update_node_connections (core.rs:776-822).  Final row(e) =
-            // old entries that survive, in their stored order (add_neighbor
-            // leaves them where they are, :793; rm_neighbor keeps order, :808)
-            // followed by the brand-new ones nearest first (:790-796).
-            uint32_t kept = 0;
-            for (uint32_t base = 0; base < cnt; base += 64) {
-                const uint32_t i = base + lane;
-                const uint32_t x = i < cnt ? m.aux[i] : kEmpty;
-                bool inS = false;
-                if (i < cnt)
-                    for (uint32_t j = 0; j < nS; ++j) inS |= key_id(m.S[j]) == x;
-                const uint64_t kb = __ballot(inS);
-                if (inS) erow[1 + kept + __popcll(kb & lanemask_lt(lane))] = x;
-                kept += __popcll(kb);
-                // bidirectionally remove old-but-not-new (:805-819)
-                const bool drop = i < cnt && !inS;
-                if (drop) {
-                    uint32_t *xrow = row_ptr(g, x, lc);
-                    uint32_t xc = xrow[0];
-                    if (xc > stride - 1) xc = stride - 1;
-                    uint32_t p = 0;
-                    while (p < xc && xrow[1 + p] != e) ++p;
-                    if (p == xc) atomicOr(&g.hdr->status, ST_ASYMMETRIC); // reference panics, :150
-                    else {
-                        for (; p + 1 < xc; ++p) xrow[1 + p] = xrow[2 + p];
-                        xrow[0] = xc - 1;
-                    }
-                }
-                touch_push(touched, touched_cap, nt, x, drop, lane); // :816
-            }
-            // new neighbours that were not adjacent before (:790-796)
-            {
-                const uint32_t x = (uint32_t)lane < nS ? key_id(m.S[lane]) : kEmpty;
-                bool isNew = (uint32_t)lane < nS;
-                if (isNew)
-                    for (uint32_t i = 0; i < cnt; ++i) isNew &= m.aux[i] != x;
-                const uint64_t nb = __ballot(isNew);
-                if (isNew) {
-                    erow[1 + kept + __popcll(nb & lanemask_lt(lane))] = x;
-                    uint32_t *xrow = row_ptr(g, x, lc);
-                    uint32_t xc = xrow[0];
-                    if (xc > stride - 1) xc = stride - 1;
-                    bool present = false;
-                    for (uint32_t p = 0; p < xc; ++p) present |= xrow[1 + p] == e;
-                    if (!present) {
-                        if (xc + 1 > stride - 1) atomicOr(&g.hdr->status, ST_ROW_OVERFLOW);
-                        else { xrow[1 + xc] = e; xrow[0] = xc + 1; atomicMax(maxdeg, xc + 1); }
-                    }
-                }
-                kept += __popcll(nb);
-                touch_push(touched, touched_cap, nt, x, (uint32_t)lane < nS, lane); // :796
-            }
-            if (lane == 0) erow[0] = kept;
-            touch_push(touched, touched_cap, nt, e, lane == 0, lane);               // :787
-            __threadfence();
-            __syncthreads();
+            update_connections(g, m, e, erow, cnt, nS, lc, stride, maxdeg, kEmpty, touched, touched_cap, nt, lane);
         }
     }
 
@@ -312,6 +337,80 @@ __global__ __launch_bounds__(64) void k_insert_commit_exact(GraphView g, uint32_
         atomicAdd(&g.hdr->ctr_insert[0], (unsigned long long)ctr.n_dist);
         atomicAdd(&g.hdr->ctr_insert[1], (unsigned long long)ctr.n_ids);
         atomicAdd(&g.hdr->ctr_insert[3], (unsigned long long)skipped);
+    }
+    if (vis.glob_dirty) visited_clear(vis, lane);
+}
+
+// ---------------------------------------------------------------------------
+// HNSW.NODE.DEL (core.rs:414-475): for every layer of the node (ascending, :434) and every
+// neighbour n of it in stored order (:829), n re-selects its links from its two-hop neighbourhood
+// with the node ignored (delete_node_from_neighbors, :824-863).  One wave, the reference's serial
+// order.  The host re-elects the enterpoint afterwards.
+// ---------------------------------------------------------------------------
+template <int MODE, int T, int R>
+__global__ __launch_bounds__(64) void k_delete_exact(GraphView g, uint32_t id, uint32_t mlinks, uint32_t lnb,
+                                                     uint32_t lcap, uint32_t *__restrict__ gspill, uint32_t gnb,
+                                                     uint32_t *__restrict__ touched, uint32_t touched_cap)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    WaveMem m;
+    Visited vis;
+    carve<R, T, true>(smem, g.dim, lnb, lcap, m, vis);
+    vis.glob = gspill;
+    vis.gnb = gnb;
+    vis.glob_dirty = false;
+    vis.spilled = false;
+    vis.count = 0;
+    WorkCtr ctr = {};
+    uint32_t nt = 0;
+    bool fail = false;
+    const uint32_t l = g.levels[id];
+
+    for (uint32_t lc = 0; lc <= l && !fail; ++lc) {              // core.rs:434
+        const uint32_t stride = lc ? g.strideU : g.stride0;
+        const uint32_t mmax = lc ? mlinks : 2 * mlinks;           // core.rs:846
+        uint32_t *maxdeg = lc ? &g.hdr->max_degU : &g.hdr->max_deg0;
+        uint32_t *drow = row_ptr(g, id, lc);                      // not modified while we walk it
+        uint32_t dcnt = drow[0];
+        if (dcnt > stride - 1) dcnt = stride - 1;
+        for (uint32_t kk = 0; kk < dcnt && !fail; ++kk) {         // core.rs:829 stored order
+            const uint32_t n = drow[1 + kk];
+            uint32_t *erow = row_ptr(g, n, lc);
+            uint32_t cnt = erow[0];
+            if (cnt > stride - 1) cnt = stride - 1;
+            ctr.n_ids += cnt;
+            // nconn (core.rs:832-844): sims from n to each of its neighbours (the node included)
+            QReg<T> qe;
+            load_query<MODE, T>(g.vec + (size_t)n * g.dim, g.dim, qe, m.qlds, lane);
+            uint32_t nE = 0;
+            for (uint32_t base = 0; base < cnt; base += 64) {
+                const uint32_t i = base + lane;
+                const uint32_t nf = cnt - base < 64 ? cnt - base : 64;
+                if (i < cnt) { uint32_t x = erow[1 + i]; m.fresh[lane] = x; m.aux[i] = x; }
+                __syncthreads();
+                compute_dists<MODE, T>(g, qe, m, nf, lane);   // :840-841
+                ctr.n_dist += nf;
+                __syncthreads();
+                const bool have = (uint32_t)lane < nf;
+                const uint64_t key = have ? pack_key(m.dsc[lane], m.fresh[lane]) : ~0ull;
+                nE = merge_sorted<R>(m.W, nE, R * 64, key, have, lane);
+            }
+            // select_neighbors(n, nconn, m_max, ignored = node) (core.rs:853)
+            const uint32_t nS = select_topm<MODE, T>(g, m, vis, qe, m.W, nE, n, mmax, lc, ctr, lane, fail, id);
+            if (fail) break;
+            // update_node_connections(n, new, old, ignored = node) (core.rs:856); :855 is covered by :787
+            update_connections(g, m, n, erow, cnt, nS, lc, stride, maxdeg, id, touched, touched_cap, nt, lane);
+        }
+        if (lane == 0) drow[0] = 0;                               // the node is gone (core.rs:419)
+        __threadfence();
+        __syncthreads();
+    }
+    if (fail && lane == 0) atomicOr(&g.hdr->status, ST_VISITED_OVERFLOW);
+    if (lane == 0) {
+        g.hdr->n_touched = nt;
+        atomicAdd(&g.hdr->ctr_insert[0], (unsigned long long)ctr.n_dist);
+        atomicAdd(&g.hdr->ctr_insert[1], (unsigned long long)ctr.n_ids);
     }
     if (vis.glob_dirty) visited_clear(vis, lane);
 }

@@ -91,6 +91,21 @@ public:
             for (uint32_t i = 0; i < nt && i < touched.size(); ++i) update_fn(names_[touched[i]], touched[i]);
     }
 
+    // delete_node(&mut self, name, update_fn)   core.rs:414-475
+    void delete_node(const std::string &node, const std::function<void(const std::string &, uint32_t)> &update_fn = nullptr)
+    {
+        auto it = ids_.find(node);
+        if (it == ids_.end()) throw HNSWError("Node: \"" + node + "\" does not exist", HNSW_ERR_NOT_FOUND);  // :421
+        const uint32_t id = it->second;
+        uint32_t nt = 0;
+        std::vector<uint32_t> touched(8192);
+        check(hnsw_delete(h_, id, touched.data(), (uint32_t)touched.size(), &nt));
+        ids_.erase(it);
+        if (update_fn)                                                 // core.rs:441-446
+            for (uint32_t i = 0; i < nt && i < touched.size(); ++i) update_fn(names_[touched[i]], touched[i]);
+    }
+    bool contains(const std::string &node) const { return ids_.count(node) != 0; }
+
     // search_knn(&self, data, k)   core.rs:477-486
     std::vector<SearchResult> search_knn(const std::vector<float> &data, size_t k) const
     {

@@ -99,7 +99,7 @@ class Index:
         return int(self.info().enterpoint)
 
     def _name_of(self, i):
-        return self._names[i] if i < len(self._names) else str(i)
+        return self._names[i] if i < len(self._names) and self._names[i] is not None else str(i)
 
     # -- HNSW.NODE.ADD (core.rs:383-412) ------------------------------------------
     def add_node(self, name, data, update_fn=None, level=-1):
@@ -127,6 +127,21 @@ class Index:
             for t in touched[: min(nt.value, cap)]:
                 update_fn(self._name_of(int(t)), int(t))
         return i
+
+    # -- HNSW.NODE.DEL (core.rs:414-475) --------------------------------------------
+    def delete_node(self, name, update_fn=None):
+        i = self._ids.get(name)
+        if i is None:                                          # core.rs:419-422
+            raise HNSWError('Node: "%s" does not exist' % name, _capi.ERR_NOT_FOUND)
+        cap = 8192
+        touched = np.empty(cap, dtype=np.uint32)
+        nt = C.c_uint32(0)
+        self._check(self._lib.hnsw_delete(self._h, i, _u32p(touched), cap, C.byref(nt)))
+        del self._ids[name]
+        self._names[i] = None
+        if update_fn is not None:                              # core.rs:441-446
+            for t in touched[: min(nt.value, cap)]:
+                update_fn(self._name_of(int(t)), int(t))
 
     def add_batch(self, vectors, names=None, levels=None, mode="exact"):
         """Bulk NODE.ADD (hnsw_add_batch).  mode 'exact' replays the reference's
@@ -200,7 +215,7 @@ class Index:
 
     def export_graph(self, with_vectors=False):
         inf = self.info()
-        n = int(inf.node_count)
+        n = int(inf.allocated_ids)
         levels = np.zeros(max(n, 1), dtype=np.uint32)
         if n:
             self._check(self._lib.hnsw_get_levels(self._h, _u32p(levels)))

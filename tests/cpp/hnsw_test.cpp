@@ -1,5 +1,4 @@
-// hnsw_test.cpp -- src/hnsw/core_tests.rs:6-53 (hnsw_test, up to the search
-// block; HNSW.NODE.DEL is outside this round's path) against the MI355X engine
+// hnsw_test.cpp -- src/hnsw/core_tests.rs:6-53 (hnsw_test: create, add, search, delete) against the MI355X engine
 // through the C++ host mirror.  Also src/hnsw/metrics_tests.rs through
 // hnsw_metric_pairs.  Exit code 0 = all assertions hold.
 #include <cmath>
@@ -97,6 +96,24 @@ int main()
         bool back = false;
         for (const auto &x : index.neighbors(nb, 0)) back |= x == "node10";
         ASSERT(back);
+    }
+    // ---- core_tests.rs:55-80 delete node ------------------------------------------------
+    for (size_t i = 0; i < n; ++i) {
+        std::string name = "node" + std::to_string(i);
+        index.delete_node(name, mock_fn);
+        ASSERT(index.node_count() == n - i - 1);
+        ASSERT(!index.contains(name));
+        // no remaining node lists it as a neighbour (sampled: the survivors next to it on the line)
+        for (size_t jn = i + 1; jn < n && jn < i + 8; ++jn)
+            for (size_t lc = 0; lc <= index.max_layer(); ++lc)
+                for (const auto &x : index.neighbors("node" + std::to_string(jn), lc)) ASSERT(x != name);
+    }
+    ASSERT(!index.has_enterpoint());
+    try {
+        index.delete_node("node3");
+        ASSERT(false);
+    } catch (const HNSWError &e) {
+        ASSERT(e.error_string() == "String(\"Node: \\\"node3\\\" does not exist\")");   // core.rs:421
     }
     std::printf("hnsw_test ok (%zu update_fn calls)\n", updates);
     return 0;

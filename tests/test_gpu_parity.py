@@ -394,3 +394,60 @@ def test_many_layers_small_m(eng, oracle_mod):
     oids, osims, _, _ = o.search_batch(Q, 5)
     assert np.array_equal(ids, oids) and np.array_equal(_bits(sims), _bits(osims))
     gi.close()
+
+
+# ---- HNSW.NODE.DEL (core.rs:414-475) ------------------------------------------------------
+def test_hnsw_test_delete_reference_kat(eng):
+    """core_tests.rs:55-80 through the engine"""
+    from redis_hnsw_amd import HNSWError
+    index = eng.Index("foo", 4, 5, 16, seed=5)
+    n = 100
+    for i in range(n):
+        index.add_node("node%d" % i, np.full(4, float(i), np.float32))
+    for i in range(n):
+        index.delete_node("node%d" % i, lambda s, nid: None)
+        assert index.node_count == n - i - 1
+        g = index.export_graph()
+        for col in g["col"]:
+            assert i not in col.tolist()
+    assert index.enterpoint is None and index.search_knn(np.zeros(4, np.float32), 3) == []
+    with pytest.raises(HNSWError) as e:
+        index.delete_node("node3")
+    assert e.value.error_string() == 'String("Node: \\"node3\\" does not exist")'     # core.rs:421
+    index.add_node("again", np.zeros(4, np.float32))                                # core.rs:393-405
+    assert index.node_count == 1 and index.enterpoint == "again"
+    index.close()
+
+
+@pytest.mark.parametrize("n,dim,m,ef", [(300, 32, 5, 16), (400, 128, 16, 64), (250, 4, 5, 16)])
+def test_delete_matches_oracle(eng, oracle_mod, n, dim, m, ef):
+    V = make_data(n + 60, dim, seed=71)
+    lv = oracle_mod.draw_levels(n + 60, m, 4)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    gi = eng.Index("foo", dim, m, ef)
+    o.add_batch(V[:n], lv[:n])
+    gi.add_batch(V[:n], levels=lv[:n], mode="exact")
+    order = np.random.default_rng(5).permutation(n)[: n // 2]
+    ep0 = o.enterpoint
+    order = np.concatenate([[ep0], order[order != ep0]])          # delete the enterpoint first (re-election)
+    for step, i in enumerate(order):
+        ot = o.delete(int(i), want_touched=True)
+        got = []
+        gi.delete_node("node%d" % i, lambda s, nid: got.append(nid))
+        assert sorted(got) == sorted(ot.tolist()), "touched set of delete %d" % i
+        if step % 25 == 0 or step == len(order) - 1:
+            ok, why = graphs_equal(o.export(), gi.export_graph())
+            assert ok, "after deleting %d nodes: %s" % (step + 1, why)
+    assert gi.node_count == o.live_count
+    Q = make_data(48, dim, seed=2)
+    ids, sims, n_out = gi.search_batch(Q, 5)
+    oids, osims, on, _ = o.search_batch(Q, 5)
+    assert np.array_equal(n_out, on) and np.array_equal(ids, oids) and np.array_equal(_bits(sims), _bits(osims))
+    assert not (set(ids.ravel().tolist()) & set(int(x) for x in order))
+    # inserts after deletes keep matching (ids are not reused)
+    for i in range(n, n + 60):
+        o.add(V[i], int(lv[i]))
+        gi.add_node("node%d" % i, V[i], level=int(lv[i]))
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    gi.close()

@@ -115,3 +115,35 @@ def test_first_node_level_zero_and_no_draw(oracle_mod):  # core.rs:393-405
     assert idx.max_layer == 2 and idx.enterpoint == 1     # core.rs:587-593
     assert idx.neighbors(1, 0).tolist() == [0] and idx.neighbors(0, 0).tolist() == [1]
     assert idx.neighbors(1, 1).tolist() == []
+
+
+# ---- core_tests.rs:55-80: delete every node in insertion order ------------------
+@pytest.mark.parametrize("seed", range(12))
+def test_hnsw_test_delete(oracle_mod, seed):
+    idx = _line_index(oracle_mod, seed)
+    n = 100
+    for i in range(n):
+        idx.delete(i)
+        assert idx.live_count == n - i - 1                      # index.node_count
+        assert not idx.is_live(i)                               # index.nodes.get(name).is_none()
+        g = idx.export()
+        for col in g["col"]:                                    # no neighbour list mentions it
+            assert i not in col.tolist()
+        # what is left is still a graph the reference accepts: symmetric links (core.rs:145-152 unwraps)
+        for l, (rp, col) in enumerate(zip(g["row_ptr"], g["col"])):
+            for a in range(0, n, 7):
+                for b in col[int(rp[a]):int(rp[a + 1])]:
+                    assert a in col[int(rp[b]):int(rp[b + 1])].tolist()
+    assert idx.enterpoint == -1 and idx.live_count == 0
+    with pytest.raises(KeyError):
+        idx.delete(3)                                           # "Node: ... does not exist" core.rs:421
+    # HNSW.NODE.ADD on the emptied index works again (core.rs:393-405 first-node branch)
+    i = idx.add(np.zeros(4, np.float32))
+    assert idx.live_count == 1 and idx.enterpoint == i
+
+
+def test_delete_then_search_skips_the_node(oracle_mod):
+    idx = _line_index(oracle_mod, 1)
+    idx.delete(10)
+    ids, sims = idx.search(np.full(4, 10.0, np.float32), 4)
+    assert 10 not in ids.tolist() and set(ids[:2].tolist()) == {9, 11}
