@@ -451,3 +451,43 @@ def test_delete_matches_oracle(eng, oracle_mod, n, dim, m, ef):
     ok, why = graphs_equal(o.export(), gi.export_graph())
     assert ok, why
     gi.close()
+
+
+# ---- BASELINE.json's full size (C2): properties + sampled oracle parity ----------------------
+def test_full_size_c2_properties_and_sampled_parity(eng, oracle_mod):
+    """1M x 128, M=16, ef=200, k=10, batch 1024 (fast GPU build): size-independent properties on the
+    whole batch, and bit-exact parity with the oracle searching the same exported graph on a sample."""
+    from bench import draw_levels
+    N, dim, M, ef, k, B = 1_000_000, 128, 16, 200, 10, 1024
+    V = np.random.default_rng(1).random((N, dim), dtype=np.float32)
+    Q = np.random.default_rng(2).random((B, dim), dtype=np.float32)
+    gi = eng.Index("c2", dim, M, ef)
+    gi.add_batch(V, levels=draw_levels(N, M, 7), mode="fast")
+    assert gi.node_count == N
+    ids, sims, n_out = gi.search_batch(Q, k)
+    assert np.all(n_out == k)                                              # min(k, ef, reachable) = k
+    assert np.all(ids < N)
+    assert np.all(sims[:, :-1] >= sims[:, 1:])                             # nearest first (core.rs:878-890)
+    assert np.all(sims <= 0)                                               # sim = -(squared L2)
+    assert all(len(set(r.tolist())) == k for r in ids)                     # no node twice
+    # the similarity reported for an id is the metric of that pair, recomputed independently in f64
+    d = ((Q[:64, None, :].astype(np.float64) - V[ids[:64].astype(np.int64)].astype(np.float64)) ** 2).sum(-1)
+    assert np.allclose(-d, sims[:64], rtol=1e-5, atol=0)
+    ids2, sims2, _ = gi.search_batch(Q, k)                                 # idempotent
+    assert np.array_equal(ids, ids2) and np.array_equal(_bits(sims), _bits(sims2))
+    half, _, _ = gi.search_batch(Q[:100], k)                               # batch composition does not matter
+    assert np.array_equal(half, ids[:100])
+    # a stored vector finds itself at similarity -0.0
+    self_ids, self_sims, _ = gi.search_batch(V[12345:12346], 1)
+    assert self_ids[0, 0] == 12345 and _bits(self_sims)[0, 0] == 0x80000000
+    # sampled parity: the oracle searching the very same graph
+    g = gi.export_graph()
+    g["vectors"] = V
+    o = oracle_mod.OracleIndex.from_graph(dim, M, ef, g)
+    gi.reset_counters()
+    sids, ssims, _ = gi.search_batch(Q[:48], k)
+    oids, osims, on, oct = o.search_batch(Q[:48], k, threads=8)
+    assert np.array_equal(sids, oids) and np.array_equal(_bits(ssims), _bits(osims))
+    sc, _ = gi.counters()
+    assert (sc.n_dist, sc.n_ids, sc.n_expand) == (oct.n_dist, oct.n_ids, oct.n_expand)
+    gi.close()
