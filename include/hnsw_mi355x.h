@@ -129,7 +129,7 @@ hnsw_status hnsw_export_layer(hnsw_index *h, uint32_t layer, uint64_t *row_ptr /
                               uint32_t *col);
 
 /* Engine knobs (not part of the reference surface): "lds_buckets" (32-byte
- * buckets of the per-query LDS visited table), "grid" (cap on resident query waves), "prefetch" (runner-up prefetch on/off),
+ * buckets of the per-query LDS visited table), "grid" (cap on resident query waves), "tag_table" (16-bit tag visited table on/off), "tag_bb" (force its log2 size),
  * "fast_seed" / "fast_batch_max" / "fast_batch_div" (fast build schedule).   */
 hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value);
 

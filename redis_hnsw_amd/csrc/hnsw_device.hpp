@@ -48,7 +48,8 @@ struct GraphView {
     const uint32_t *levels;     // [cap]
     DevHeader *hdr;
     uint32_t dim, stride0, strideU;
-    uint32_t flags;             // bit 0: runner-up prefetch in search_level
+    uint32_t flags;             // (unused)
+    uint32_t tagcfg;            // 16-bit tag visited table: log2(buckets) | idbits << 8; 0 = 32-bit ids
 };
 
 __device__ __forceinline__ uint32_t *row_ptr(const GraphView &g, uint32_t id, uint32_t lc)
@@ -112,20 +113,24 @@ struct QReg {
 // The reference's AVX2 kernel (metrics.rs:48-77) keeps 4 accumulators x 8
 // lanes; element 32t + 8a + j goes to lane j of accumulator a by one FMA per
 // t.  A piece p holds j = 4(p%2)+c of accumulator a = p/2, c = 0..3.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Two lanes of the reference's AVX registers per packed instruction: v_pk_add_f32 (exact
+// subtraction) and v_pk_fma_f32 (IEEE fused multiply-add per half) -- same bits as the scalar
+// forms, half the instructions of a wave that can only issue one every four cycles.
 template <int T>
 __device__ __forceinline__ float4 avx_accumulate(const float4 (&q)[T], const float4 (&v)[T])
 {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x2 alo = {0.f, 0.f}, ahi = {0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-        float dx = __fsub_rn(q[t].x, v[t].x), dy = __fsub_rn(q[t].y, v[t].y);
-        float dz = __fsub_rn(q[t].z, v[t].z), dw = __fsub_rn(q[t].w, v[t].w);
-        acc.x = __fmaf_rn(dx, dx, acc.x); // metrics.rs:57,60,64,68
-        acc.y = __fmaf_rn(dy, dy, acc.y);
-        acc.z = __fmaf_rn(dz, dz, acc.z);
-        acc.w = __fmaf_rn(dw, dw, acc.w);
+        const f32x2 qlo = {q[t].x, q[t].y}, qhi = {q[t].z, q[t].w};
+        const f32x2 vlo = {v[t].x, v[t].y}, vhi = {v[t].z, v[t].w};
+        const f32x2 dlo = qlo - vlo, dhi = qhi - vhi;
+        alo = __builtin_elementwise_fma(dlo, dlo, alo);   // metrics.rs:57,60,64,68
+        ahi = __builtin_elementwise_fma(dhi, dhi, ahi);
     }
-    return acc;
+    return make_float4(alo.x, alo.y, ahi.x, ahi.y);
 }
 
 // (e1+e2)+(e3+e4) per lane (metrics.rs:71-74), low128+high128 (:37-39),
@@ -255,6 +260,8 @@ struct Visited {
     uint32_t *glob;
     uint32_t lnb, gnb;       // buckets in the LDS / HBM table
     uint32_t lcap;           // ids the LDS table may hold before the set moves to HBM
+    uint32_t tag_bb;         // 0: 32-bit ids in LDS; else log2(buckets) of the 16-bit tag table
+    uint32_t idbits;         // tag mode: ids are < 2^idbits
     uint32_t count;          // ids held (wave-uniform)
     bool spilled;            // wave-uniform
     bool glob_dirty;         // wave-uniform
@@ -318,15 +325,75 @@ __device__ __forceinline__ bool glob_set_insert(uint32_t *tab, uint32_t nb, uint
     return false;
 }
 
+// ---- 16-bit tag mode -------------------------------------------------------------------------
+// Twice the ids per LDS byte, still exact: the id is run through a BIJECTION of [0, 2^idbits)
+// (odd multiplier, then xor-shift), the low tag_bb bits pick a 16-byte bucket and the remaining
+// bits (<= 13) are stored as a tag next to a 3-bit displacement 0..6 (how many buckets past its
+// home the entry had to go).  (home bucket, tag) identifies the id uniquely, so equality of the 16-bit
+// entry in bucket home+d is equality of ids.  Bucket = [u16 arrivals][u16 entry x 7]; one
+// ds_read_b128 per lookup.  Free slots hold 0xFFFF, which no entry can equal (a displacement is
+// never 7).  If an id finds seven consecutive full buckets the query falls back to the HBM table: entries are decoded back to ids (the hash is
+// inverted) and moved there.
+constexpr uint32_t kTagMul = 0x9E3779B1u;
+constexpr uint32_t kTagMulInv = 0x0E8B2F51u;   // kTagMul * kTagMulInv == 1 (mod 2^32)
+static_assert((uint32_t)(kTagMul * kTagMulInv) == 1u, "modular inverse");
+
+__device__ __forceinline__ uint32_t tag_hash(uint32_t id, uint32_t idbits)
+{
+    const uint32_t mask = idbits >= 32 ? 0xFFFFFFFFu : ((1u << idbits) - 1u);
+    const uint32_t x = (id * kTagMul) & mask;
+    return x ^ (x >> ((idbits + 1) >> 1));
+}
+__device__ __forceinline__ uint32_t tag_unhash(uint32_t h, uint32_t idbits)
+{
+    const uint32_t mask = idbits >= 32 ? 0xFFFFFFFFu : ((1u << idbits) - 1u);
+    const uint32_t x = h ^ (h >> ((idbits + 1) >> 1));   // shift >= idbits/2: self-inverse
+    return (x * kTagMulInv) & mask;
+}
+__device__ __forceinline__ uint32_t haszero16(uint32_t x) { return (x - 0x00010001u) & ~x & 0x80008000u; }
+
+// 1: inserted (was absent), 0: already present, 2: seven full buckets in a row (caller must spill)
+__device__ __forceinline__ uint32_t tag_set_insert(uint32_t *tab, uint32_t bb, uint32_t idbits, uint32_t id)
+{
+    const uint32_t h = tag_hash(id, idbits);
+    const uint32_t bmask = (1u << bb) - 1u;
+    const uint32_t b0 = h & bmask, tag = h >> bb;
+    for (uint32_t d = 0; d < 7; ++d) {
+        const uint32_t b = (b0 + d) & bmask;
+        uint32_t *bp = tab + (b << 2);
+        const uint4 w = *reinterpret_cast<const uint4 *>(bp);
+        const uint32_t want = (tag << 3) | d;
+        const uint32_t ww = want | (want << 16);
+        const uint32_t hit = haszero16(w.y ^ ww) | haszero16(w.z ^ ww) | haszero16(w.w ^ ww) |
+                             ((w.x >> 16) == want ? 1u : 0u);
+        if (hit) return 0;
+        if ((w.x & 0xFFFFu) < kBucketIds) {
+            const uint32_t old = atomicAdd(bp, 1u) & 0xFFFFu;      // arrivals live in the low half
+            if (old < kBucketIds) {
+                reinterpret_cast<unsigned short *>(bp)[1 + old] = (unsigned short)want;
+                return 1;
+            }
+        }
+    }
+    return 2;
+}
+
 // empty bucket = {0, kEmpty x 7}.  16-byte piece i is the head of a bucket iff i
 // is even; i = lane + 64k keeps the lane's parity, so each lane stores one constant.
 __device__ __forceinline__ void visited_clear(Visited &v, int lane)
 {
     uint4 *t4 = reinterpret_cast<uint4 *>(v.lds);
-    const uint4 e = make_uint4((lane & 1) ? kEmpty : 0u, kEmpty, kEmpty, kEmpty);
-    for (uint32_t i = lane; i < 2 * v.lnb; i += 64) t4[i] = e;
+    if (v.tag_bb) {
+        // 16-byte buckets: low half of word 0 = arrivals (0), everything else 0xFFFF
+        const uint4 e = make_uint4(0xFFFF0000u, kEmpty, kEmpty, kEmpty);
+        for (uint32_t i = lane; i < (1u << v.tag_bb); i += 64) t4[i] = e;
+    } else {
+        const uint4 e = make_uint4((lane & 1) ? kEmpty : 0u, kEmpty, kEmpty, kEmpty);
+        for (uint32_t i = lane; i < 2 * v.lnb; i += 64) t4[i] = e;
+    }
     if (v.glob_dirty) {
         uint4 *g4 = reinterpret_cast<uint4 *>(v.glob);
+        const uint4 e = make_uint4((lane & 1) ? kEmpty : 0u, kEmpty, kEmpty, kEmpty);
         for (uint32_t i = lane; i < 2 * v.gnb; i += 64) g4[i] = e;
         __threadfence();
         v.glob_dirty = false;
@@ -336,10 +403,57 @@ __device__ __forceinline__ void visited_clear(Visited &v, int lane)
     __syncthreads();
 }
 
+// Move the whole LDS set to the HBM table and continue there.
+__device__ __forceinline__ void visited_spill(Visited &v, int lane, unsigned long long *spill_ctr)
+{
+    if (v.tag_bb) {
+        const uint32_t nb = 1u << v.tag_bb, bmask = nb - 1u;
+        const unsigned short *t16 = reinterpret_cast<const unsigned short *>(v.lds);
+        for (uint32_t i = lane; i < nb * 8u; i += 64) {
+            const uint32_t b = i >> 3, sl = i & 7u;
+            const uint32_t arrivals = t16[b << 3];
+            if (sl >= 1 && sl <= (arrivals < kBucketIds ? arrivals : kBucketIds)) {
+                const uint32_t e = t16[i];
+                const uint32_t home = (b - (e & 7u)) & bmask;
+                const uint32_t id = tag_unhash(((e >> 3) << v.tag_bb) | home, v.idbits);
+                glob_set_insert(v.glob, v.gnb, id);
+            }
+        }
+    } else {
+        for (uint32_t i = lane; i < v.lnb * 8u; i += 64) {
+            const uint32_t id = v.lds[i];
+            if ((i & 7u) != 0u && id != kEmpty) glob_set_insert(v.glob, v.gnb, id);
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    v.spilled = true;
+    v.glob_dirty = true;
+    if (lane == 0 && spill_ctr) atomicAdd(spill_ctr, 1ull);
+}
+
+// Whole-wave insert of one id per lane flagged `valid`; returns this lane's "was absent" flag.
+// (Tag mode can hit a run of full buckets: the set then moves to HBM and the lanes concerned
+// retry there; lanes that already inserted keep their answer.)
+__device__ __forceinline__ bool visited_insert_wave(Visited &v, bool valid, uint32_t id, int lane,
+                                                    unsigned long long *spill_ctr)
+{
+    if (v.spilled) return valid && glob_set_insert(v.glob, v.gnb, id);
+    if (!v.tag_bb) return valid && lds_set_insert(v.lds, v.lnb, id);
+    const uint32_t r = valid ? tag_set_insert(v.lds, v.tag_bb, v.idbits, id) : 0u;
+    if (__ballot(r == 2u)) {
+        visited_spill(v, lane, spill_ctr);
+        if (r == 2u) return glob_set_insert(v.glob, v.gnb, id);
+    }
+    return r == 1u;
+}
+
+// single-lane form (entry points): a fresh table cannot overflow
 __device__ __forceinline__ bool visited_insert(const Visited &v, uint32_t id)
 {
-    if (!v.spilled) return lds_set_insert(v.lds, v.lnb, id);
-    return glob_set_insert(v.glob, v.gnb, id);
+    if (v.spilled) return glob_set_insert(v.glob, v.gnb, id);
+    if (v.tag_bb) return tag_set_insert(v.lds, v.tag_bb, v.idbits, id) == 1u;
+    return lds_set_insert(v.lds, v.lnb, id);
 }
 
 // Make room for up to 64 more ids.  Returns false if even the HBM table is full.
@@ -349,16 +463,7 @@ __device__ __forceinline__ bool visited_reserve(Visited &v, int lane, unsigned l
     if (!v.spilled) {
         if (v.count + 64 <= v.lcap) return true;
         if (v.count + 64 > gcap) return false;         // would not fit there either
-        // move every id to the HBM table and continue there
-        for (uint32_t i = lane; i < v.lnb * 8u; i += 64) {
-            const uint32_t id = v.lds[i];
-            if ((i & 7u) != 0u && id != kEmpty) glob_set_insert(v.glob, v.gnb, id);
-        }
-        __threadfence();
-        __syncthreads();
-        v.spilled = true;
-        v.glob_dirty = true;
-        if (lane == 0 && spill_ctr) atomicAdd(spill_ctr, 1ull);
+        visited_spill(v, lane, spill_ctr);
     }
     return v.count + 64 <= gcap;
 }
@@ -449,7 +554,7 @@ __host__ __device__ inline size_t lds_bytes(int R, int T, uint32_t dim, uint32_t
 
 template <int R, int T, bool INS>
 __device__ __forceinline__ void carve(unsigned char *smem, uint32_t dim, uint32_t nbuckets, uint32_t lcap, WaveMem &m,
-                                      Visited &vis)
+                                      Visited &vis, uint32_t tagcfg = 0)
 {
     unsigned char *p = smem;
     m.W = reinterpret_cast<uint64_t *>(p); p += (size_t)R * 64 * 8;
@@ -466,6 +571,8 @@ __device__ __forceinline__ void carve(unsigned char *smem, uint32_t dim, uint32_
     vis.lds = reinterpret_cast<uint32_t *>(p);
     vis.lnb = nbuckets;
     vis.lcap = lcap;
+    vis.tag_bb = tagcfg & 0xFFu;          // tagcfg = log2(16-byte buckets) | idbits << 8, or 0
+    vis.idbits = tagcfg >> 8;
 }
 
 struct WorkCtr {
@@ -546,7 +653,7 @@ __device__ uint32_t search_level_v1(const GraphView &g, const WaveMem &m, Visite
             if (wbase) word = wi < stride ? row[wi] : 0u;
             const bool valid = wi >= 1 && wi <= cnt;
             if (!visited_reserve(vis, lane, &g.hdr->ctr_search[3])) { fail = true; return nW; }
-            const bool fresh = valid && visited_insert(vis, word); // core.rs:648-649
+            const bool fresh = visited_insert_wave(vis, valid, word, lane, &g.hdr->ctr_search[3]); // core.rs:648-649
             const uint64_t fm = __ballot(fresh);
             const uint32_t nf = __popcll(fm);
             PH_MARK(ctr, 1);  // visited filter
@@ -749,7 +856,7 @@ __device__ uint32_t search_level_v2(const GraphView &g, const WaveMem &m, Visite
             if (wbase) word = wi < stride ? row[wi] : 0u;
             const bool valid = wi >= 1 && wi <= cnt;
             if (!visited_reserve(vis, lane, &g.hdr->ctr_search[3])) { fail = true; return nW; }
-            const bool fresh = valid && visited_insert(vis, word); // core.rs:648-649
+            const bool fresh = visited_insert_wave(vis, valid, word, lane, &g.hdr->ctr_search[3]); // core.rs:648-649
             const uint64_t fm = __ballot(fresh);
             const uint32_t nf = __popcll(fm);
             PH_MARK(ctr, 1);  // visited filter

@@ -55,6 +55,8 @@ struct hnsw_index {
     bool ev_valid = false;
     int lds_buckets_override = -1;
     bool prefetch = true;
+    bool tag_table = true;          // 16-bit tag visited table when the id range allows it
+    int tag_bb_override = -1;       // tests: force log2(buckets) of the tag table
     bool fast_built = false;        // the fast build prunes one-directionally: links may be asymmetric
     uint32_t lds_fill_x2 = 13;       // LDS visited table holds lnb * fill/2 ids (of 7 per bucket) before spilling
     int grid_override = -1;
@@ -144,7 +146,8 @@ GraphView view(const hnsw_index *h)
     g.dim = h->dim;
     g.stride0 = h->stride0;
     g.strideU = h->strideU;
-    g.flags = h->prefetch ? 1u : 0u;
+    g.flags = 0;
+    g.tagcfg = 0;
     return g;
 }
 
@@ -268,6 +271,36 @@ uint32_t pick_lnb(const hnsw_index *h, int R, int T, bool ins, uint32_t nwaves)
     return std::max(std::min(fit, useful), 2u);
 }
 
+// LDS visited-set configuration of one launch
+struct VisCfg {
+    uint32_t lnb;      // 32-byte buckets (32-bit id mode); also sizes LDS in tag mode via `bytes`
+    uint32_t lcap;     // ids before the set moves to HBM
+    uint32_t tagcfg;   // 0, or log2(16-byte buckets) | idbits << 8
+    size_t bytes;      // LDS bytes of the table
+};
+
+VisCfg pick_vis(const hnsw_index *h, int R, int T, bool ins, uint32_t nwaves)
+{
+    VisCfg c;
+    c.lnb = pick_lnb(h, R, T, ins, nwaves);
+    c.lcap = c.lnb * h->lds_fill_x2 / 2;
+    c.tagcfg = 0;
+    c.bytes = (size_t)c.lnb * 32;
+    if (!h->tag_table || (h->lds_buckets_override >= 2 && h->tag_bb_override < 2)) return c;
+    // tag mode: the largest power-of-two count of 16-byte buckets in the same LDS share, if the
+    // id range fits 13 tag bits (ids < 2^(bb+13): 16 M nodes at 2048 buckets)
+    uint32_t bb = 0;
+    while (((size_t)16 << (bb + 1)) <= c.bytes && bb + 1 <= 12) ++bb;
+    if (h->tag_bb_override >= 2) bb = std::min<uint32_t>(bb, (uint32_t)h->tag_bb_override);
+    if (bb < 2) return c;
+    const uint32_t idbits = std::max(ceil_log2(std::max(h->cap, 2u)), bb);
+    if (idbits - bb > 13) return c;
+    c.tagcfg = bb | (idbits << 8);
+    c.lcap = (1u << bb) * 6u;                     // 6 of the 7 entries per bucket
+    c.bytes = (size_t)16 << bb;
+    return c;
+}
+
 constexpr uint32_t kSpillRegions = 4;
 
 // Pick the next spill region for a launch on `st`; the stream first waits for the launch that used
@@ -328,8 +361,11 @@ template <int MODE, int T, int R>
 hnsw_status launch_search_t(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t *d_ids,
                             float *d_sims, uint32_t *d_nout, hipStream_t st)
 {
-    const uint32_t lnb = pick_lnb(h, R, T, false, B);
-    const size_t lds = lds_bytes(R, T, h->dim, lnb, false);
+    const VisCfg vc = pick_vis(h, R, T, false, B);
+    const uint32_t lnb = vc.lnb;
+    const size_t lds = lds_fixed_bytes(R, T, h->dim, false) + vc.bytes;
+    GraphView gv = view(h);
+    gv.tagcfg = vc.tagcfg;
     auto kern = k_search<MODE, T, R>;
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -339,7 +375,7 @@ hnsw_status launch_search_t(hnsw_index *h, const float *dQ, uint32_t B, uint32_t
     hnsw_status ss = spill_acquire(h, st, &region, &spill);
     if (ss != HNSW_OK) return ss;
     HIP_TRY(h, hipEventRecord(h->ev0, st));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, st, view(h), dQ, B, k, h->efc, lnb, lnb * h->lds_fill_x2 / 2, spill,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, st, gv, dQ, B, k, h->efc, lnb, vc.lcap, spill,
                        h->spill_gnb, d_ids, d_sims, d_nout);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->ev1, st));
@@ -521,6 +557,8 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
 {
     if (!h || !key) return HNSW_ERR_INVALID;
     if (!std::strcmp(key, "prefetch")) { h->prefetch = value != 0; return HNSW_OK; }
+    if (!std::strcmp(key, "tag_table")) { h->tag_table = value != 0; return HNSW_OK; }
+    if (!std::strcmp(key, "tag_bb")) { h->tag_bb_override = (int)value; return HNSW_OK; }
     if (!std::strcmp(key, "lds_fill_x2")) { h->lds_fill_x2 = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 2), 13); return HNSW_OK; }
     if (!std::strcmp(key, "lds_buckets")) { h->lds_buckets_override = (int)value; return HNSW_OK; }
     if (!std::strcmp(key, "lds_hash_bits")) { h->lds_buckets_override = std::max<int>(2, (int)((1ll << value) / 8)); return HNSW_OK; }

@@ -38,7 +38,7 @@ __device__ uint32_t select_topm(const GraphView &g, const WaveMem &m, Visited &v
     for (uint32_t base = 0; base < ncand; base += 64) {     // core.rs:693-696
         if (!visited_reserve(vis, lane, nullptr)) { fail = true; return 0; }
         const uint32_t i = base + lane;
-        if (i < ncand) visited_insert(vis, key_id(cand[i]));
+        visited_insert_wave(vis, i < ncand, i < ncand ? key_id(cand[i]) : 0u, lane, nullptr);
         vis.count += ncand - base < 64 ? ncand - base : 64;
     }
     // core.rs:685 w = c.clone(): S starts as the nearest mcap candidates, minus `ignored`
@@ -80,7 +80,7 @@ __device__ uint32_t select_topm(const GraphView &g, const WaveMem &m, Visited &v
             if (wbase) word = wi < stride ? row[wi] : 0u;
             const bool valid = wi >= 1 && wi <= cnt && word != qid && word != ignored; // core.rs:704-708
             if (!visited_reserve(vis, lane, nullptr)) { fail = true; return 0; }
-            const bool fresh = valid && visited_insert(vis, word);  // core.rs:710,718
+            const bool fresh = visited_insert_wave(vis, valid, word, lane, nullptr);  // core.rs:710,718
             const uint64_t fm = __ballot(fresh);
             const uint32_t nf = __popcll(fm);
             if (nf == 0) continue;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(64) void k_insert_plan(GraphView g, uint32_t first_
     const int lane = threadIdx.x;
     WaveMem m;
     Visited vis;
-    carve<R, T, true>(smem, g.dim, lnb, lcap, m, vis);
+    carve<R, T, true>(smem, g.dim, lnb, lcap, m, vis, g.tagcfg);
     vis.glob = gspill + (size_t)blockIdx.x * gnb * 8;
     vis.gnb = gnb;
     vis.glob_dirty = false;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(64) void k_insert_commit_exact(GraphView g, uint32_
     const int lane = threadIdx.x;
     WaveMem m;
     Visited vis;
-    carve<R, T, true>(smem, g.dim, lnb, lcap, m, vis);
+    carve<R, T, true>(smem, g.dim, lnb, lcap, m, vis, g.tagcfg);
     vis.glob = gspill;
     vis.gnb = gnb;
     vis.glob_dirty = false;
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(64) void k_delete_exact(GraphView g, uint32_t id, u
     const int lane = threadIdx.x;
     WaveMem m;
     Visited vis;
-    carve<R, T, true>(smem, g.dim, lnb, lcap, m, vis);
+    carve<R, T, true>(smem, g.dim, lnb, lcap, m, vis, g.tagcfg);
     vis.glob = gspill;
     vis.gnb = gnb;
     vis.glob_dirty = false;

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(64) void k_search(GraphView g, const float *__restr
     const int lane = threadIdx.x;
     WaveMem m;
     Visited vis;
-    carve<R, T, false>(smem, g.dim, lnb, lcap, m, vis);
+    carve<R, T, false>(smem, g.dim, lnb, lcap, m, vis, g.tagcfg);
     vis.glob = gspill + (size_t)blockIdx.x * gnb * 8;
     vis.gnb = gnb;
     vis.glob_dirty = false;

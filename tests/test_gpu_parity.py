@@ -124,6 +124,40 @@ def test_search_visited_spill_is_exact(eng, oracle_mod, built):
     gi.close()
 
 
+@pytest.mark.parametrize("bb", [3, 5, 7])
+def test_tag_table_spill_and_decode_is_exact(eng, oracle_mod, built, bb):
+    """A tiny 16-bit tag table: full-bucket chains and capacity spills decode every entry back to its
+    id (inverse hash) and continue in HBM; ids, similarities and counters must not change."""
+    n, dim, m, ef, k, nq = 2000, 128, 16, 200, 10, 64
+    V, o, lv = built(n, dim, m, ef)
+    gi = eng.Index("foo", dim, m, ef)
+    gi.import_graph(o.export())
+    Q = make_data(nq, dim, seed=3)
+    gi.set_tuning("tag_bb", bb)
+    gi.reset_counters()
+    ids, sims, n_out = gi.search_batch(Q, k)
+    sc, _ = gi.counters()
+    assert sc.n_spill > 0
+    oids, osims, on, oct = o.search_batch(Q, k)
+    assert np.array_equal(ids, oids) and np.array_equal(_bits(sims), _bits(osims))
+    assert (sc.n_dist, sc.n_ids, sc.n_expand) == (oct.n_dist, oct.n_ids, oct.n_expand)
+    gi.close()
+
+
+def test_32bit_visited_table_still_exact(eng, oracle_mod, built):
+    """tag_table=0 keeps the 32-bit-id LDS table (used for indexes above 16 M ids)"""
+    n, dim, m, ef, k, nq = 2000, 128, 16, 200, 10, 64
+    V, o, lv = built(n, dim, m, ef)
+    gi = eng.Index("foo", dim, m, ef)
+    gi.import_graph(o.export())
+    gi.set_tuning("tag_table", 0)
+    Q = make_data(nq, dim, seed=3)
+    ids, sims, _ = gi.search_batch(Q, k)
+    oids, osims, _, _ = o.search_batch(Q, k)
+    assert np.array_equal(ids, oids) and np.array_equal(_bits(sims), _bits(osims))
+    gi.close()
+
+
 def test_export_round_trip(eng, oracle_mod, built):
     V, o, lv = built(1200, 32, 5, 16)
     g = o.export()
