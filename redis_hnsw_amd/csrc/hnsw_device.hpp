@@ -602,7 +602,7 @@ struct WorkCtr {
 // one is popped.  Leaves W[0..n) sorted nearest first; returns n.
 // ---------------------------------------------------------------------------
 template <int MODE, int T, int R>
-__device__ uint32_t search_level_v1(const GraphView &g, const WaveMem &m, Visited &vis, const QReg<T> &qr,
+__device__ __forceinline__ uint32_t search_level_v1(const GraphView &g, const WaveMem &m, Visited &vis, const QReg<T> &qr,
                                  uint32_t ep, uint32_t ef, uint32_t lc, WorkCtr &ctr, int lane, bool &fail)
 {
     visited_clear(vis, lane);                    // core.rs:614
@@ -792,7 +792,7 @@ __device__ __forceinline__ uint64_t w_at(const uint64_t (&w)[R], uint32_t idx)
 }
 
 template <int MODE, int T, int R>
-__device__ uint32_t search_level_v2(const GraphView &g, const WaveMem &m, Visited &vis, const QReg<T> &qr,
+__device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const WaveMem &m, Visited &vis, const QReg<T> &qr,
                                     uint32_t ep, uint32_t ef, uint32_t lc, WorkCtr &ctr, int lane, bool &fail)
 {
     static_assert(MODE == MODE_AVX && T > 0, "register-resident path");

@@ -330,8 +330,9 @@ hnsw_status wait_inflight_searches(hnsw_index *h)
 __global__ void k_fill_buckets(uint4 *t, size_t n16)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint4 e0 = make_uint4(0u, kEmpty, kEmpty, kEmpty), e1 = make_uint4(kEmpty, kEmpty, kEmpty, kEmpty);
-    for (; i < n16; i += (size_t)gridDim.x * blockDim.x) t[i] = (i & 1) ? e1 : e0;
+    // piece i heads a bucket iff i is even; the stride is even, so a thread's parity is constant
+    const uint4 e = make_uint4((i & 1) ? kEmpty : 0u, kEmpty, kEmpty, kEmpty);
+    for (; i < n16; i += (size_t)gridDim.x * blockDim.x) t[i] = e;
 }
 
 hnsw_status ensure_spill(hnsw_index *h)

@@ -30,7 +30,7 @@ constexpr uint32_t kPlanStride = 1 + 64;  // per (slot, layer): count + up to 64
 // untouched.  Result in m.S[0..n), sorted; returns n.
 // ---------------------------------------------------------------------------
 template <int MODE, int T>
-__device__ uint32_t select_topm(const GraphView &g, const WaveMem &m, Visited &vis, const QReg<T> &qr,
+__device__ __forceinline__ uint32_t select_topm(const GraphView &g, const WaveMem &m, Visited &vis, const QReg<T> &qr,
                                 const uint64_t *cand, uint32_t ncand, uint32_t qid, uint32_t mcap,
                                 uint32_t lc, WorkCtr &ctr, int lane, bool &fail, uint32_t ignored = kEmpty)
 {
@@ -106,7 +106,7 @@ __device__ uint32_t select_topm(const GraphView &g, const WaveMem &m, Visited &v
 // plan[(slot*kMaxLayers + lc)*kPlanStride] = n, then n ids nearest first.
 // ---------------------------------------------------------------------------
 template <int MODE, int T, int R>
-__global__ __launch_bounds__(64) void k_insert_plan(GraphView g, uint32_t first_id, uint32_t count, uint32_t ef,
+__global__ __launch_bounds__(64, 1) void k_insert_plan(GraphView g, uint32_t first_id, uint32_t count, uint32_t ef,
                                                     uint32_t mlinks, uint32_t lnb, uint32_t lcap, uint32_t *__restrict__ gspill,
                                                     uint32_t gnb, uint32_t *__restrict__ plan)
 {
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64) void k_insert_plan(GraphView g, uint32_t first_
 __device__ __forceinline__ void touch_push(uint32_t *touched, uint32_t cap, uint32_t &nt, uint32_t id, bool on,
                                            int lane);
 
-__device__ void update_connections(const GraphView &g, const WaveMem &m, uint32_t e, uint32_t *erow, uint32_t cnt,
+__device__ __forceinline__ void update_connections(const GraphView &g, const WaveMem &m, uint32_t e, uint32_t *erow, uint32_t cnt,
                                    uint32_t nS, uint32_t lc, uint32_t stride, uint32_t *maxdeg, uint32_t ignored,
                                    uint32_t *touched, uint32_t touched_cap, uint32_t &nt, int lane)
 {
@@ -245,7 +245,7 @@ __device__ __forceinline__ void touch_push(uint32_t *touched, uint32_t cap, uint
 }
 
 template <int MODE, int T, int R>
-__global__ __launch_bounds__(64) void k_insert_commit_exact(GraphView g, uint32_t id, uint32_t mlinks,
+__global__ __launch_bounds__(64, 1) void k_insert_commit_exact(GraphView g, uint32_t id, uint32_t mlinks,
                                                             uint32_t lnb, uint32_t lcap, uint32_t *__restrict__ gspill,
                                                             uint32_t gnb, const uint32_t *__restrict__ plan,
                                                             uint32_t *__restrict__ touched, uint32_t touched_cap)
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(64) void k_insert_commit_exact(GraphView g, uint32_
 // order.  The host re-elects the enterpoint afterwards.
 // ---------------------------------------------------------------------------
 template <int MODE, int T, int R>
-__global__ __launch_bounds__(64) void k_delete_exact(GraphView g, uint32_t id, uint32_t mlinks, uint32_t lnb,
+__global__ __launch_bounds__(64, 1) void k_delete_exact(GraphView g, uint32_t id, uint32_t mlinks, uint32_t lnb,
                                                      uint32_t lcap, uint32_t *__restrict__ gspill, uint32_t gnb,
                                                      uint32_t *__restrict__ touched, uint32_t touched_cap)
 {
