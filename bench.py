@@ -116,11 +116,12 @@ def main():
     # ---- device-resident inputs/outputs ---------------------------------------------
     dev = torch.device("cuda", local_rank)
     myQ = torch.from_numpy(Qall[rank * n_qbatches * B:(rank + 1) * n_qbatches * B]).to(dev)
-    d_ids = torch.empty((B, k), dtype=torch.int32, device=dev)
-    d_sims = torch.empty((B, k), dtype=torch.float32, device=dev)
+    # ids and similarities share one buffer so that a single all-gather moves both
+    d_out = torch.empty((2, B, k), dtype=torch.int32, device=dev)
+    d_ids = d_out[0]
+    d_sims = d_out[1].view(torch.float32)
     d_n = torch.empty((B,), dtype=torch.int32, device=dev)
-    g_ids = torch.empty((world * B, k), dtype=torch.int32, device=coll_dev) if world > 1 else None
-    g_sims = torch.empty((world * B, k), dtype=torch.float32, device=coll_dev) if world > 1 else None
+    g_out = torch.empty((world * 2, B, k), dtype=torch.int32, device=coll_dev) if world > 1 else None
     stream = torch.cuda.current_stream()
 
     def step(i):
@@ -128,10 +129,7 @@ def main():
         index.search_batch_device(q.data_ptr(), B, k, d_ids.data_ptr(), d_sims.data_ptr(), d_n.data_ptr(),
                                   stream.cuda_stream)
         if world > 1:   # the path's one real exchange: gather every shard's top-k
-            if backend == "nccl":
-                shard.gather_topk(dist, d_ids, d_sims, world, g_ids, g_sims)
-            else:
-                shard.gather_topk(dist, d_ids.cpu(), d_sims.cpu(), world, g_ids, g_sims)
+            shard.gather_packed(dist, d_out if backend == "nccl" else d_out.cpu(), world, g_out)
 
     log("inputs resident; warm-up")
     for i in range(args.warmup):

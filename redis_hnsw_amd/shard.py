@@ -27,6 +27,17 @@ def gather_topk(dist, ids, sims, world, out_ids=None, out_sims=None):
     return out_ids, out_sims
 
 
+def gather_packed(dist, packed, world, out=None):
+    """One collective instead of two: `packed` is an int32 [2, b, k] buffer whose plane 0 holds the ids
+    and plane 1 the f32 similarities (bit pattern); returns [world, 2, b, k]."""
+    import torch
+    if out is None:   # concatenation layout (world * 2, b, k): accepted by both RCCL and gloo
+        out = torch.empty((world * packed.shape[0],) + tuple(packed.shape[1:]), dtype=packed.dtype,
+                          device=packed.device)
+    dist.all_gather_into_tensor(out, packed.contiguous())
+    return out.view((world,) + tuple(packed.shape))
+
+
 def broadcast_graph(dist, graph, n_nodes, src=0, device="cpu"):
     """One-time index distribution: rank `src` holds `graph` (levels, enterpoint,
     max_layer, per-layer CSR as produced by Index.export_graph()); every rank

@@ -53,6 +53,11 @@ def _worker(rank, world, port, tmpdir):
     rids, rsims, _, _ = replica.search_batch(Q, k)
     assert np.array_equal(all_ids.numpy(), rids.astype(np.int64))
     assert np.array_equal(all_sims.numpy().view(np.uint32), rsims.view(np.uint32))
+    # the single-collective form bench.py uses: ids and similarity bits in one int32 buffer
+    packed = torch.from_numpy(np.stack([ids.astype(np.int32), sims.view(np.int32)]))
+    allp = shard.gather_packed(dist, packed, world).numpy()
+    assert np.array_equal(allp[:, 0].reshape(-1, k), rids.astype(np.int32))
+    assert np.array_equal(allp[:, 1].reshape(-1, k).view(np.uint32), rsims.view(np.uint32))
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(tmpdir, "ok%d" % rank), "w").write("ok")
