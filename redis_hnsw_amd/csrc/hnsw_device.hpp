@@ -48,7 +48,6 @@ struct GraphView {
     const uint32_t *levels;     // [cap]
     DevHeader *hdr;
     uint32_t dim, stride0, strideU;
-    uint32_t flags;             // (unused)
     uint32_t tagcfg;            // 16-bit tag visited table: log2(buckets) | idbits << 8; 0 = 32-bit ids
 };
 
@@ -621,23 +620,11 @@ __device__ __forceinline__ uint32_t search_level_v1(const GraphView &g, const Wa
     const uint32_t stride = lc ? g.strideU : g.stride0;
 
     PH_T0();
-#ifdef HNSW_PHASE_TIMERS
-    uint32_t predicted = kEmpty;
-#endif
     for (;;) {
         const int pos = find_unexpanded<R>(m.W, nW, lane); // core.rs:631
         if (pos < 0) break;                               // core.rs:630,635
         const uint64_t ckey = m.W[pos];
         const uint32_t c = key_id(ckey);
-#ifdef HNSW_PHASE_TIMERS
-        if (ef > 1) {
-            ctr.ph[4] += (c == predicted);
-            // the runner-up: next unexpanded entry after pos (what a prefetcher would guess)
-            predicted = kEmpty;
-            for (uint32_t j = pos + 1; j < nW; ++j)
-                if (!(m.W[j] & 1ull)) { predicted = key_id(m.W[j]); break; }
-        }
-#endif
         __syncthreads();
         if (lane == 0) m.W[pos] = ckey | 1ull;
         ctr.n_expand += 1;
@@ -682,12 +669,11 @@ __device__ __forceinline__ uint32_t search_level_v1(const GraphView &g, const Wa
 // L, 64+L, ...), LDS only carries the scatter of the merge; neighbour ids reach
 // the 8-lane gather groups with ds_bpermute instead of an LDS compaction, and
 // each distance is kept by the lane that will own its key, so no LDS staging of
-// ids / distances is left.  While the current candidate's vectors are in
-// flight, the adjacency row and the vectors of the runner-up (the candidate the
-// next expansion will take unless this one uncovers a nearer node) are pulled
-// towards L2: about half of all expansions then start from a register-resident
-// row and L2-resident vectors.  The prefetch touches no state: results are
-// identical to v1 and to the reference.
+// ids / distances is left.  Two exact overlaps hide the dependent-access
+// latencies: the next candidate is known before the last merge of an expansion,
+// so its adjacency row is requested first and the merge's rank loop runs under
+// that fetch; the merge's scatter is deferred until the next expansion's vector
+// loads are in flight.  Results are identical to v1 and to the reference.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t bperm(uint32_t v, int src_lane)
 {
@@ -791,11 +777,70 @@ __device__ __forceinline__ uint64_t w_at(const uint64_t (&w)[R], uint32_t idx)
     return v;
 }
 
+// Squared distances from the query to NR vectors (ids idr[]), AVX2 summation order, for the 8-lane
+// group this lane belongs to.  T > 0: query in registers, all T loads per vector issued at once.
+// T == 0 (any dim % 32 == 0): query pieces come from LDS and the row is walked 128 floats at a
+// time with the accumulators carried -- the per-lane FMA order in t is the same.  hook() runs once,
+// right after the first loads have been issued (work to overlap with their latency).
+template <int T, int NR, typename Hook>
+__device__ __forceinline__ void dist_rounds(const float4 *vec4, uint32_t row4, const uint32_t (&idr)[NR],
+                                            const QReg<T> &qr, const float *qlds, int pp, float (&d)[NR],
+                                            Hook &&hook)
+{
+    if constexpr (T > 0) {
+        float4 v[NR][T];
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) {
+            const float4 *p = vec4 + (size_t)idr[rr] * row4 + pp;
+#pragma unroll
+            for (int t = 0; t < T; ++t) v[rr][t] = p[t * 8];
+        }
+        hook();
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) d[rr] = avx_reduce(avx_accumulate<T>(qr.q, v[rr])); // core.rs:652
+    } else {
+        const uint32_t Trt = row4 >> 3;               // 128-byte blocks per row
+        const float4 *q4 = reinterpret_cast<const float4 *>(qlds) + pp;
+        f32x2 alo[NR], ahi[NR];
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) { alo[rr] = f32x2{0.f, 0.f}; ahi[rr] = f32x2{0.f, 0.f}; }
+        bool first = true;
+        for (uint32_t t0 = 0; t0 < Trt; t0 += 4) {
+            float4 v[NR][4], q[4];
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb) {
+                if (t0 + tb < Trt) {
+                    q[tb] = q4[(t0 + tb) * 8];
+#pragma unroll
+                    for (int rr = 0; rr < NR; ++rr) v[rr][tb] = (vec4 + (size_t)idr[rr] * row4 + pp)[(t0 + tb) * 8];
+                }
+            }
+            if (first) { hook(); first = false; }
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb) {
+                if (t0 + tb < Trt) {
+                    const f32x2 qlo = {q[tb].x, q[tb].y}, qhi = {q[tb].z, q[tb].w};
+#pragma unroll
+                    for (int rr = 0; rr < NR; ++rr) {
+                        const f32x2 dlo = qlo - f32x2{v[rr][tb].x, v[rr][tb].y};
+                        const f32x2 dhi = qhi - f32x2{v[rr][tb].z, v[rr][tb].w};
+                        alo[rr] = __builtin_elementwise_fma(dlo, dlo, alo[rr]);   // metrics.rs:57,60,64,68
+                        ahi[rr] = __builtin_elementwise_fma(dhi, dhi, ahi[rr]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr)
+            d[rr] = avx_reduce(make_float4(alo[rr].x, alo[rr].y, ahi[rr].x, ahi[rr].y));
+    }
+}
+
 template <int MODE, int T, int R>
 __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const WaveMem &m, Visited &vis, const QReg<T> &qr,
                                     uint32_t ep, uint32_t ef, uint32_t lc, WorkCtr &ctr, int lane, bool &fail)
 {
-    static_assert(MODE == MODE_AVX && T > 0, "register-resident path");
+    static_assert(MODE == MODE_AVX, "AVX2 summation order (dim % 32 == 0)");
     const int grp = lane >> 3, pp = piece_of_lane(lane), sub = lane & 7;
     const float4 *vec4 = reinterpret_cast<const float4 *>(g.vec);
     const uint32_t row4 = g.dim >> 2;                 // float4 per vector row
@@ -810,11 +855,10 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
     uint64_t w[R];
     uint64_t ckey;
     {
-        float4 v[T];
-        const float4 *p = vec4 + (size_t)ep * row4 + pp;
-#pragma unroll
-        for (int t = 0; t < T; ++t) v[t] = p[t * 8];
-        const float d = avx_reduce(avx_accumulate<T>(qr.q, v)); // core.rs:621
+        const uint32_t id1[1] = {ep};
+        float d1[1];
+        dist_rounds<T, 1>(vec4, row4, id1, qr, m.qlds, pp, d1, [] {});   // core.rs:621
+        const float d = d1[0];
         ctr.n_dist += 1;
 #pragma unroll
         for (int r = 0; r < R; ++r) w[r] = ~0ull;
@@ -880,7 +924,6 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
                     (uint32_t)__builtin_amdgcn_readlane((int)word, __ffsll((unsigned long long)fm) - 1);
 #pragma unroll
                 for (int r0 = 0; r0 < 4; r0 += RB) {
-                    float4 v[RB][T];
                     uint32_t idr[RB];
 #pragma unroll
                     for (int rr = 0; rr < RB; ++rr) {
@@ -888,20 +931,19 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
                         const int s = pass * 32 + r * 8 + grp;
                         const uint32_t got = bperm(word, (s + shift) & 63);
                         idr[rr] = ((pm >> (r * 8 + grp)) & 1u) ? got : safe_id;
-                        const float4 *p = vec4 + (size_t)idr[rr] * row4 + pp;
-#pragma unroll
-                        for (int t = 0; t < T; ++t) v[rr][t] = p[t * 8];
                     }
-                    if (r0 == 0 && __ballot(ptake)) {          // deferred scatter, under the loads just issued
-                        nW = merge_apply<R>(w, m.W, nW, ef, pkey, ptake, pup, ppos, lane);
-                        ptake = false;
-                        PH_MARK(ctr, 3);
-                    }
+                    float dd[RB];
+                    dist_rounds<T, RB>(vec4, row4, idr, qr, m.qlds, pp, dd, [&] {
+                        if (r0 == 0 && __ballot(ptake)) {      // deferred scatter, under the loads just issued
+                            nW = merge_apply<R>(w, m.W, nW, ef, pkey, ptake, pup, ppos, lane);
+                            ptake = false;
+                            PH_MARK(ctr, 3);
+                        }
+                    });
 #pragma unroll
                     for (int rr = 0; rr < RB; ++rr) {
                         const int r = r0 + rr;
-                        const float d = avx_reduce(avx_accumulate<T>(qr.q, v[rr]));    // core.rs:652
-                        if (sub == r && ((pm >> (r * 8 + grp)) & 1u)) { key = pack_key(d, idr[rr]); have = true; }
+                        if (sub == r && ((pm >> (r * 8 + grp)) & 1u)) { key = pack_key(dd[rr], idr[rr]); have = true; }
                     }
                 }
                 PH_MARK(ctr, 2);  // vector gather + distances
@@ -979,7 +1021,7 @@ __device__ __forceinline__ uint32_t search_level(const GraphView &g, const WaveM
                                                  WorkCtr &ctr, int lane, bool &fail)
 {
 #ifndef HNSW_SEARCH_V1
-    if constexpr (MODE == MODE_AVX && T > 0) return search_level_v2<MODE, T, R>(g, m, vis, qr, ep, ef, lc, ctr, lane, fail);
+    if constexpr (MODE == MODE_AVX) return search_level_v2<MODE, T, R>(g, m, vis, qr, ep, ef, lc, ctr, lane, fail);
     else
 #endif
         return search_level_v1<MODE, T, R>(g, m, vis, qr, ep, ef, lc, ctr, lane, fail);

@@ -54,7 +54,6 @@ struct hnsw_index {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_sync = nullptr;
     bool ev_valid = false;
     int lds_buckets_override = -1;
-    bool prefetch = true;
     bool tag_table = true;          // 16-bit tag visited table when the id range allows it
     int tag_bb_override = -1;       // tests: force log2(buckets) of the tag table
     bool fast_built = false;        // the fast build prunes one-directionally: links may be asymmetric
@@ -146,7 +145,6 @@ GraphView view(const hnsw_index *h)
     g.dim = h->dim;
     g.stride0 = h->stride0;
     g.strideU = h->strideU;
-    g.flags = 0;
     g.tagcfg = 0;
     return g;
 }
@@ -557,7 +555,6 @@ const char *hnsw_last_error(const hnsw_index *h) { return h ? h->err.c_str() : "
 hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
 {
     if (!h || !key) return HNSW_ERR_INVALID;
-    if (!std::strcmp(key, "prefetch")) { h->prefetch = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "tag_table")) { h->tag_table = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "tag_bb")) { h->tag_bb_override = (int)value; return HNSW_OK; }
     if (!std::strcmp(key, "lds_fill_x2")) { h->lds_fill_x2 = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 2), 13); return HNSW_OK; }

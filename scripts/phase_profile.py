@@ -41,15 +41,14 @@ lib = _capi.load()
 if hasattr(lib, "hnsw_debug_phase_cycles"):
     out = (C.c_uint64 * 8)()
     lib.hnsw_debug_phase_cycles(gi._h, out)
-    tot = sum(out[:4])
+    tot = sum(out[:6])
     if tot:
         names = ["pop+row fetch", "visited filter", "gather+dist", "merge W"]
         per_step = sc.n_expand
         for i, nm in enumerate(names):
             print("  %-16s %6.1f%%  %8.0f cycles/expansion" % (nm, 100.0 * out[i] / tot, out[i] / per_step))
         print("  choose next + row request   %8.0f cycles/expansion" % (out[4] / per_step))
-        print("  deferred merges: %.2f accepted keys/expansion, rank loop %.0f cycles/expansion (%.0f per key)" % (
-            out[5] / per_step, out[6] / per_step, out[6] / max(out[5], 1)))
+        print("  merge ranks (under row fetch) %6.0f cycles/expansion" % (out[5] / per_step))
         print("  longest wave %.1f us" % (out[7] / 100.0))
         print("  total cycles/expansion %.0f ; cycles/query %.0f" % (tot / per_step, tot / (reps * B)))
 
