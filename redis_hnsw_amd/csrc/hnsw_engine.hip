@@ -555,6 +555,10 @@ const char *hnsw_last_error(const hnsw_index *h) { return h ? h->err.c_str() : "
 hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
 {
     if (!h || !key) return HNSW_ERR_INVALID;
+    if (!std::strcmp(key, "force_restride")) {   // tests: widen both adjacency tables by `value` words now
+        HIP_TRY(h, hipSetDevice(h->device));
+        return restride(h, h->stride0 + (uint32_t)value, h->strideU + (uint32_t)value);
+    }
     if (!std::strcmp(key, "tag_table")) { h->tag_table = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "tag_bb")) { h->tag_bb_override = (int)value; return HNSW_OK; }
     if (!std::strcmp(key, "lds_fill_x2")) { h->lds_fill_x2 = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 2), 13); return HNSW_OK; }

@@ -411,6 +411,54 @@ def test_exact_insert_after_fast_build(eng, oracle_mod):
     gi.close()
 
 
+@pytest.mark.parametrize("n,dim,m,ef,k", [(400, 32, 32, 64, 20), (500, 64, 8, 600, 50), (300, 128, 12, 1024, 10)])
+def test_wide_rows_and_large_ef(eng, oracle_mod, n, dim, m, ef, k):
+    """M=32 (rows wider than one 64-lane chunk) and ef up to the 1024 limit (R = 16 list slices):
+    exact insert and search against the oracle"""
+    V = make_data(n, dim, seed=81)
+    lv = oracle_mod.draw_levels(n, m, 6)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch(V, lv)
+    gi = eng.Index("foo", dim, m, ef)
+    gi.add_batch(V, levels=lv, mode="exact")
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    Q = make_data(24, dim, seed=2)
+    gi.reset_counters()
+    ids, sims, n_out = gi.search_batch(Q, k)
+    oids, osims, on, oct = o.search_batch(Q, k)
+    assert np.array_equal(n_out, on)
+    valid = np.arange(k)[None, :] < on[:, None]
+    assert np.array_equal(ids[valid], oids[valid]) and np.array_equal(_bits(sims)[valid], _bits(osims)[valid])
+    sc, _ = gi.counters()
+    assert (sc.n_dist, sc.n_ids, sc.n_expand) == (oct.n_dist, oct.n_ids, oct.n_expand)
+    gi.close()
+
+
+def test_restride_keeps_the_graph(eng, oracle_mod):
+    """widening the adjacency tables (what the engine does when degrees approach the row capacity)
+    in the middle of an exact build must not change anything"""
+    n, dim, m, ef = 500, 32, 6, 32
+    V = make_data(n, dim, seed=91)
+    lv = oracle_mod.draw_levels(n, m, 3)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch(V, lv)
+    gi = eng.Index("foo", dim, m, ef)
+    s0 = gi.info().stride0
+    for i in range(n):
+        gi.add_node("node%d" % i, V[i], level=int(lv[i]))
+        if i in (100, 300):
+            gi.set_tuning("force_restride", 16)
+    assert gi.info().stride0 == s0 + 32
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    Q = make_data(16, dim, seed=2)
+    ids, sims, _ = gi.search_batch(Q, 5)
+    oids, osims, _, _ = o.search_batch(Q, 5)
+    assert np.array_equal(ids, oids) and np.array_equal(_bits(sims), _bits(osims))
+    gi.close()
+
+
 def test_many_layers_small_m(eng, oracle_mod):
     """M=2 gives level_mult = 1/ln 2: tall hierarchies (10+ layers) and tiny rows"""
     n, dim, m, ef = 600, 32, 2, 8
