@@ -12,8 +12,14 @@ N = int(sys.argv[1]); dim = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 M = int(sys.argv[3]) if len(sys.argv) > 3 else 16; ef = int(sys.argv[4]) if len(sys.argv) > 4 else 200
 modes = sys.argv[5].split(",") if len(sys.argv) > 5 else ["fast", "exact"]
 k = 10
-V = np.random.default_rng(1).random((N, dim), dtype=np.float32)
-Q = np.random.default_rng(2).random((512, dim), dtype=np.float32)
+if os.environ.get("HNSW_DATA") == "clustered":
+    from bench import clustered
+    centers = np.random.default_rng(3).random((64, dim), dtype=np.float32)
+    V = clustered(N, dim, 3, centers)
+    Q = clustered(512, dim, 4, centers)
+else:
+    V = np.random.default_rng(1).random((N, dim), dtype=np.float32)
+    Q = np.random.default_rng(2).random((512, dim), dtype=np.float32)
 lv = draw_levels(N, M, 7)
 gt = brute_force_topk(V, Q, k)
 for mode in modes:
