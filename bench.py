@@ -133,12 +133,33 @@ def main():
     g_out = torch.empty((world * 2, B, k), dtype=torch.int32, device=coll_dev) if world > 1 else None
     stream = torch.cuda.current_stream()
 
+    # N > 1: the gather of step i runs on its own stream while step i+1 searches (two result buffers)
+    overlap = world > 1
+    if overlap:
+        comm_stream = torch.cuda.Stream()
+        bufs = [d_out, torch.empty_like(d_out)]
+        gouts = [g_out, torch.empty_like(g_out)]
+        ready = [torch.cuda.Event(), torch.cuda.Event()]
+        gathered = [torch.cuda.Event(), torch.cuda.Event()]
+
     def step(i):
         q = myQ[(i % n_qbatches) * B:(i % n_qbatches + 1) * B]
-        index.search_batch_device(q.data_ptr(), B, k, d_ids.data_ptr(), d_sims.data_ptr(), d_n.data_ptr(),
+        if not overlap:
+            index.search_batch_device(q.data_ptr(), B, k, d_ids.data_ptr(), d_sims.data_ptr(), d_n.data_ptr(),
+                                      stream.cuda_stream)
+            return
+        s_ = i % 2
+        buf = bufs[s_]
+        if i >= 2:
+            stream.wait_event(gathered[s_])          # the gather that last read this buffer is done
+        index.search_batch_device(q.data_ptr(), B, k, buf[0].data_ptr(), buf[1].data_ptr(), d_n.data_ptr(),
                                   stream.cuda_stream)
-        if world > 1:   # the path's one real exchange: gather every shard's top-k
-            shard.gather_packed(dist, d_out if backend == "nccl" else d_out.cpu(), world, g_out)
+        ready[s_].record(stream)
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(ready[s_])
+            # the path's one real exchange: gather every shard's top-k (host copies in the gloo test mode)
+            shard.gather_packed(dist, buf if backend == "nccl" else buf.cpu(), world, gouts[s_])
+            gathered[s_].record(comm_stream)
 
     log("inputs resident; warm-up")
     for i in range(args.warmup):
