@@ -176,7 +176,7 @@ hnsw_status ensure_node_cap(hnsw_index *h, uint32_t need)
         HIP_TRY(h, hipMemcpyAsync(nub, h->d_upper_base, (size_t)h->n * 4, hipMemcpyDeviceToDevice, h->stream));
         HIP_TRY(h, hipMemcpyAsync(nlv, h->d_levels, (size_t)h->n * 4, hipMemcpyDeviceToDevice, h->stream));
     }
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipDeviceSynchronize());   // searches enqueued on caller streams may still read the old tables
     dev_free(h, h->d_vec, (size_t)h->cap * h->dim);
     dev_free(h, h->d_adj0, (size_t)h->cap * h->stride0);
     dev_free(h, h->d_upper_base, (size_t)h->cap);
@@ -196,7 +196,7 @@ hnsw_status ensure_upper_cap(hnsw_index *h, uint32_t need)
     if ((s = dev_alloc(h, &nadj, (size_t)ncap * h->strideU, 0)) != HNSW_OK) return s;
     if (h->upper_used)
         HIP_TRY(h, hipMemcpyAsync(nadj, h->d_adjU, (size_t)h->upper_used * h->strideU * 4, hipMemcpyDeviceToDevice, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipDeviceSynchronize());   // searches enqueued on caller streams may still read the old tables
     dev_free(h, h->d_adjU, (size_t)h->upper_cap * h->strideU);
     h->d_adjU = nadj;
     h->upper_cap = ncap;
@@ -215,7 +215,7 @@ hnsw_status restride(hnsw_index *h, uint32_t nstride0, uint32_t nstrideU)
             uint32_t blocks = (uint32_t)((rows * 64 + 255) / 256);
             hipLaunchKernelGGL(k_restride, dim3(blocks), dim3(256), 0, h->stream, h->d_adj0, h->stride0, nadj, nstride0, rows);
         }
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipDeviceSynchronize());   // searches enqueued on caller streams may still read the old tables
         dev_free(h, h->d_adj0, (size_t)h->cap * h->stride0);
         h->d_adj0 = nadj;
         h->stride0 = nstride0;
@@ -229,7 +229,7 @@ hnsw_status restride(hnsw_index *h, uint32_t nstride0, uint32_t nstrideU)
             uint32_t blocks = (uint32_t)((rows * 64 + 255) / 256);
             hipLaunchKernelGGL(k_restride, dim3(blocks), dim3(256), 0, h->stream, h->d_adjU, h->strideU, nadj, nstrideU, rows);
         }
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipDeviceSynchronize());   // searches enqueued on caller streams may still read the old tables
         dev_free(h, h->d_adjU, (size_t)h->upper_cap * h->strideU);
         h->d_adjU = nadj;
         h->strideU = nstrideU;

@@ -25,7 +25,9 @@ CASES = {
     "u600_dim32_m5_ef16": (600, 32, 5, 16, 5, 32, 1, 7),
     "u500_dim128_m16_ef64": (500, 128, 16, 64, 10, 32, 1, 7),
     "u400_dim12_m6_ef24": (400, 12, 6, 24, 8, 32, 5, 9),   # scalar metric order
+    "u360_dim32_m5_ef16_del": (360, 32, 5, 16, 5, 32, 11, 13),   # 300 adds, 100 deletes, 60 more adds
 }
+DELETES = {"u360_dim32_m5_ef16_del": (300, 100, 17)}   # name: (adds before, deletes, order seed)
 
 
 def build(name, spec):
@@ -40,11 +42,22 @@ def build(name, spec):
         Q = np.random.default_rng(ds + 100).random((nq, dim), dtype=np.float32)
         lv = oracle.draw_levels(n, m, ls)
     o = oracle.OracleIndex(dim, m, ef)
-    o.add_batch(V, lv)
+    n_first = n if name not in DELETES else DELETES[name][0]
+    o.add_batch(V[:n_first], lv[:n_first])
+    deleted = np.zeros(0, dtype=np.int64)
+    if name in DELETES:       # HNSW.NODE.DEL (enterpoint first), then the remaining HNSW.NODE.ADDs
+        _, n_del, seed = DELETES[name]
+        order = np.random.default_rng(seed).permutation(n_first)[:n_del]
+        ep0 = o.enterpoint
+        deleted = np.concatenate([[ep0], order[order != ep0]]).astype(np.int64)
+        for i in deleted:
+            o.delete(int(i))
+        o.add_batch(V[n_first:], lv[n_first:])
     g = o.export()
     ids, sims, n_out, ct = o.search_batch(Q, k)
     ic = o.insert_counters()
     out = dict(params=np.array([n, dim, m, ef, k], dtype=np.int64), vectors=V, queries=Q, levels=lv.astype(np.int32),
+               n_first=np.int64(n_first), deleted=deleted,
                enterpoint=np.int64(g["enterpoint"]), max_layer=np.int64(g["max_layer"]),
                ids=ids, sims_bits=sims.view(np.uint32), n_out=n_out,
                search_counters=np.array([ct.n_dist, ct.n_ids, ct.n_expand], dtype=np.int64),

@@ -18,4 +18,6 @@ def load_golden(name):
              row_ptr=[z["row_ptr_%d" % l] for l in range(L)], col=[z["col_%d" % l] for l in range(L)])
     return dict(n=n, dim=dim, m=m, ef=ef, k=k, V=z["vectors"], Q=z["queries"], levels=z["levels"], graph=g,
                 ids=z["ids"], sims_bits=z["sims_bits"], n_out=z["n_out"],
-                search_counters=z["search_counters"], insert_counters=z["insert_counters"])
+                search_counters=z["search_counters"], insert_counters=z["insert_counters"],
+                n_first=int(z["n_first"]) if "n_first" in z else n,
+                deleted=z["deleted"] if "deleted" in z else np.zeros(0, dtype=np.int64))

@@ -292,7 +292,12 @@ def test_engine_reproduces_golden(eng, name):
     """exact GPU insert -> the golden graph; GPU search -> golden ids / similarity bits / counters"""
     c = load_golden(name)
     gi = eng.Index("g", c["dim"], c["m"], c["ef"])
-    gi.add_batch(c["V"], levels=c["levels"], mode="exact")
+    nf = c["n_first"]
+    gi.add_batch(c["V"][:nf], levels=c["levels"][:nf], mode="exact")
+    for i in c["deleted"]:
+        gi.delete_node("node%d" % int(i))
+    if nf < c["n"]:
+        gi.add_batch(c["V"][nf:], levels=c["levels"][nf:], mode="exact")
     ok, why = graphs_equal(c["graph"], gi.export_graph())
     assert ok, why
     gi.reset_counters()
