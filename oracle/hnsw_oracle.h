@@ -10,11 +10,11 @@
  * Pinning: the reference is Rust and cannot be compiled in this image (no
  * rustc/cargo), so oracle/_ref does not exist.  The oracle is pinned against
  * every known-answer test the reference holds for this path
- * (src/hnsw/metrics_tests.rs:3-33, src/hnsw/core_tests.rs:12-53); see
- * tests/test_oracle_kat.py.
+ * (src/hnsw/metrics_tests.rs:3-33, src/hnsw/core_tests.rs:12-80, the delete
+ * loop included); see tests/test_oracle_kat.py.
  *
- * Two deliberate, documented restatement choices (neither is observable on
- * tie-free data):
+ * Deliberate, documented restatement choices (none observable on tie-free
+ * data; the fourth only when the enterpoint itself is deleted):
  *   1. Ids are dense u32 in insertion order; names stay on the caller's side.
  *   2. Rust's BinaryHeap leaves the order of EQUAL similarities unspecified
  *      (core_tests.rs:50-53 does not assert it).  The oracle fixes a total
@@ -23,6 +23,9 @@
  *   3. The level RNG is entropy seeded in the reference (core.rs:344), so
  *      levels are an explicit input (or drawn from a seeded generator using
  *      the same formula floor(-ln U * 1/ln m), core.rs:338,601-605).
+ *   4. delete_node re-elects the enterpoint with HashSet::iter().next()
+ *      (core.rs:453), i.e. arbitrarily among the nodes of the highest non-empty
+ *      layer; the oracle takes the smallest id of that layer.
  */
 #ifndef HNSW_ORACLE_H
 #define HNSW_ORACLE_H
