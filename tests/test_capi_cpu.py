@@ -55,3 +55,11 @@ def test_cpp_host_mirror_builds(capi):
     from redis_hnsw_amd import build
     exe = build.build_host_test()
     assert os.path.exists(exe)
+
+
+def test_error_string_is_the_debug_rendering():
+    """core.rs:42-46: clients see format!("{:?}", HNSWError::String(msg))"""
+    from redis_hnsw_amd import HNSWError
+    assert HNSWError("data dimension: 3 does not match Index").error_string() == \
+        'String("data dimension: 3 does not match Index")'
+    assert HNSWError('Node: "a\\b" already exists').error_string() == 'String("Node: \\"a\\\\b\\" already exists")'
