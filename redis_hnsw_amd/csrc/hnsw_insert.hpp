@@ -84,16 +84,54 @@ __device__ __forceinline__ uint32_t select_topm(const GraphView &g, const WaveMe
             const uint64_t fm = __ballot(fresh);
             const uint32_t nf = __popcll(fm);
             if (nf == 0) continue;
-            if (fresh) m.fresh[__popcll(fm & lanemask_lt(lane))] = word;
             vis.count += nf;
             ctr.n_dist += nf;
-            __syncthreads();
-            compute_dists<MODE, T>(g, qr, m, nf, lane);      // core.rs:711
-            __syncthreads();
-            const bool have = (uint32_t)lane < nf;
-            const uint64_t key = have ? pack_key(m.dsc[lane], m.fresh[lane]) : ~0ull;
-            const uint64_t worst = nS == mcap ? m.S[mcap - 1] : ~0ull;
-            nS = merge_sorted<1>(m.S, nS, mcap, key, have && key < worst, lane); // core.rs:717
+            if constexpr (MODE == MODE_AVX) {
+                // same gather as search_level_v2: ids reach the 8-lane groups with ds_bpermute, the
+                // four rounds of a pass are one straight-line block, keys stay in their owning lane
+                const int grp = lane >> 3, pp = piece_of_lane(lane), sub = lane & 7;
+                const float4 *vec4 = reinterpret_cast<const float4 *>(g.vec);
+                const uint32_t row4 = g.dim >> 2;
+                const int shift = wbase ? 0 : 1;
+                const uint64_t fms = fm >> shift;
+                const uint32_t safe_id =
+                    (uint32_t)__builtin_amdgcn_readlane((int)word, __ffsll((unsigned long long)fm) - 1);
+                for (int pass = 0; pass < 2; ++pass) {
+                    const uint32_t pm = (uint32_t)(fms >> (32 * pass));
+                    if (pm == 0) continue;
+                    constexpr int RB = (T <= 4) ? 4 : (T <= 8 ? 2 : 1);
+                    uint64_t key = ~0ull;
+                    bool have = false;
+#pragma unroll
+                    for (int r0 = 0; r0 < 4; r0 += RB) {
+                        uint32_t idr[RB];
+#pragma unroll
+                        for (int rr = 0; rr < RB; ++rr) {
+                            const int r = r0 + rr;
+                            const uint32_t got = bperm(word, (pass * 32 + r * 8 + grp + shift) & 63);
+                            idr[rr] = ((pm >> (r * 8 + grp)) & 1u) ? got : safe_id;
+                        }
+                        float dd[RB];
+                        dist_rounds<T, RB>(vec4, row4, idr, qr, m.qlds, pp, dd, [] {});   // core.rs:711
+#pragma unroll
+                        for (int rr = 0; rr < RB; ++rr) {
+                            const int r = r0 + rr;
+                            if (sub == r && ((pm >> (r * 8 + grp)) & 1u)) { key = pack_key(dd[rr], idr[rr]); have = true; }
+                        }
+                    }
+                    const uint64_t worst = nS == mcap ? m.S[mcap - 1] : ~0ull;
+                    nS = merge_sorted<1>(m.S, nS, mcap, key, have && key < worst, lane);   // core.rs:717
+                }
+            } else {
+                if (fresh) m.fresh[__popcll(fm & lanemask_lt(lane))] = word;
+                __syncthreads();
+                compute_dists<MODE, T>(g, qr, m, nf, lane);      // core.rs:711
+                __syncthreads();
+                const bool have = (uint32_t)lane < nf;
+                const uint64_t key = have ? pack_key(m.dsc[lane], m.fresh[lane]) : ~0ull;
+                const uint64_t worst = nS == mcap ? m.S[mcap - 1] : ~0ull;
+                nS = merge_sorted<1>(m.S, nS, mcap, key, have && key < worst, lane); // core.rs:717
+            }
         }
     }
     __syncthreads();
