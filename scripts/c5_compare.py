@@ -16,31 +16,38 @@ V = np.random.default_rng(1).random((N, dim), dtype=np.float32)
 Q = np.random.default_rng(2).random((B, dim), dtype=np.float32)
 lv = draw_levels(N, M, 7)
 out = dict(N=N, dim=dim, M=M, ef=ef, k=k, queries=B)
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "c5_compare_%d.json" % N)
+os.makedirs(os.path.dirname(OUT), exist_ok=True)
+
+
+def save():
+    json.dump(out, open(OUT, "w"), indent=1)
+    print(json.dumps(out), flush=True)
+
+
 gt = brute_force_topk(V, Q, k)
 
 t = time.time(); gf = Index("fast", dim, M, ef); gf.add_batch(V, levels=lv, mode="fast"); out["gpu_fast_build_s"] = round(time.time() - t, 2)
 ids, sims, _ = gf.search_batch(Q, k)
 out["recall_gpu_fast_built"] = round(recall_at_k(ids, gt), 4)
-print(json.dumps(out), flush=True)
+save()
 
 t = time.time(); o = oracle.OracleIndex(dim, M, ef); o.add_batch(V, lv); out["cpu_reference_order_build_s"] = round(time.time() - t, 1)
 oids, osims, _, _ = o.search_batch(Q, k, threads=os.cpu_count())
 out["recall_cpu_reference_order_built"] = round(recall_at_k(oids, gt), 4)
-print(json.dumps(out), flush=True)
+save()
 
 g = o.export()
 gc = Index("cpu-built", dim, M, ef); gc.import_graph(g)
 ids2, sims2, _ = gc.search_batch(Q, k)
 out["gpu_search_on_cpu_built_graph_identical"] = bool(np.array_equal(ids2, oids) and np.array_equal(sims2.view(np.uint32), osims.view(np.uint32)))
-import torch
-dev = torch.device("cuda", 0)
-dQ = torch.from_numpy(Q).to(dev); di = torch.empty((B, k), dtype=torch.int32, device=dev); ds = torch.empty((B, k), dtype=torch.float32, device=dev); dn = torch.empty(B, dtype=torch.int32, device=dev)
-st = torch.cuda.current_stream()
 for name, gi in (("gpu_fast_built", gf), ("cpu_built", gc)):
-    for _ in range(3): gi.search_batch_device(dQ.data_ptr(), B, k, di.data_ptr(), ds.data_ptr(), dn.data_ptr(), st.cuda_stream)
-    torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(10): gi.search_batch_device(dQ.data_ptr(), B, k, di.data_ptr(), ds.data_ptr(), dn.data_ptr(), st.cuda_stream)
-    torch.cuda.synchronize(); out["gpu_qps_on_%s_graph" % name] = round(10 * B / (time.perf_counter() - t), 1)
+    for _ in range(3): gi.search_batch(Q, k)
+    ms = []
+    for _ in range(10):
+        gi.search_batch(Q, k); ms.append(gi.last_search_kernel_ms())
+    out["gpu_kernel_ms_on_%s_graph" % name] = round(float(np.mean(ms)), 4)
+    out["gpu_qps_on_%s_graph" % name] = round(B / (float(np.mean(ms)) * 1e-3), 1)
+    save()
 deg = np.diff(g["row_ptr"][0].astype(np.int64)); out["cpu_built_layer0_degree_mean_max"] = [round(float(deg.mean()), 2), int(deg.max())]
-print(json.dumps(out), flush=True)
-json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "c5_compare_%d.json" % N), "w"), indent=1)
+save()
