@@ -39,6 +39,18 @@ def build_library(force=False, extra_flags=()):
     return LIB_PATH
 
 
+PROF_LIB_PATH = os.path.join(LIB_DIR, "libhnsw_mi355x_prof.so")
+
+
+def build_profiling_library():
+    """Development aid: the same library with per-phase cycle counters compiled in
+    (-DHNSW_PHASE_TIMERS); use it with HNSW_MI355X_LIB=<path> scripts/phase_profile.py."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc()] + FLAGS + ["-DHNSW_PHASE_TIMERS", "-o", PROF_LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    subprocess.check_call(cmd, cwd=CSRC)
+    return PROF_LIB_PATH
+
+
 if __name__ == "__main__":
     print(build_library(force=True))
 
