@@ -190,6 +190,21 @@ def test_hnsw_test_reference_kat(eng):
     index.close()
 
 
+def test_reply_name_is_last_dot_segment_and_inputs_are_cast_to_f32(eng):
+    """core.rs:885-887 (result name = last '.'-separated segment of the node key, the module stores
+    "hnsw.{idx}.{node}") and src/lib.rs:345-346,469-470 (f64 arguments are cast with `as f32`)"""
+    index = eng.Index("foo", 4, 5, 16)
+    third = 1.0 / 3.0                                     # not representable in f32
+    index.add_node("hnsw.foo.alpha", np.array([third] * 4, dtype=np.float64))
+    index.add_node("hnsw.foo.beta", np.array([2.0] * 4, dtype=np.float64))
+    res = index.search_knn(np.array([third] * 4, dtype=np.float64), 2)
+    assert [r.name for r in res] == ["alpha", "beta"]
+    assert res[0].sim == 0.0                              # both sides rounded the same way
+    d = np.float32(2.0) - np.float32(third)
+    assert res[1].sim == -float(np.float32(np.float32(np.float32(d * d) + np.float32(d * d)) + np.float32(d * d)) + np.float32(d * d))
+    index.close()
+
+
 def test_errors_match_reference(eng):
     from redis_hnsw_amd import HNSWError
     index = eng.Index("foo", 4, 5, 16)

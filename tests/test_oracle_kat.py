@@ -147,3 +147,32 @@ def test_delete_then_search_skips_the_node(oracle_mod):
     idx.delete(10)
     ids, sims = idx.search(np.full(4, 10.0, np.float32), 4)
     assert 10 not in ids.tolist() and set(ids[:2].tolist()) == {9, 11}
+
+
+# ---- structural quirks of the reference pinned on the oracle --------------
+def test_graph_invariants_of_the_reference_algorithm(oracle_mod):
+    n, dim, m, ef = 3000, 32, 16, 200
+    V = np.random.default_rng(1).random((n, dim), dtype=np.float32)
+    lv = oracle_mod.draw_levels(n, m, 7)
+    idx = oracle_mod.OracleIndex(dim, m, ef)
+    for i in range(n):
+        idx.add(V[i], int(lv[i]))
+        if i in (50, 500, 2999):
+            # quirk 5: a new node links with m (not 2m) at every layer, layer 0 included (core.rs:526)
+            for l in range(min(int(lv[i]), idx.max_layer) + 1):
+                assert len(idx.neighbors(i, l)) <= m
+    g = idx.export()
+    # quirk 7: the graph is symmetric at all times (core.rs:770-772, 793-795, 808-816)
+    for l, (rp, col) in enumerate(zip(g["row_ptr"], g["col"])):
+        rows = [set(col[int(rp[a]):int(rp[a + 1])].tolist()) for a in range(n)]
+        for a in range(n):
+            assert a not in rows[a]
+            for b in rows[a]:
+                assert a in rows[b], "layer %d: %d -> %d has no back link" % (l, a, b)
+    # quirk 6: degrees are NOT bounded by m_max0 = 2m: the shrink of one node adds edges to third
+    # parties without shrinking them (core.rs:790-796); SURVEY measured max 41 / 62 nodes over at this size
+    deg0 = np.diff(g["row_ptr"][0].astype(np.int64))
+    assert deg0.max() > 2 * m and (deg0 > 2 * m).sum() > 10
+    # quirk 12: min(k, ef, reachable) results, nearest first
+    ids, sims = idx.search(V[7], 500)
+    assert len(ids) == ef and np.all(np.diff(sims) <= 0) and ids[0] == 7 and sims[0] == 0
