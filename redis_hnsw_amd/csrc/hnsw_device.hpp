@@ -895,87 +895,108 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
         uint32_t word_next = 0;
         const uint32_t *row_next = row;
 
-        for (uint32_t wbase = 0; wbase <= cnt; wbase += 64) {   // core.rs:646 stored order
-            const uint32_t wi = wbase + lane;
-            if (wbase) word = wi < stride ? row[wi] : 0u;
-            const bool valid = wi >= 1 && wi <= cnt;
+        // one pass = up to 32 fresh neighbours: gather, distances, accept test, then either the choice of
+        // the next candidate (last pass of the expansion; its keys stay pending) or an immediate merge
+        auto do_pass = [&](uint32_t word_, uint64_t fm_, int shift, int pass, bool is_last) {
+            const uint64_t fms = fm_ >> shift;
+            const uint32_t pm = (uint32_t)(fms >> (32 * pass));
+            if (pm == 0) return;
+            constexpr int RB = (T <= 4) ? 4 : (T <= 8 ? 2 : 1);   // rounds of 8 vectors in flight
+            uint64_t key = ~0ull;
+            bool have = false;
+            // Slots without a fresh neighbour re-read the first fresh one (same lines, already in
+            // flight): the four rounds then form one straight-line block the compiler interleaves.
+            const uint32_t safe_id =
+                (uint32_t)__builtin_amdgcn_readlane((int)word_, __ffsll((unsigned long long)fm_) - 1);
+#pragma unroll
+            for (int r0 = 0; r0 < 4; r0 += RB) {
+                uint32_t idr[RB];
+#pragma unroll
+                for (int rr = 0; rr < RB; ++rr) {
+                    const int r = r0 + rr;
+                    const int s = pass * 32 + r * 8 + grp;
+                    const uint32_t got = bperm(word_, (s + shift) & 63);
+                    idr[rr] = ((pm >> (r * 8 + grp)) & 1u) ? got : safe_id;
+                }
+                float dd[RB];
+                dist_rounds<T, RB>(vec4, row4, idr, qr, m.qlds, pp, dd, [&] {
+                    if (r0 == 0 && __ballot(ptake)) {      // deferred scatter, under the loads just issued
+                        nW = merge_apply<R>(w, m.W, nW, ef, pkey, ptake, pup, ppos, lane);
+                        ptake = false;
+                        PH_MARK(ctr, 3);
+                    }
+                });
+#pragma unroll
+                for (int rr = 0; rr < RB; ++rr) {
+                    const int r = r0 + rr;
+                    if (sub == r && ((pm >> (r * 8 + grp)) & 1u)) { key = pack_key(dd[rr], idr[rr]); have = true; }
+                }
+            }
+            PH_MARK(ctr, 2);  // vector gather + distances
+            const uint64_t worst = nW == ef ? w_at<R>(w, ef - 1) : ~0ull;     // core.rs:651
+            const bool take = have && key < worst;                            // core.rs:657
+            if (is_last) {
+                // last merge of this expansion: choose the next candidate now
+                uint64_t rkey = ~0ull;
+                int r2, l2;
+                const bool have_r = first_unexpanded<R>(w, rkey, r2, l2);
+                if (!have_r) rkey = ~0ull;
+                uint64_t bm = __ballot(take && key < rkey);
+                nkey = rkey;
+                while (bm) {
+                    const int j = __ffsll((unsigned long long)bm) - 1;
+                    bm &= bm - 1;
+                    const uint64_t kj = readlane64(key, j);
+                    if (kj < nkey) nkey = kj;
+                }
+                have_next = nkey != ~0ull;
+                if (have_next) {
+                    row_next = row_ptr(g, key_id(nkey), lc);
+                    word_next = (uint32_t)lane < stride ? row_next[lane] : 0u;
+                }
+                next_issued = true;
+                pkey = key;                                                   // merged next expansion
+                ptake = take;
+                PH_MARK(ctr, 4);  // choose next + request its row
+            } else {
+                nW = merge_regs<R>(w, m.W, nW, ef, key, take, lane);          // core.rs:659-664
+                PH_MARK(ctr, 3);  // merge into W
+            }
+        };
+
+        if (cnt <= 32) {
+            // the common case, straight-line: one chunk, one pass (slots come from lanes 1..32)
+            const bool valid = lane >= 1 && (uint32_t)lane <= cnt;
             if (!visited_reserve(vis, lane, &g.hdr->ctr_search[3])) { fail = true; return nW; }
             const bool fresh = visited_insert_wave(vis, valid, word, lane, &g.hdr->ctr_search[3]); // core.rs:648-649
             const uint64_t fm = __ballot(fresh);
             const uint32_t nf = __popcll(fm);
             PH_MARK(ctr, 1);  // visited filter
-            if (nf == 0) continue;
-            vis.count += nf;
-            ctr.n_dist += nf;
-            // Slot s of this chunk is lane s; in the first chunk lane 0 holds the degree, so slots are
-            // taken from lane s+1 to keep 32 neighbours in 4 rounds.
-            const int shift = wbase ? 0 : 1;
-            const uint64_t fms = fm >> shift;
-            const bool last_chunk = wbase + 64 > cnt;
-            for (int pass = 0; pass < 2; ++pass) {
-                const uint32_t pm = (uint32_t)(fms >> (32 * pass));
-                if (pm == 0) continue;
-                constexpr int RB = (T <= 4) ? 4 : (T <= 8 ? 2 : 1);   // rounds of 8 vectors in flight
-                uint64_t key = ~0ull;
-                bool have = false;
-                // Slots without a fresh neighbour re-read the first fresh one (same lines, already in
-                // flight): the four rounds then form one straight-line block the compiler interleaves.
-                const uint32_t safe_id =
-                    (uint32_t)__builtin_amdgcn_readlane((int)word, __ffsll((unsigned long long)fm) - 1);
-#pragma unroll
-                for (int r0 = 0; r0 < 4; r0 += RB) {
-                    uint32_t idr[RB];
-#pragma unroll
-                    for (int rr = 0; rr < RB; ++rr) {
-                        const int r = r0 + rr;
-                        const int s = pass * 32 + r * 8 + grp;
-                        const uint32_t got = bperm(word, (s + shift) & 63);
-                        idr[rr] = ((pm >> (r * 8 + grp)) & 1u) ? got : safe_id;
-                    }
-                    float dd[RB];
-                    dist_rounds<T, RB>(vec4, row4, idr, qr, m.qlds, pp, dd, [&] {
-                        if (r0 == 0 && __ballot(ptake)) {      // deferred scatter, under the loads just issued
-                            nW = merge_apply<R>(w, m.W, nW, ef, pkey, ptake, pup, ppos, lane);
-                            ptake = false;
-                            PH_MARK(ctr, 3);
-                        }
-                    });
-#pragma unroll
-                    for (int rr = 0; rr < RB; ++rr) {
-                        const int r = r0 + rr;
-                        if (sub == r && ((pm >> (r * 8 + grp)) & 1u)) { key = pack_key(dd[rr], idr[rr]); have = true; }
-                    }
-                }
-                PH_MARK(ctr, 2);  // vector gather + distances
-                const uint64_t worst = nW == ef ? w_at<R>(w, ef - 1) : ~0ull;     // core.rs:651
-                const bool take = have && key < worst;                            // core.rs:657
-                if (last_chunk && (pass == 1 || (fms >> 32) == 0)) {
-                    // last merge of this expansion: choose the next candidate now
-                    uint64_t rkey = ~0ull;
-                    int r2, l2;
-                    const bool have_r = first_unexpanded<R>(w, rkey, r2, l2);
-                    if (!have_r) rkey = ~0ull;
-                    uint64_t bm = __ballot(take && key < rkey);
-                    nkey = rkey;
-                    while (bm) {
-                        const int j = __ffsll((unsigned long long)bm) - 1;
-                        bm &= bm - 1;
-                        const uint64_t kj = readlane64(key, j);
-                        if (kj < nkey) nkey = kj;
-                    }
-                    have_next = nkey != ~0ull;
-                    if (have_next) {
-                        row_next = row_ptr(g, key_id(nkey), lc);
-                        word_next = (uint32_t)lane < stride ? row_next[lane] : 0u;
-                    }
-                    next_issued = true;
-                    pkey = key;                                                   // merged next expansion
-                    ptake = take;
-                    PH_MARK(ctr, 4);  // choose next + request its row
-                } else {
-                    nW = merge_regs<R>(w, m.W, nW, ef, key, take, lane);          // core.rs:659-664
-                    PH_MARK(ctr, 3);  // merge into W
-                }
+            if (nf) {
+                vis.count += nf;
+                ctr.n_dist += nf;
+                do_pass(word, fm, 1, 0, true);
+            }
+        } else {
+            for (uint32_t wbase = 0; wbase <= cnt; wbase += 64) {   // core.rs:646 stored order
+                const uint32_t wi = wbase + lane;
+                if (wbase) word = wi < stride ? row[wi] : 0u;
+                const bool valid = wi >= 1 && wi <= cnt;
+                if (!visited_reserve(vis, lane, &g.hdr->ctr_search[3])) { fail = true; return nW; }
+                const bool fresh = visited_insert_wave(vis, valid, word, lane, &g.hdr->ctr_search[3]); // core.rs:648-649
+                const uint64_t fm = __ballot(fresh);
+                const uint32_t nf = __popcll(fm);
+                PH_MARK(ctr, 1);  // visited filter
+                if (nf == 0) continue;
+                vis.count += nf;
+                ctr.n_dist += nf;
+                // Slot s of this chunk is lane s; in the first chunk lane 0 holds the degree, so slots
+                // are taken from lane s+1 to keep 32 neighbours in 4 rounds.
+                const int shift = wbase ? 0 : 1;
+                const bool last_chunk = wbase + 64 > cnt;
+                const bool two = ((fm >> shift) >> 32) != 0;
+                if ((uint32_t)(fm >> shift)) do_pass(word, fm, shift, 0, last_chunk && !two);
+                if (two) do_pass(word, fm, shift, 1, last_chunk);
             }
         }
         if (!next_issued) {
