@@ -714,7 +714,7 @@ __device__ __forceinline__ void merge_rank(const uint64_t (&w)[R], uint64_t nk, 
 template <int R>
 __device__ __forceinline__ uint32_t merge_apply(uint64_t (&w)[R], uint64_t *Wbuf, uint32_t nW, uint32_t cap,
                                                 uint64_t nk, bool take, const uint32_t (&up)[R], uint32_t mypos,
-                                                int lane)
+                                                int lane, uint64_t *worst = nullptr)
 {
     uint32_t total = nW + (uint32_t)__popcll(__ballot(take));
     if (total > cap) total = cap;
@@ -736,18 +736,20 @@ __device__ __forceinline__ uint32_t merge_apply(uint64_t (&w)[R], uint64_t *Wbuf
         const uint32_t i = r * 64 + lane;
         w[r] = i < total ? Wbuf[i] : ~0ull;
     }
+    // the accept threshold of the next expansion (core.rs:651): the cap-th key once the list is full
+    if (worst) *worst = total == cap ? Wbuf[cap - 1] : ~0ull;
     __builtin_amdgcn_wave_barrier();
     return total;
 }
 
 template <int R>
 __device__ __forceinline__ uint32_t merge_regs(uint64_t (&w)[R], uint64_t *Wbuf, uint32_t nW, uint32_t cap,
-                                               uint64_t nk, bool take, int lane)
+                                               uint64_t nk, bool take, int lane, uint64_t *worst = nullptr)
 {
     if (__ballot(take) == 0) return nW;
     uint32_t up[R], mypos;
     merge_rank<R>(w, nk, take, up, mypos, lane);
-    return merge_apply<R>(w, Wbuf, nW, cap, nk, take, up, mypos, lane);
+    return merge_apply<R>(w, Wbuf, nW, cap, nk, take, up, mypos, lane, worst);
 }
 
 // first entry whose expanded bit is clear (slots past nW hold ~0, bit set)
@@ -870,6 +872,8 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
     // expansion's vector loads have been issued, i.e. under their latency
     uint64_t pkey = ~0ull;
     bool ptake = false;
+    // W's ef-th key once it is full (accept threshold, core.rs:651); with ef = 1 the entry point fills it
+    uint64_t worst = ef == 1 ? ckey : ~0ull;
     uint32_t pup[R], ppos = 0;     // its ranks, computed under the row-fetch latency
 #pragma unroll
     for (int r = 0; r < R; ++r) pup[r] = 0;
@@ -921,7 +925,7 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
                 float dd[RB];
                 dist_rounds<T, RB>(vec4, row4, idr, qr, m.qlds, pp, dd, [&] {
                     if (r0 == 0 && __ballot(ptake)) {      // deferred scatter, under the loads just issued
-                        nW = merge_apply<R>(w, m.W, nW, ef, pkey, ptake, pup, ppos, lane);
+                        nW = merge_apply<R>(w, m.W, nW, ef, pkey, ptake, pup, ppos, lane, &worst);
                         ptake = false;
                         PH_MARK(ctr, 3);
                     }
@@ -933,7 +937,6 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
                 }
             }
             PH_MARK(ctr, 2);  // vector gather + distances
-            const uint64_t worst = nW == ef ? w_at<R>(w, ef - 1) : ~0ull;     // core.rs:651
             const bool take = have && key < worst;                            // core.rs:657
             if (is_last) {
                 // last merge of this expansion: choose the next candidate now
@@ -959,7 +962,7 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
                 ptake = take;
                 PH_MARK(ctr, 4);  // choose next + request its row
             } else {
-                nW = merge_regs<R>(w, m.W, nW, ef, key, take, lane);          // core.rs:659-664
+                nW = merge_regs<R>(w, m.W, nW, ef, key, take, lane, &worst);  // core.rs:659-664
                 PH_MARK(ctr, 3);  // merge into W
             }
         };
@@ -1002,7 +1005,7 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
         if (!next_issued) {
             // the last chunk had no unvisited neighbour: nothing is in flight to hide a merge under
             if (__ballot(ptake)) {
-                nW = merge_apply<R>(w, m.W, nW, ef, pkey, ptake, pup, ppos, lane);
+                nW = merge_apply<R>(w, m.W, nW, ef, pkey, ptake, pup, ppos, lane, &worst);
                 ptake = false;
             }
             int r2, l2;
@@ -1028,7 +1031,7 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
         word = word_next;
     }
     // the last expansion's keys were never ranked (the loop ended before that point)
-    if (__ballot(ptake)) nW = merge_regs<R>(w, m.W, nW, ef, pkey, ptake, lane);
+    if (__ballot(ptake)) nW = merge_regs<R>(w, m.W, nW, ef, pkey, ptake, lane, &worst);
     // leave W in LDS for the callers (top-k output, select_neighbors)
 #pragma unroll
     for (int r = 0; r < R; ++r) m.W[r * 64 + lane] = w[r];
