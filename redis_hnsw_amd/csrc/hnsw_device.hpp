@@ -1,14 +1,18 @@
 // hnsw_device.hpp -- device-side building blocks of the MI355X HNSW engine.
 //
-// gfx950 only.  One 64-lane wavefront owns one query (or one insert); all
-// per-query state lives in that wave's LDS slice:
-//   W      sorted (dist, id) keys, the reference's W and C heaps in one array
-//   hash   exact open-addressing visited set (core.rs:614 HashSet), spills
-//          to an HBM table when it fills
-//   fresh  compacted ids of the unvisited neighbours of the current candidate
-//   dsc    their squared distances
+// gfx950 only.  One 64-lane wavefront owns one query (or one insert).  Its state:
+//   W        sorted (dist, id) keys -- the reference's W and C heaps in one list.
+//            search_level_v2 (every dim % 32 == 0) keeps it in registers and uses
+//            LDS only to scatter a merge; search_level_v1 (the reference's scalar
+//            metric order, other dims) keeps it in LDS.
+//   visited  exact hash set in LDS (core.rs:614 HashSet): 16-bit tags behind a
+//            bijective hash, or 32-bit ids above 16 M nodes; moves to an HBM
+//            table if it ever fills.
+//   fresh / dsc / S / aux   LDS scratch of the v1 path and the insert kernels.
 // The vector matrix is row-major f32 [N][dim]; 8 lanes stream one row with
 // 16 B loads (one 128 B line per 8-lane group per load instruction).
+// Everything is force-inlined into the kernels: a real call makes the compiler
+// spill the state structs to scratch and turn LDS accesses into flat ones.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -767,16 +771,6 @@ __device__ __forceinline__ bool first_unexpanded(const uint64_t (&w)[R], uint64_
         }
     }
     return false;
-}
-
-template <int R>
-__device__ __forceinline__ uint64_t w_at(const uint64_t (&w)[R], uint32_t idx)
-{
-    uint64_t v = ~0ull;
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-        if ((idx >> 6) == (uint32_t)r) v = readlane64(w[r], idx & 63);
-    return v;
 }
 
 // Squared distances from the query to NR vectors (ids idr[]), AVX2 summation order, for the 8-lane
