@@ -19,6 +19,9 @@
  *  - Every function returns an hnsw_status; hnsw_last_error() gives the text.
  *  - There is no CPU fallback: without a usable gfx950 device hnsw_create
  *    fails with HNSW_ERR_DEVICE.
+ *  - Vector components must be finite: the host entry points return
+ *    HNSW_ERR_INVALID otherwise (the reference's OrderedFloat NaN order,
+ *    core.rs:4,241, is not reproduced); the _device entry point does not check.
  */
 #ifndef HNSW_MI355X_H
 #define HNSW_MI355X_H
@@ -127,6 +130,15 @@ hnsw_status hnsw_get_neighbors(hnsw_index *h, uint32_t id, uint32_t layer,
 hnsw_status hnsw_layer_nnz(hnsw_index *h, uint32_t layer, uint64_t *nnz);
 hnsw_status hnsw_export_layer(hnsw_index *h, uint32_t layer, uint64_t *row_ptr /*[n+1]*/,
                               uint32_t *col);
+
+/* Snapshot of the whole index (parameters, level generator state, vectors, levels, tombstones,
+ * per-layer adjacency in stored order) as one byte string: what the module's RDB callbacks
+ * (save_index / load_index, src/types.rs:176-284) stream instead of per-node keys.  A restored
+ * index continues exactly where the saved one was (same graph, same future level draws).       */
+hnsw_status hnsw_serialize_size(hnsw_index *h, uint64_t *bytes);
+hnsw_status hnsw_serialize(hnsw_index *h, void *buf, uint64_t cap, uint64_t *written);
+hnsw_status hnsw_deserialize(const void *buf, uint64_t bytes, uint64_t seed, int device,
+                             hnsw_index **out);
 
 /* Engine knobs (not part of the reference surface): "lds_buckets" (32-byte
  * buckets of the per-query LDS visited table), "grid" (cap on resident query waves), "tag_table" (16-bit tag visited table on/off), "tag_bb" (force its log2 size),

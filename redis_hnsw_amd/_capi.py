@@ -45,6 +45,9 @@ SIGNATURES = {
     "hnsw_get_neighbors": (C.c_int, [H, C.c_uint32, C.c_uint32, u32p, C.c_uint32, u32p]),
     "hnsw_layer_nnz": (C.c_int, [H, C.c_uint32, u64p]),
     "hnsw_export_layer": (C.c_int, [H, C.c_uint32, u64p, u32p]),
+    "hnsw_serialize_size": (C.c_int, [H, u64p]),
+    "hnsw_serialize": (C.c_int, [H, C.c_void_p, C.c_uint64, u64p]),
+    "hnsw_deserialize": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(H)]),
     "hnsw_set_tuning": (C.c_int, [H, C.c_char_p, C.c_int64]),
     "hnsw_get_counters": (C.c_int, [H, C.POINTER(Counters), C.POINTER(Counters)]),
     "hnsw_reset_counters": (C.c_int, [H]),

@@ -83,6 +83,16 @@ hnsw_status fail(hnsw_index *h, hnsw_status s, const std::string &msg)
 }
 
 uint32_t round_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
+
+// The reference orders similarities with OrderedFloat (NaN sorts as the nearest, core.rs:4,241); the
+// engine's keys are IEEE bit patterns of finite distances, so non-finite components are refused at the
+// host entry points instead of producing a different order.
+bool all_finite(const float *v, size_t n)
+{
+    for (size_t i = 0; i < n; ++i)
+        if (!std::isfinite(v[i])) return false;
+    return true;
+}
 uint32_t ceil_log2(uint64_t x)
 {
     uint32_t b = 0;
@@ -580,6 +590,7 @@ hnsw_status hnsw_add(hnsw_index *h, const float *v, uint32_t dim, int32_t level,
         snprintf(buf, sizeof buf, "data dimension: %u does not match Index", dim);
         return fail(h, HNSW_ERR_DIM_MISMATCH, buf);
     }
+    if (!all_finite(v, dim)) return fail(h, HNSW_ERR_INVALID, "non-finite vector component");
     HIP_TRY(h, hipSetDevice(h->device));
     uint32_t nt = 0;
     hnsw_status s = add_exact(h, v, nullptr, level, out_id, touched != nullptr, &nt);
@@ -610,6 +621,7 @@ hnsw_status hnsw_add_batch(hnsw_index *h, const float *V, uint32_t n, uint32_t d
     }
     if (n == 0) return HNSW_OK;
     if (mode > 1) return fail(h, HNSW_ERR_INVALID, "mode must be 0 (exact) or 1 (fast)");
+    if (!all_finite(V, (size_t)n * dim)) return fail(h, HNSW_ERR_INVALID, "non-finite vector component");
     HIP_TRY(h, hipSetDevice(h->device));
     hnsw_status s;
     uint32_t done = 0;
@@ -746,6 +758,7 @@ hnsw_status hnsw_search_batch(hnsw_index *h, const float *Q, uint32_t B, uint32_
     }
     if (B == 0) return HNSW_OK;
     if (k == 0) return fail(h, HNSW_ERR_INVALID, "k must be >= 1");
+    if (!all_finite(Q, (size_t)B * dim)) return fail(h, HNSW_ERR_INVALID, "non-finite query component");
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->n == h->n_dead || h->enterpoint < 0) {
         for (uint32_t b = 0; b < B; ++b) n_out[b] = 0;
@@ -959,6 +972,111 @@ hnsw_status hnsw_export_layer(hnsw_index *h, uint32_t layer, uint64_t *row_ptr, 
     (void)hipFree(d_rp);
     (void)hipFree(d_col);
     return HNSW_OK;
+}
+
+// ---- snapshot (what the RDB save/load callbacks of src/types.rs:176-284 would stream) -----------
+namespace {
+constexpr char kSnapMagic[8] = {'H', 'N', 'S', 'W', 'M', 'I', '3', '5'};
+struct SnapHeader {
+    char magic[8];
+    uint32_t version, dim, m, efc, n, n_dead, max_layer, n_layers;
+    int64_t enterpoint;
+    uint64_t rng[4];
+};
+inline uint64_t pad8(uint64_t b) { return (b + 7) & ~7ull; }   // every section starts 8-byte aligned
+}
+
+hnsw_status hnsw_serialize_size(hnsw_index *h, uint64_t *bytes)
+{
+    if (!h || !bytes) return HNSW_ERR_INVALID;
+    uint64_t total = sizeof(SnapHeader) + pad8((uint64_t)h->n * 4) + pad8(h->n) + pad8((uint64_t)h->n * h->dim * 4);
+    const uint32_t n_layers = h->n ? h->max_layer + 1 : 0;
+    for (uint32_t l = 0; l < n_layers; ++l) {
+        uint64_t nnz = 0;
+        hnsw_status s = hnsw_layer_nnz(h, l, &nnz);
+        if (s != HNSW_OK) return s;
+        total += 8 + ((uint64_t)h->n + 1) * 8 + pad8(nnz * 4);
+    }
+    *bytes = total;
+    return HNSW_OK;
+}
+
+hnsw_status hnsw_serialize(hnsw_index *h, void *buf, uint64_t cap, uint64_t *written)
+{
+    if (!h || !buf || !written) return HNSW_ERR_INVALID;
+    uint64_t need = 0;
+    hnsw_status s = hnsw_serialize_size(h, &need);
+    if (s != HNSW_OK) return s;
+    if (cap < need) return fail(h, HNSW_ERR_INVALID, "snapshot buffer too small");
+    HIP_TRY(h, hipSetDevice(h->device));
+    unsigned char *p = static_cast<unsigned char *>(buf);
+    SnapHeader hd;
+    std::memset(&hd, 0, sizeof hd);
+    std::memcpy(hd.magic, kSnapMagic, 8);
+    hd.version = 1; hd.dim = h->dim; hd.m = h->m; hd.efc = h->efc; hd.n = h->n; hd.n_dead = h->n_dead;
+    hd.max_layer = h->max_layer; hd.n_layers = h->n ? h->max_layer + 1 : 0; hd.enterpoint = h->enterpoint;
+    std::memcpy(hd.rng, h->rng, sizeof hd.rng);
+    std::memcpy(p, &hd, sizeof hd); p += sizeof hd;
+    std::memset(p, 0, need - sizeof hd);
+    if (h->n) std::memcpy(p, h->h_levels.data(), (size_t)h->n * 4);
+    p += pad8((uint64_t)h->n * 4);
+    if (h->n) std::memcpy(p, h->h_dead.data(), h->n);
+    p += pad8(h->n);
+    if (h->n) {
+        HIP_TRY(h, hipMemcpyAsync(p, h->d_vec, (size_t)h->n * h->dim * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    p += pad8((uint64_t)h->n * h->dim * 4);
+    for (uint32_t l = 0; l < hd.n_layers; ++l) {
+        uint64_t nnz = 0;
+        if ((s = hnsw_layer_nnz(h, l, &nnz)) != HNSW_OK) return s;
+        std::memcpy(p, &nnz, 8); p += 8;
+        uint64_t *rp = reinterpret_cast<uint64_t *>(p); p += ((size_t)h->n + 1) * 8;
+        uint32_t *cl = reinterpret_cast<uint32_t *>(p); p += pad8(nnz * 4);
+        if ((s = hnsw_export_layer(h, l, rp, cl)) != HNSW_OK) return s;
+    }
+    *written = (uint64_t)(p - static_cast<unsigned char *>(buf));
+    return HNSW_OK;
+}
+
+hnsw_status hnsw_deserialize(const void *buf, uint64_t bytes, uint64_t seed, int device, hnsw_index **out)
+{
+    if (!buf || !out || bytes < sizeof(SnapHeader)) return HNSW_ERR_INVALID;
+    const unsigned char *p = static_cast<const unsigned char *>(buf), *end = p + bytes;
+    SnapHeader hd;
+    std::memcpy(&hd, p, sizeof hd); p += sizeof hd;
+    if (std::memcmp(hd.magic, kSnapMagic, 8) != 0 || hd.version != 1) { *out = nullptr; return HNSW_ERR_INVALID; }
+    hnsw_status s = hnsw_create(hd.dim, hd.m, hd.efc, seed, device, out);
+    if (s != HNSW_OK) return s;
+    hnsw_index *h = *out;
+    std::memcpy(h->rng, hd.rng, sizeof hd.rng);
+    if (hd.n == 0) return HNSW_OK;
+    if ((uint64_t)(end - p) < pad8((uint64_t)hd.n * 4) + pad8(hd.n) + pad8((uint64_t)hd.n * hd.dim * 4)) return fail(h, HNSW_ERR_INVALID, "truncated snapshot");
+    const uint32_t *levels = reinterpret_cast<const uint32_t *>(p); p += pad8((uint64_t)hd.n * 4);
+    const unsigned char *dead = p; p += pad8(hd.n);
+    const float *vectors = reinterpret_cast<const float *>(p); p += pad8((uint64_t)hd.n * hd.dim * 4);
+    std::vector<const uint64_t *> rps(hd.n_layers);
+    std::vector<const uint32_t *> cols(hd.n_layers);
+    for (uint32_t l = 0; l < hd.n_layers; ++l) {
+        if ((uint64_t)(end - p) < 8 + ((uint64_t)hd.n + 1) * 8) return fail(h, HNSW_ERR_INVALID, "truncated snapshot");
+        uint64_t nnz;
+        std::memcpy(&nnz, p, 8); p += 8;
+        rps[l] = reinterpret_cast<const uint64_t *>(p); p += ((size_t)hd.n + 1) * 8;
+        if ((uint64_t)(end - p) < pad8(nnz * 4)) return fail(h, HNSW_ERR_INVALID, "truncated snapshot");
+        cols[l] = reinterpret_cast<const uint32_t *>(p); p += pad8(nnz * 4);
+    }
+    // an index whose every node was deleted has no enterpoint: import a placeholder, then fix up
+    int64_t ep = hd.enterpoint;
+    if (ep < 0) {
+        ep = 0;
+    }
+    // hnsw_import derives max_layer from the enterpoint's level; a deleted enterpoint cannot occur
+    if ((s = hnsw_import(h, hd.n, vectors, levels, ep, hd.n_layers ? hd.n_layers : 1, rps.data(), cols.data())) != HNSW_OK) return s;
+    h->h_dead.assign(dead, dead + hd.n);
+    h->n_dead = hd.n_dead;
+    h->enterpoint = hd.enterpoint;
+    h->max_layer = hd.max_layer;
+    return push_header(h);
 }
 
 hnsw_status hnsw_get_counters(hnsw_index *h, hnsw_counters *search, hnsw_counters *insert)

@@ -237,6 +237,43 @@ class Index:
             g["vectors"] = V
         return g
 
+    # -- snapshot (the module's RDB save/load, src/types.rs:176-284) --------------------------
+    def serialize(self):
+        """bytes: engine snapshot followed by the host-side name table (JSON)"""
+        import json
+        nbytes = C.c_uint64(0)
+        self._check(self._lib.hnsw_serialize_size(self._h, C.byref(nbytes)))
+        buf = (C.c_ubyte * max(int(nbytes.value), 1))()
+        wrote = C.c_uint64(0)
+        self._check(self._lib.hnsw_serialize(self._h, buf, nbytes.value, C.byref(wrote)))
+        names = json.dumps(dict(name=self.name, names=self._names)).encode()
+        return int(wrote.value).to_bytes(8, "little") + bytes(buf)[: wrote.value] + names
+
+    @classmethod
+    def deserialize(cls, blob, seed=0, device=0):
+        import json
+        n = int.from_bytes(blob[:8], "little")
+        snap, meta = blob[8:8 + n], json.loads(blob[8 + n:].decode())
+        lib = _capi.load()
+        h = _capi.H()
+        cbuf = (C.c_ubyte * max(n, 1)).from_buffer_copy(snap if n else b"\0")
+        st = lib.hnsw_deserialize(cbuf, n, seed, device, C.byref(h))
+        if st != _capi.OK:
+            msg = lib.hnsw_last_error(h).decode() if h else "bad snapshot"
+            if h:
+                lib.hnsw_destroy(h)
+            raise HNSWError(msg, st)
+        self = cls.__new__(cls)
+        self._lib, self._h, self.name = lib, h, meta["name"]
+        i = _capi.Info()
+        lib.hnsw_get_info(h, C.byref(i))
+        self.data_dim, self.m, self.m_max, self.m_max_0 = int(i.dim), int(i.m), int(i.m_max), int(i.m_max0)
+        self.ef_construction = int(i.ef_construction)
+        self.level_mult = 1.0 / np.log(float(self.m))
+        self._names = meta["names"]
+        self._ids = {nm: j for j, nm in enumerate(self._names) if nm is not None}
+        return self
+
     def neighbors(self, i, layer):
         inf = self.info()
         cap = int(max(inf.stride0, inf.stride_upper))

@@ -221,6 +221,12 @@ def test_errors_match_reference(eng):
     assert e.value.error_string() == 'String("data dimension: 5 does not match Index")'   # core.rs:479
     # k larger than the index: min(k, ef, reachable) results (core.rs:878-890)
     assert len(index.search_knn(np.zeros(4, np.float32), 10)) == 2
+    # non-finite components are refused (documented limit: the reference's NaN ordering is not reproduced)
+    with pytest.raises(HNSWError):
+        index.add_node("c", np.array([0, np.nan, 0, 0], np.float32))
+    with pytest.raises(HNSWError):
+        index.search_knn(np.array([0, np.inf, 0, 0], np.float32), 1)
+    assert index.node_count == 2
     index.close()
 
 
@@ -594,3 +600,32 @@ def test_full_size_c2_properties_and_sampled_parity(eng, oracle_mod):
     sc, _ = gi.counters()
     assert (sc.n_dist, sc.n_ids, sc.n_expand) == (oct.n_dist, oct.n_ids, oct.n_expand)
     gi.close()
+
+
+# ---- snapshot / restore -------------------------------------------------------------------
+def test_snapshot_round_trip_continues_identically(eng, oracle_mod):
+    n, dim, m, ef = 400, 32, 6, 32
+    V = make_data(n + 80, dim, seed=101)
+    a = eng.Index("snap", dim, m, ef, seed=9)
+    for i in range(n):
+        a.add_node("hnsw.snap.n%d" % i, V[i])              # levels drawn by the engine's generator
+    for i in (3, 77, a.enterpoint_id, 250):
+        a.delete_node("hnsw.snap.n%d" % i)
+    blob = a.serialize()
+    b = eng.Index.deserialize(blob)
+    assert (b.name, b.data_dim, b.m, b.ef_construction, b.node_count) == ("snap", dim, m, ef, a.node_count)
+    assert b.enterpoint == a.enterpoint and b.max_layer == a.max_layer
+    ok, why = graphs_equal(a.export_graph(), b.export_graph())
+    assert ok, why
+    Q = make_data(32, dim, seed=2)
+    ia, sa, na = a.search_batch(Q, 5)
+    ib, sb, nb = b.search_batch(Q, 5)
+    assert np.array_equal(ia, ib) and np.array_equal(_bits(sa), _bits(sb)) and np.array_equal(na, nb)
+    assert [r.name for r in a.search_knn(Q[0], 3)] == [r.name for r in b.search_knn(Q[0], 3)]
+    # both continue with the same level draws and end with the same graph
+    for i in range(n, n + 80):
+        a.add_node("hnsw.snap.n%d" % i, V[i])
+        b.add_node("hnsw.snap.n%d" % i, V[i])
+    ok, why = graphs_equal(a.export_graph(), b.export_graph())
+    assert ok, why
+    a.close(); b.close()
