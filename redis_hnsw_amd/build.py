@@ -12,7 +12,7 @@ DEPS = ["hnsw_engine.hip", "hnsw_device.hpp", "hnsw_kernels.hpp", "hnsw_insert.h
         os.path.join("..", "..", "include", "hnsw_mi355x.h")]
 # -ffp-contract=off: the metric must round exactly where the reference's does
 # (explicit fma only, metrics.rs:57); never -ffast-math.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+FLAGS = ["--offload-arch=gfx950", "-Os", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function"]
 
 
@@ -27,6 +27,8 @@ def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
+    if os.path.getmtime(os.path.abspath(__file__)) > t:  # the flags live here
+        return True
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 

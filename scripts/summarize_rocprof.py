@@ -11,8 +11,8 @@ import sys
 def stats(db):
     cur = sqlite3.connect(db).cursor()
     rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
-    print("# rocprofv3 --kernel-trace --stats  (durations in ns)")
-    print("%-64s %8s %14s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
+    print("# rocprofv3 --kernel-trace --stats  (durations in us, as the rocpd top_kernels view reports them)")
+    print("%-64s %8s %14s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
     for name, calls, tot, avg, pct in rows[:25]:
         short = name.split("(")[0].replace("void ", "")
         print("%-64s %8d %14.0f %12.1f %6.2f%%" % (short[:64], calls, tot * 1.0, avg * 1.0, pct))
