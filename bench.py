@@ -216,7 +216,7 @@ def main():
     # ---- informational: the same configuration on clustered data, where the reference algorithm's
     # recall is high enough for recall parity to mean something (uniform 128-d: 0.27 at 1 M)
     clus = None
-    if cfg_is_c2 and not args.no_clustered:
+    if cfg_is_c2 and not args.no_clustered and world == 1:
         centers = np.random.default_rng(3).random((64, dim), dtype=np.float32)
         Vc = clustered(N, dim, 3, centers)
         Qc = torch.from_numpy(clustered(B, dim, 4, centers)).to(dev)
@@ -271,7 +271,7 @@ def main():
 
     # ---- CPU baseline: the oracle (C restatement of the Rust path), bounded sample -------
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:   # timed at N=1 only: the other ranks would idle in the barrier
         from oracle import oracle
         graph["vectors"] = V
         o = oracle.OracleIndex.from_graph(dim, M, ef, graph)

@@ -100,12 +100,8 @@ constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7-i inside each 8
 //   piece ^ 2 = quad xor 2, piece ^ 4 = half mirror, piece ^ 1 = quad xor 1.
 __device__ __forceinline__ int piece_of_lane(int lane)
 {
-    int i = lane & 7;
-#ifdef HNSW_NO_DPP
-    return i;
-#else
+    const int i = lane & 7;
     return i < 4 ? i : 11 - i;
-#endif
 }
 
 template <int T>
@@ -140,23 +136,12 @@ __device__ __forceinline__ float4 avx_accumulate(const float4 (&q)[T], const flo
 // (s0+s1)+(s2+s3) (:27-31).  Every lane of the group ends with the result.
 __device__ __forceinline__ float avx_reduce(float4 a)
 {
-#ifdef HNSW_NO_DPP
-#define HNSW_X(v, m) __shfl_xor((v), (m))
-    a.x = __fadd_rn(a.x, HNSW_X(a.x, 2)); a.y = __fadd_rn(a.y, HNSW_X(a.y, 2));
-    a.z = __fadd_rn(a.z, HNSW_X(a.z, 2)); a.w = __fadd_rn(a.w, HNSW_X(a.w, 2));
-    a.x = __fadd_rn(a.x, HNSW_X(a.x, 4)); a.y = __fadd_rn(a.y, HNSW_X(a.y, 4));
-    a.z = __fadd_rn(a.z, HNSW_X(a.z, 4)); a.w = __fadd_rn(a.w, HNSW_X(a.w, 4));
-    a.x = __fadd_rn(a.x, HNSW_X(a.x, 1)); a.y = __fadd_rn(a.y, HNSW_X(a.y, 1));
-    a.z = __fadd_rn(a.z, HNSW_X(a.z, 1)); a.w = __fadd_rn(a.w, HNSW_X(a.w, 1));
-#undef HNSW_X
-#else
     a.x = __fadd_rn(a.x, dpp_mov<DPP_QUAD_XOR2>(a.x)); a.y = __fadd_rn(a.y, dpp_mov<DPP_QUAD_XOR2>(a.y));
     a.z = __fadd_rn(a.z, dpp_mov<DPP_QUAD_XOR2>(a.z)); a.w = __fadd_rn(a.w, dpp_mov<DPP_QUAD_XOR2>(a.w));
     a.x = __fadd_rn(a.x, dpp_mov<DPP_HALF_MIRROR>(a.x)); a.y = __fadd_rn(a.y, dpp_mov<DPP_HALF_MIRROR>(a.y));
     a.z = __fadd_rn(a.z, dpp_mov<DPP_HALF_MIRROR>(a.z)); a.w = __fadd_rn(a.w, dpp_mov<DPP_HALF_MIRROR>(a.w));
     a.x = __fadd_rn(a.x, dpp_mov<DPP_QUAD_XOR1>(a.x)); a.y = __fadd_rn(a.y, dpp_mov<DPP_QUAD_XOR1>(a.y));
     a.z = __fadd_rn(a.z, dpp_mov<DPP_QUAD_XOR1>(a.z)); a.w = __fadd_rn(a.w, dpp_mov<DPP_QUAD_XOR1>(a.w));
-#endif
     return __fadd_rn(__fadd_rn(a.x, a.y), __fadd_rn(a.z, a.w));
 }
 
@@ -876,8 +861,6 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
 
     for (;;) {
         // ckey is the candidate being expanded (already marked), `word` its adjacency row (core.rs:631-645)
-        const uint32_t c = key_id(ckey);
-        (void)c;
         ctr.n_expand += 1;
         uint32_t cnt = __builtin_amdgcn_readfirstlane(word);
         if (cnt > stride - 1) cnt = stride - 1;
@@ -892,6 +875,33 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
         uint64_t nkey = ~0ull;
         uint32_t word_next = 0;
         const uint32_t *row_next = row;
+
+        // last keys of an expansion: choose the next candidate now, request its row; the keys stay
+        // pending and are merged under the latencies that follow
+        auto choose_next = [&](uint64_t key, bool take) {
+            // last merge of this expansion: choose the next candidate now
+            uint64_t rkey = ~0ull;
+            int r2, l2;
+            const bool have_r = first_unexpanded<R>(w, rkey, r2, l2);
+            if (!have_r) rkey = ~0ull;
+            uint64_t bm = __ballot(take && key < rkey);
+            nkey = rkey;
+            while (bm) {
+                const int j = __ffsll((unsigned long long)bm) - 1;
+                bm &= bm - 1;
+                const uint64_t kj = readlane64(key, j);
+                if (kj < nkey) nkey = kj;
+            }
+            have_next = nkey != ~0ull;
+            if (have_next) {
+                row_next = row_ptr(g, key_id(nkey), lc);
+                word_next = (uint32_t)lane < stride ? row_next[lane] : 0u;
+            }
+            next_issued = true;
+            pkey = key;                                                   // merged next expansion
+            ptake = take;
+            PH_MARK(ctr, 4);  // choose next + request its row
+        };
 
         // one pass = up to 32 fresh neighbours: gather, distances, accept test, then either the choice of
         // the next candidate (last pass of the expansion; its keys stay pending) or an immediate merge
@@ -933,28 +943,7 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
             PH_MARK(ctr, 2);  // vector gather + distances
             const bool take = have && key < worst;                            // core.rs:657
             if (is_last) {
-                // last merge of this expansion: choose the next candidate now
-                uint64_t rkey = ~0ull;
-                int r2, l2;
-                const bool have_r = first_unexpanded<R>(w, rkey, r2, l2);
-                if (!have_r) rkey = ~0ull;
-                uint64_t bm = __ballot(take && key < rkey);
-                nkey = rkey;
-                while (bm) {
-                    const int j = __ffsll((unsigned long long)bm) - 1;
-                    bm &= bm - 1;
-                    const uint64_t kj = readlane64(key, j);
-                    if (kj < nkey) nkey = kj;
-                }
-                have_next = nkey != ~0ull;
-                if (have_next) {
-                    row_next = row_ptr(g, key_id(nkey), lc);
-                    word_next = (uint32_t)lane < stride ? row_next[lane] : 0u;
-                }
-                next_issued = true;
-                pkey = key;                                                   // merged next expansion
-                ptake = take;
-                PH_MARK(ctr, 4);  // choose next + request its row
+                choose_next(key, take);
             } else {
                 nW = merge_regs<R>(w, m.W, nW, ef, key, take, lane, &worst);  // core.rs:659-664
                 PH_MARK(ctr, 3);  // merge into W
@@ -962,17 +951,54 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
         };
 
         if (cnt <= 32) {
-            // the common case, straight-line: one chunk, one pass (slots come from lanes 1..32)
-            const bool valid = lane >= 1 && (uint32_t)lane <= cnt;
+            // The common case, straight-line: one chunk, one pass (slots come from lanes 1..32).  The
+            // vectors of ALL its neighbours are requested the moment the row is here; the visited
+            // filter (core.rs:648-649) and the deferred merge run under that latency, and the filter's
+            // answer only masks the keys afterwards.  A distance is a pure function of (query, vector),
+            // so the result is unchanged; the price is the vectors of already-visited neighbours
+            // (n_ids - n_dist, a few per cent of the traffic).
             if (!visited_reserve(vis, lane, &g.hdr->ctr_search[3])) { fail = true; return nW; }
-            const bool fresh = visited_insert_wave(vis, valid, word, lane, &g.hdr->ctr_search[3]); // core.rs:648-649
-            const uint64_t fm = __ballot(fresh);
-            const uint32_t nf = __popcll(fm);
-            PH_MARK(ctr, 1);  // visited filter
-            if (nf) {
+            if (cnt) {
+                const bool valid = lane >= 1 && (uint32_t)lane <= cnt;
+                const uint32_t pm = cnt >= 32 ? 0xFFFFFFFFu : ((1u << cnt) - 1u);
+                constexpr int RB = (T <= 4) ? 4 : (T <= 8 ? 2 : 1);   // rounds of 8 vectors in flight
+                const uint32_t safe_id = (uint32_t)__builtin_amdgcn_readlane((int)word, 1);
+                uint64_t key = ~0ull, fm = 0;
+                bool have = false;
+#pragma unroll
+                for (int r0 = 0; r0 < 4; r0 += RB) {
+                    uint32_t idr[RB];
+#pragma unroll
+                    for (int rr = 0; rr < RB; ++rr) {
+                        const int s = (r0 + rr) * 8 + grp;
+                        const uint32_t got = bperm(word, s + 1);
+                        idr[rr] = ((pm >> s) & 1u) ? got : safe_id;
+                    }
+                    float dd[RB];
+                    dist_rounds<T, RB>(vec4, row4, idr, qr, m.qlds, pp, dd, [&] {
+                        if (r0 == 0) {
+                            fm = __ballot(visited_insert_wave(vis, valid, word, lane, &g.hdr->ctr_search[3]));
+                            PH_MARK(ctr, 1);  // visited filter
+                            if (__ballot(ptake)) {      // deferred scatter of the previous expansion's keys
+                                nW = merge_apply<R>(w, m.W, nW, ef, pkey, ptake, pup, ppos, lane, &worst);
+                                ptake = false;
+                                PH_MARK(ctr, 3);
+                            }
+                        }
+                    });
+#pragma unroll
+                    for (int rr = 0; rr < RB; ++rr) {
+                        const int r = r0 + rr;
+                        if (sub == r && ((pm >> (r * 8 + grp)) & 1u)) { key = pack_key(dd[rr], idr[rr]); have = true; }
+                    }
+                }
+                PH_MARK(ctr, 2);  // vector gather + distances
+                const uint32_t nf = __popcll(fm);
                 vis.count += nf;
-                ctr.n_dist += nf;
-                do_pass(word, fm, 1, 0, true);
+                ctr.n_dist += nf;                      // the reference evaluates the fresh ones (core.rs:652)
+                const bool fresh_mine = (fm >> ((sub & 3) * 8 + grp + 1)) & 1ull;
+                const bool take = have && fresh_mine && key < worst;              // core.rs:657
+                choose_next(key, take);
             }
         } else {
             for (uint32_t wbase = 0; wbase <= cnt; wbase += 64) {   // core.rs:646 stored order
@@ -1038,11 +1064,8 @@ __device__ __forceinline__ uint32_t search_level(const GraphView &g, const WaveM
                                                  const QReg<T> &qr, uint32_t ep, uint32_t ef, uint32_t lc,
                                                  WorkCtr &ctr, int lane, bool &fail)
 {
-#ifndef HNSW_SEARCH_V1
     if constexpr (MODE == MODE_AVX) return search_level_v2<MODE, T, R>(g, m, vis, qr, ep, ef, lc, ctr, lane, fail);
-    else
-#endif
-        return search_level_v1<MODE, T, R>(g, m, vis, qr, ep, ef, lc, ctr, lane, fail);
+    else return search_level_v1<MODE, T, R>(g, m, vis, qr, ep, ef, lc, ctr, lane, fail);
 }
 
 } // namespace hnsw

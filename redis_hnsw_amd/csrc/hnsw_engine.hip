@@ -1127,11 +1127,14 @@ hnsw_status hnsw_metric_pairs(int device, const float *a, const float *b, uint32
     if (hipSetDevice(device) != hipSuccess) return HNSW_ERR_DEVICE;
     float *da = nullptr, *db = nullptr, *ds = nullptr;
     size_t bytes = (size_t)n * dim * 4;
+    auto release = [&] { (void)hipFree(da); (void)hipFree(db); (void)hipFree(ds); };
     if (hipMalloc((void **)&da, bytes) != hipSuccess || hipMalloc((void **)&db, bytes) != hipSuccess ||
-        hipMalloc((void **)&ds, (size_t)n * 4) != hipSuccess)
+        hipMalloc((void **)&ds, (size_t)n * 4) != hipSuccess ||
+        hipMemcpy(da, a, bytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(db, b, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        release();
         return HNSW_ERR_DEVICE;
-    (void)hipMemcpy(da, a, bytes, hipMemcpyHostToDevice);
-    (void)hipMemcpy(db, b, bytes, hipMemcpyHostToDevice);
+    }
     uint32_t grid = std::min(n, 1024u);
     if (dim % 32 == 0 && (dim == 128 || dim == 768)) {
         // the register-resident kernels the search uses for these dims
@@ -1145,9 +1148,10 @@ hnsw_status hnsw_metric_pairs(int device, const float *a, const float *b, uint32
         else
             hipLaunchKernelGGL(k_metric_pairs<MODE_SCALAR>, dim3(grid), dim3(64), lds, 0, da, db, n, dim, ds);
     }
-    hipError_t e = hipDeviceSynchronize();
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(sims, ds, (size_t)n * 4, hipMemcpyDeviceToHost);
-    (void)hipFree(da); (void)hipFree(db); (void)hipFree(ds);
+    release();
     return e == hipSuccess ? HNSW_OK : HNSW_ERR_DEVICE;
 }
 
