@@ -680,24 +680,28 @@ template <int R>
 __device__ __forceinline__ void merge_rank(const uint64_t (&w)[R], uint64_t nk, bool take, uint32_t (&up)[R],
                                            uint32_t &mypos, int lane)
 {
+    uint32_t stay[R];                              // new keys ABOVE each old entry (it does not move for those)
 #pragma unroll
-    for (int r = 0; r < R; ++r) up[r] = 0;
+    for (int r = 0; r < R; ++r) stay[r] = 0;
     mypos = 0;
-    uint64_t mm = __ballot(take);
+    const uint64_t mm0 = __ballot(take);
+    uint64_t mm = mm0;
     while (mm) {
         const int j = __ffsll((unsigned long long)mm) - 1;
         mm &= mm - 1;
         const uint64_t s = readlane64(nk, j);
-        uint32_t rank = 0;
+        uint32_t rank = (uint32_t)__popcll(__ballot(nk < s) & mm0);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const bool below = w[r] < s;          // slots past the end hold ~0: never below
             rank += __popcll(__ballot(below));
-            up[r] += below ? 0u : 1u;
+            stay[r] += below ? 1u : 0u;
         }
-        rank += __popcll(__ballot(take && nk < s));
-        if (lane == j) mypos = rank;
+        mypos = lane == j ? rank : mypos;
     }
+    const uint32_t n = (uint32_t)__popcll(mm0);
+#pragma unroll
+    for (int r = 0; r < R; ++r) up[r] = n - stay[r];
 }
 
 template <int R>
