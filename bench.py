@@ -314,7 +314,7 @@ def main():
                                % (cfg_name, N, dim, M, ef, k, B),
                    "nodes": N, "dim": dim, "M": M, "ef": ef, "k": k, "batch": B, "build": args.build,
                    "parallelism": "replica x%d, query batch sharded" % world},
-        "recall_at_10": None if recall is None else round(recall, 4),
+        "recall_at_%d" % k: None if recall is None else round(recall, 4),
         "build_seconds": None if t_build is None else round(t_build, 2),
         "host_buffers_qps": round(host_qps, 1),
         "clustered": clus,
