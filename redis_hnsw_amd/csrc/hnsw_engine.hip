@@ -176,10 +176,17 @@ hnsw_status ensure_node_cap(hnsw_index *h, uint32_t need)
     float *nvec = nullptr;
     uint32_t *nadj0 = nullptr, *nub = nullptr, *nlv = nullptr;
     hnsw_status s;
-    if ((s = dev_alloc(h, &nvec, (size_t)ncap * h->dim)) != HNSW_OK) return s;
-    if ((s = dev_alloc(h, &nadj0, (size_t)ncap * h->stride0, 0)) != HNSW_OK) return s;
-    if ((s = dev_alloc(h, &nub, (size_t)ncap, 0xFF)) != HNSW_OK) return s;
-    if ((s = dev_alloc(h, &nlv, (size_t)ncap, 0)) != HNSW_OK) return s;
+    if ((s = dev_alloc(h, &nvec, (size_t)ncap * h->dim)) != HNSW_OK ||
+        (s = dev_alloc(h, &nadj0, (size_t)ncap * h->stride0, 0)) != HNSW_OK ||
+        (s = dev_alloc(h, &nub, (size_t)ncap, 0xFF)) != HNSW_OK ||
+        (s = dev_alloc(h, &nlv, (size_t)ncap, 0)) != HNSW_OK) {
+        // out of HBM part-way: give back what was taken, the index stays as it was
+        dev_free(h, nvec, (size_t)ncap * h->dim);
+        dev_free(h, nadj0, (size_t)ncap * h->stride0);
+        dev_free(h, nub, (size_t)ncap);
+        dev_free(h, nlv, (size_t)ncap);
+        return s;
+    }
     if (h->n) {
         HIP_TRY(h, hipMemcpyAsync(nvec, h->d_vec, (size_t)h->n * h->dim * 4, hipMemcpyDeviceToDevice, h->stream));
         HIP_TRY(h, hipMemcpyAsync(nadj0, h->d_adj0, (size_t)h->n * h->stride0 * 4, hipMemcpyDeviceToDevice, h->stream));
