@@ -8,7 +8,7 @@ from bench import draw_levels
 from redis_hnsw_amd import Index, _capi
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-dim, M, ef, k, B = 128, 16, 200, 10, 1024
+dim, M, ef, k, B = 128, 16, 200, 10, (int(sys.argv[2]) if len(sys.argv) > 2 else 1024)
 V = np.random.default_rng(1).random((N, dim), dtype=np.float32)
 Q = np.random.default_rng(2).random((4 * B, dim), dtype=np.float32)
 gi = Index("p", dim, M, ef)
@@ -42,7 +42,11 @@ if hasattr(lib, "hnsw_debug_phase_cycles"):
     out = (C.c_uint64 * 8)()
     lib.hnsw_debug_phase_cycles(gi._h, out)
     tot = sum(out[:6])
-    if tot:
+    if os.environ.get("HNSW_TWO_WAVE") == "1":
+        ne = sc.n_expand
+        print("  two-wave, clocks per expansion: distance wave %.0f (waiting for the set wave %.0f); set wave %.0f "
+              "(waiting for keys %.0f, merge %.0f, filter %.0f; filter wave waiting for the next candidate %.0f)" % (out[1] / ne, out[0] / ne, out[3] / ne, out[2] / ne, out[4] / ne, out[5] / ne, out[6] / ne))
+    elif tot:
         names = ["pop+row fetch", "visited filter", "gather+dist", "merge W"]
         per_step = sc.n_expand
         for i, nm in enumerate(names):
