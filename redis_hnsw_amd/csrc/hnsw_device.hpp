@@ -882,12 +882,13 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
 
         // last keys of an expansion: choose the next candidate now, request its row; the keys stay
         // pending and are merged under the latencies that follow
-        auto choose_next = [&](uint64_t key, bool take) {
+        auto choose_next = [&](uint64_t key, bool take, bool rkey_known = false, uint64_t rkey_pre = ~0ull) {
             // last merge of this expansion: choose the next candidate now
-            uint64_t rkey = ~0ull;
-            int r2, l2;
-            const bool have_r = first_unexpanded<R>(w, rkey, r2, l2);
-            if (!have_r) rkey = ~0ull;
+            uint64_t rkey = rkey_pre;
+            if (!rkey_known) {
+                int r2, l2;
+                if (!first_unexpanded<R>(w, rkey, r2, l2)) rkey = ~0ull;
+            }
             uint64_t bm = __ballot(take && key < rkey);
             nkey = rkey;
             while (bm) {
@@ -967,7 +968,7 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
                 const uint32_t pm = cnt >= 32 ? 0xFFFFFFFFu : ((1u << cnt) - 1u);
                 constexpr int RB = (T <= 4) ? 4 : (T <= 8 ? 2 : 1);   // rounds of 8 vectors in flight
                 const uint32_t safe_id = (uint32_t)__builtin_amdgcn_readlane((int)word, 1);
-                uint64_t key = ~0ull, fm = 0;
+                uint64_t key = ~0ull, fm = 0, rkey_pre = ~0ull;
                 bool have = false;
 #pragma unroll
                 for (int r0 = 0; r0 < 4; r0 += RB) {
@@ -988,6 +989,10 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
                                 ptake = false;
                                 PH_MARK(ctr, 3);
                             }
+                            // W is complete now: its first unexpanded entry is known before the
+                            // distances are (one scan less between the vectors and the next row request)
+                            int r2, l2;
+                            if (!first_unexpanded<R>(w, rkey_pre, r2, l2)) rkey_pre = ~0ull;
                         }
                     });
 #pragma unroll
@@ -1002,7 +1007,7 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
                 ctr.n_dist += nf;                      // the reference evaluates the fresh ones (core.rs:652)
                 const bool fresh_mine = (fm >> ((sub & 3) * 8 + grp + 1)) & 1ull;
                 const bool take = have && fresh_mine && key < worst;              // core.rs:657
-                choose_next(key, take);
+                choose_next(key, take, true, rkey_pre);
             }
         } else {
             for (uint32_t wbase = 0; wbase <= cnt; wbase += 64) {   // core.rs:646 stored order
