@@ -968,8 +968,8 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
                 const uint32_t pm = cnt >= 32 ? 0xFFFFFFFFu : ((1u << cnt) - 1u);
                 constexpr int RB = (T <= 4) ? 4 : (T <= 8 ? 2 : 1);   // rounds of 8 vectors in flight
                 const uint32_t safe_id = (uint32_t)__builtin_amdgcn_readlane((int)word, 1);
-                uint64_t key = ~0ull, fm = 0, rkey_pre = ~0ull;
-                bool have = false;
+                uint64_t key = ~0ull, rkey_pre = ~0ull;
+                bool have = false, fresh_mine = false;
 #pragma unroll
                 for (int r0 = 0; r0 < 4; r0 += RB) {
                     uint32_t idr[RB];
@@ -982,7 +982,11 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
                     float dd[RB];
                     dist_rounds<T, RB>(vec4, row4, idr, qr, m.qlds, pp, dd, [&] {
                         if (r0 == 0) {
-                            fm = __ballot(visited_insert_wave(vis, valid, word, lane, &g.hdr->ctr_search[3]));
+                            const uint64_t fm = __ballot(visited_insert_wave(vis, valid, word, lane, &g.hdr->ctr_search[3]));
+                            const uint32_t nf = __popcll(fm);
+                            vis.count += nf;
+                            ctr.n_dist += nf;          // the reference evaluates the fresh ones (core.rs:652)
+                            fresh_mine = (fm >> ((sub & 3) * 8 + grp + 1)) & 1ull;   // the key this lane will hold
                             PH_MARK(ctr, 1);  // visited filter
                             if (__ballot(ptake)) {      // deferred scatter of the previous expansion's keys
                                 nW = merge_apply<R>(w, m.W, nW, ef, pkey, ptake, pup, ppos, lane, &worst);
@@ -1002,10 +1006,6 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
                     }
                 }
                 PH_MARK(ctr, 2);  // vector gather + distances
-                const uint32_t nf = __popcll(fm);
-                vis.count += nf;
-                ctr.n_dist += nf;                      // the reference evaluates the fresh ones (core.rs:652)
-                const bool fresh_mine = (fm >> ((sub & 3) * 8 + grp + 1)) & 1ull;
                 const bool take = have && fresh_mine && key < worst;              // core.rs:657
                 choose_next(key, take, true, rkey_pre);
             }
