@@ -42,11 +42,7 @@ if hasattr(lib, "hnsw_debug_phase_cycles"):
     out = (C.c_uint64 * 8)()
     lib.hnsw_debug_phase_cycles(gi._h, out)
     tot = sum(out[:6])
-    if os.environ.get("HNSW_TWO_WAVE") == "1":
-        ne = sc.n_expand
-        print("  two-wave, clocks per expansion: distance wave %.0f (waiting for the set wave %.0f); set wave %.0f "
-              "(waiting for keys %.0f, merge %.0f, filter %.0f; filter wave waiting for the next candidate %.0f)" % (out[1] / ne, out[0] / ne, out[3] / ne, out[2] / ne, out[4] / ne, out[5] / ne, out[6] / ne))
-    elif tot:
+    if tot:
         names = ["pop+row fetch", "visited filter", "gather+dist", "merge W"]
         per_step = sc.n_expand
         for i, nm in enumerate(names):
