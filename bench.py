@@ -51,8 +51,8 @@ def brute_force_gt(torch, V_dev, Q_dev, k):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--nodes", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--m", type=int, default=16)
