@@ -123,6 +123,18 @@ uint32_t draw_level(hnsw_index *h)
     return (uint32_t)l;
 }
 
+// device scratch that lives for one API call: freed on every way out of the scope (hipFree waits
+// for work still using it)
+template <typename Tp>
+struct DevScratch {
+    Tp *p = nullptr;
+    DevScratch() = default;
+    DevScratch(const DevScratch &) = delete;
+    DevScratch &operator=(const DevScratch &) = delete;
+    ~DevScratch() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t count) { return hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(Tp)); }
+};
+
 template <typename Tp>
 hnsw_status dev_alloc(hnsw_index *h, Tp **p, size_t count, int fill = -1)
 {
@@ -660,10 +672,11 @@ hnsw_status hnsw_add_batch(hnsw_index *h, const float *V, uint32_t n, uint32_t d
     HIP_TRY(h, hipMemcpyAsync(h->d_upper_base + first, h->h_upper_base.data() + first, (size_t)rest * 4, hipMemcpyHostToDevice, h->stream));
     if ((s = ensure_spill(h)) != HNSW_OK) return s;
     if ((s = ensure_plan(h, h->fast_batch_max)) != HNSW_OK) return s;
-    uint32_t *pending0 = nullptr, *pendingU = nullptr, *work_n = nullptr;
-    HIP_TRY(h, hipMalloc((void **)&pending0, (size_t)h->cap * 4));
-    HIP_TRY(h, hipMalloc((void **)&pendingU, (size_t)std::max(h->upper_cap, 1u) * 4));
-    HIP_TRY(h, hipMalloc((void **)&work_n, 4));
+    DevScratch<uint32_t> sc0, scU, scN;
+    HIP_TRY(h, sc0.alloc(h->cap));
+    HIP_TRY(h, scU.alloc(std::max(h->upper_cap, 1u)));
+    HIP_TRY(h, scN.alloc(1));
+    uint32_t *pending0 = sc0.p, *pendingU = scU.p, *work_n = scN.p;
     HIP_TRY(h, hipMemsetAsync(pending0, 0, (size_t)h->cap * 4, h->stream));
     HIP_TRY(h, hipMemsetAsync(pendingU, 0, (size_t)std::max(h->upper_cap, 1u) * 4, h->stream));
     HIP_TRY(h, hipMemsetAsync(work_n, 0, 4, h->stream));
@@ -685,8 +698,7 @@ hnsw_status hnsw_add_batch(hnsw_index *h, const float *V, uint32_t n, uint32_t d
         if ((s = add_fast_batch(h, first + pos, bs, new_max, new_ep, pending0, pendingU, work_n)) != HNSW_OK) break;
         pos += bs;
     }
-    hipError_t e = hipStreamSynchronize(h->stream);
-    (void)hipFree(pending0); (void)hipFree(pendingU); (void)hipFree(work_n);
+    hipError_t e = hipStreamSynchronize(h->stream);   // the kernels above use the scratch
     if (s != HNSW_OK) return s;
     HIP_TRY(h, e);
     DevHeader hd;
@@ -843,10 +855,12 @@ hnsw_status hnsw_import(hnsw_index *h, uint32_t n, const float *vectors, const u
     HIP_TRY(h, hipMemcpyAsync(h->d_upper_base, h->h_upper_base.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     for (uint32_t l = 0; l < n_layers; ++l) {
         uint64_t nnz = row_ptr[l][n];
-        uint64_t *d_rp = nullptr;
-        uint32_t *d_col = nullptr;
-        HIP_TRY(h, hipMalloc((void **)&d_rp, (size_t)(n + 1) * 8));
-        HIP_TRY(h, hipMalloc((void **)&d_col, (size_t)std::max<uint64_t>(nnz, 1) * 4));
+        DevScratch<uint64_t> s_rp;
+        DevScratch<uint32_t> s_col;
+        HIP_TRY(h, s_rp.alloc((size_t)n + 1));
+        HIP_TRY(h, s_col.alloc((size_t)nnz));
+        uint64_t *d_rp = s_rp.p;
+        uint32_t *d_col = s_col.p;
         HIP_TRY(h, hipMemcpyAsync(d_rp, row_ptr[l], (size_t)(n + 1) * 8, hipMemcpyHostToDevice, h->stream));
         if (nnz) HIP_TRY(h, hipMemcpyAsync(d_col, col[l], (size_t)nnz * 4, hipMemcpyHostToDevice, h->stream));
         uint32_t blocks = (uint32_t)(((uint64_t)n * 64 + 255) / 256);
@@ -857,8 +871,6 @@ hnsw_status hnsw_import(hnsw_index *h, uint32_t n, const float *vectors, const u
             hipLaunchKernelGGL(k_import_rows, dim3(blocks), dim3(256), 0, h->stream, h->d_adjU, h->strideU,
                                h->d_upper_base, l - 1, h->d_levels, l, d_rp, d_col, n);
         HIP_TRY(h, hipStreamSynchronize(h->stream));
-        (void)hipFree(d_rp);
-        (void)hipFree(d_col);
     }
     h->n = n;
     h->enterpoint = enterpoint;
@@ -923,8 +935,9 @@ static hnsw_status layer_degrees(hnsw_index *h, uint32_t layer, std::vector<uint
 {
     deg.assign(h->n, 0);
     if (h->n == 0) return HNSW_OK;
-    uint32_t *d_deg = nullptr;
-    HIP_TRY(h, hipMalloc((void **)&d_deg, (size_t)h->n * 4));
+    DevScratch<uint32_t> s_deg;
+    HIP_TRY(h, s_deg.alloc(h->n));
+    uint32_t *d_deg = s_deg.p;
     uint32_t blocks = (h->n + 255) / 256;
     if (layer == 0)
         hipLaunchKernelGGL(k_degrees, dim3(blocks), dim3(256), 0, h->stream, h->d_adj0, h->stride0,
@@ -934,7 +947,6 @@ static hnsw_status layer_degrees(hnsw_index *h, uint32_t layer, std::vector<uint
                            h->d_upper_base, layer - 1, h->d_levels, layer, h->n, d_deg);
     HIP_TRY(h, hipMemcpyAsync(deg.data(), d_deg, (size_t)h->n * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    (void)hipFree(d_deg);
     return HNSW_OK;
 }
 
@@ -962,10 +974,12 @@ hnsw_status hnsw_export_layer(hnsw_index *h, uint32_t layer, uint64_t *row_ptr, 
     for (uint32_t i = 0; i < h->n; ++i) { row_ptr[i] = t; t += deg[i]; }
     row_ptr[h->n] = t;
     if (t == 0 || h->n == 0) return HNSW_OK;
-    uint64_t *d_rp = nullptr;
-    uint32_t *d_col = nullptr;
-    HIP_TRY(h, hipMalloc((void **)&d_rp, (size_t)(h->n + 1) * 8));
-    HIP_TRY(h, hipMalloc((void **)&d_col, (size_t)t * 4));
+    DevScratch<uint64_t> s_rp;
+    DevScratch<uint32_t> s_col;
+    HIP_TRY(h, s_rp.alloc((size_t)h->n + 1));
+    HIP_TRY(h, s_col.alloc((size_t)t));
+    uint64_t *d_rp = s_rp.p;
+    uint32_t *d_col = s_col.p;
     HIP_TRY(h, hipMemcpyAsync(d_rp, row_ptr, (size_t)(h->n + 1) * 8, hipMemcpyHostToDevice, h->stream));
     uint32_t blocks = (uint32_t)(((uint64_t)h->n * 64 + 255) / 256);
     if (layer == 0)
@@ -976,8 +990,6 @@ hnsw_status hnsw_export_layer(hnsw_index *h, uint32_t layer, uint64_t *row_ptr, 
                            h->d_upper_base, layer - 1, h->d_levels, layer, h->n, d_rp, d_col);
     HIP_TRY(h, hipMemcpyAsync(col, d_col, (size_t)t * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    (void)hipFree(d_rp);
-    (void)hipFree(d_col);
     return HNSW_OK;
 }
 
