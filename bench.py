@@ -48,6 +48,32 @@ def brute_force_gt(torch, V_dev, Q_dev, k):
     return torch.cat(out).cpu().numpy()
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU
+    (what the driver's own command line does).  With fewer visible devices than ranks the ranks share
+    cuda:0 and the collectives run over gloo on host copies -- a functional check of the N>1 path, not a
+    scaling measurement (config.parallelism says so)."""
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    env = os.environ.copy()
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if ndev < args.gpus:
+        env["HNSW_BENCH_ONE_DEVICE"] = "1"
+        env["HNSW_BENCH_BACKEND"] = "gloo"
+        print("[bench] %d ranks on %d visible device(s): sharing cuda:0, gloo collectives" % (args.gpus, ndev),
+              file=sys.stderr, flush=True)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,7 +89,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clustered", action="store_true")
     ap.add_argument("--build", default="fast", choices=["fast", "exact"])
+    ap.add_argument("--verify-gather", action="store_true",
+                    help="N>1: rank 0 re-runs every rank's first batch on its own replica and compares with the gathered result")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -71,7 +101,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    if os.environ.get("HNSW_BENCH_ONE_DEVICE"):
+    one_device = bool(os.environ.get("HNSW_BENCH_ONE_DEVICE"))
+    if one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
@@ -184,6 +215,22 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_wall = float(tt.item())
     stream_ms = ev0.elapsed_time(ev1)
+    gather_ok = None
+    if world > 1 and args.verify_gather:
+        # every rank searches its first batch, one gather; rank 0 repeats all of them on its own replica
+        index.search_batch_device(myQ[:B].data_ptr(), B, k, d_ids.data_ptr(), d_sims.data_ptr(), d_n.data_ptr(),
+                                  stream.cuda_stream)
+        torch.cuda.synchronize()
+        got = shard.gather_packed(dist, d_out if backend == "nccl" else d_out.cpu(), world).cpu().numpy()
+        if rank == 0:
+            gather_ok = True
+            for r in range(world):
+                q = torch.from_numpy(Qall[r * n_qbatches * B:r * n_qbatches * B + B]).to(dev)
+                index.search_batch_device(q.data_ptr(), B, k, d_ids.data_ptr(), d_sims.data_ptr(), d_n.data_ptr(),
+                                          stream.cuda_stream)
+                torch.cuda.synchronize()
+                gather_ok = gather_ok and bool(np.array_equal(got[r], d_out.cpu().numpy()))
+            log("gathered == unsharded: %s" % gather_ok)
     log("timed region done: %.3f ms/step" % (1e3 * t_wall / args.steps))
     sc, _ = index.counters()
 
@@ -313,7 +360,9 @@ def main():
         "config": {"workload": "%s: %d nodes x dim %d, M=%d, ef=%d, k=%d, batch=%d queries/GPU, uniform[0,1) f32, replicated index"
                                % (cfg_name, N, dim, M, ef, k, B),
                    "nodes": N, "dim": dim, "M": M, "ef": ef, "k": k, "batch": B, "build": args.build,
-                   "parallelism": "replica x%d, query batch sharded" % world},
+                   "parallelism": "replica x%d, query batch sharded%s" % (
+                       world, " (ranks share one device, gloo: functional check only)" if one_device and world > 1 else "")},
+        "gather_verified": gather_ok,
         "recall_at_%d" % k: None if recall is None else round(recall, 4),
         "build_seconds": None if t_build is None else round(t_build, 2),
         "host_buffers_qps": round(host_qps, 1),

@@ -253,6 +253,8 @@ struct Visited {
     uint32_t count;          // ids held (wave-uniform)
     bool spilled;            // wave-uniform
     bool glob_dirty;         // wave-uniform
+    bool bounded;            // search only: a full LDS table stops taking ids instead of moving to HBM
+    bool lossy;              // wave-uniform: the bounded table is full, ids met from now on are not recorded
 };
 constexpr uint32_t kBucketIds = 7;
 
@@ -366,6 +368,36 @@ __device__ __forceinline__ uint32_t tag_set_insert(uint32_t *tab, uint32_t bb, u
     return 2;
 }
 
+// lookup without insert (bounded table that is full): true if id is NOT in the table
+__device__ __forceinline__ bool tag_set_absent(const uint32_t *tab, uint32_t bb, uint32_t idbits, uint32_t id)
+{
+    const uint32_t h = tag_hash(id, idbits);
+    const uint32_t bmask = (1u << bb) - 1u;
+    const uint32_t b0 = h & bmask, tag = h >> bb;
+    for (uint32_t d = 0; d < 7; ++d) {
+        const uint4 w = *reinterpret_cast<const uint4 *>(tab + (((b0 + d) & bmask) << 2));
+        const uint32_t want = (tag << 3) | d;
+        const uint32_t ww = want | (want << 16);
+        const uint32_t hit = haszero16(w.y ^ ww) | haszero16(w.z ^ ww) | haszero16(w.w ^ ww) |
+                             ((w.x >> 16) == want ? 1u : 0u);
+        if (hit) return false;
+        if ((w.x & 0xFFFFu) < kBucketIds) return true;       // an id only chains past FULL buckets
+    }
+    return true;
+}
+__device__ __forceinline__ bool lds_set_absent(const uint32_t *tab, uint32_t nb, uint32_t id)
+{
+    uint32_t b = hash_bucket(id, nb);
+    for (uint32_t it = 0; it < nb; ++it) {
+        const uint4 *p4 = reinterpret_cast<const uint4 *>(tab + (b << 3));
+        const uint4 lo = p4[0], hi = p4[1];
+        if (any_eq7(lo, hi, id)) return false;
+        if (lo.x < kBucketIds) return true;
+        b = b + 1 == nb ? 0 : b + 1;
+    }
+    return true;
+}
+
 // empty bucket = {0, kEmpty x 7}.  16-byte piece i is the head of a bucket iff i
 // is even; i = lane + 64k keeps the lane's parity, so each lane stores one constant.
 __device__ __forceinline__ void visited_clear(Visited &v, int lane)
@@ -388,6 +420,7 @@ __device__ __forceinline__ void visited_clear(Visited &v, int lane)
     }
     v.count = 0;
     v.spilled = false;
+    v.lossy = false;
     __syncthreads();
 }
 
@@ -427,8 +460,17 @@ __device__ __forceinline__ bool visited_insert_wave(Visited &v, bool valid, uint
                                                     unsigned long long *spill_ctr)
 {
     if (v.spilled) return valid && glob_set_insert(v.glob, v.gnb, id);
+    if (v.lossy)           // bounded table, full: look up only (the caller drops re-met members of W itself)
+        return valid && (v.tag_bb ? tag_set_absent(v.lds, v.tag_bb, v.idbits, id) : lds_set_absent(v.lds, v.lnb, id));
     if (!v.tag_bb) return valid && lds_set_insert(v.lds, v.lnb, id);
     const uint32_t r = valid ? tag_set_insert(v.lds, v.tag_bb, v.idbits, id) : 0u;
+    if (v.bounded) {
+        if (__ballot(r == 2u)) {                      // no room near an id's home bucket: stop recording
+            v.lossy = true;
+            if (lane == 0 && spill_ctr) atomicAdd(spill_ctr, 1ull);
+        }
+        return r != 0u;                               // 2 = absent (and not recorded)
+    }
     if (__ballot(r == 2u)) {
         visited_spill(v, lane, spill_ctr);
         if (r == 2u) return glob_set_insert(v.glob, v.gnb, id);
@@ -449,7 +491,12 @@ __device__ __forceinline__ bool visited_reserve(Visited &v, int lane, unsigned l
 {
     const uint32_t gcap = v.gnb * 6u;                  // ids at ~6/7 of the slots
     if (!v.spilled) {
-        if (v.count + 64 <= v.lcap) return true;
+        if (v.count + 64 <= v.lcap || v.lossy) return true;
+        if (v.bounded) {                               // search: keep what is recorded, forget the rest
+            v.lossy = true;
+            if (lane == 0 && spill_ctr) atomicAdd(spill_ctr, 1ull);
+            return true;
+        }
         if (v.count + 64 > gcap) return false;         // would not fit there either
         visited_spill(v, lane, spill_ctr);
     }
@@ -745,6 +792,25 @@ __device__ __forceinline__ uint32_t merge_regs(uint64_t (&w)[R], uint64_t *Wbuf,
     return merge_apply<R>(w, Wbuf, nW, cap, nk, take, up, mypos, lane, worst);
 }
 
+// Bounded visited table that has stopped recording: a neighbour met again may still be a member of W
+// (any other re-met id fails the accept test again, W's furthest only improves).  The same id always has
+// the same distance, so a member shows up as an equal key (expanded bit aside): those are dropped here.
+template <int R>
+__device__ __forceinline__ bool drop_members(const uint64_t (&w)[R], uint64_t key, bool take, int lane)
+{
+    uint64_t mm = __ballot(take), dup = 0;
+    while (mm) {
+        const int j = __ffsll((unsigned long long)mm) - 1;
+        mm &= mm - 1;
+        const uint64_t s = readlane64(key, j) >> 1;
+        bool eq = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) eq |= (w[r] >> 1) == s;
+        if (__ballot(eq)) dup |= 1ull << j;
+    }
+    return take && !((dup >> lane) & 1ull);
+}
+
 // first entry whose expanded bit is clear (slots past nW hold ~0, bit set)
 template <int R>
 __device__ __forceinline__ bool first_unexpanded(const uint64_t (&w)[R], uint64_t &key, int &rsel, int &lsel)
@@ -946,7 +1012,8 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
                 }
             }
             PH_MARK(ctr, 2);  // vector gather + distances
-            const bool take = have && key < worst;                            // core.rs:657
+            bool take = have && key < worst;                                  // core.rs:657
+            if (vis.lossy) take = drop_members<R>(w, key, take, lane);
             if (is_last) {
                 choose_next(key, take);
             } else {
@@ -1006,7 +1073,8 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
                     }
                 }
                 PH_MARK(ctr, 2);  // vector gather + distances
-                const bool take = have && fresh_mine && key < worst;              // core.rs:657
+                bool take = have && fresh_mine && key < worst;                    // core.rs:657
+                if (vis.lossy) take = drop_members<R>(w, key, take, lane);
                 choose_next(key, take, true, rkey_pre);
             }
         } else {

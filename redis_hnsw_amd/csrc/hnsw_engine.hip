@@ -59,6 +59,9 @@ struct hnsw_index {
     bool fast_built = false;        // the fast build prunes one-directionally: links may be asymmetric
     uint32_t lds_fill_x2 = 13;       // LDS visited table holds lnb * fill/2 ids (of 7 per bucket) before spilling
     int grid_override = -1;
+    bool visited_bounded = true;     // k_search: a full LDS visited table stops recording (exact results)
+    uint32_t max_waves_per_cu = 8;
+    uint32_t launch_concurrency = 1; // tuning: search launches the caller keeps in flight at once (sizes the LDS share)   // residency the LDS visited table is sized for (tuning: waves_per_cu)
     uint32_t fast_seed = 512, fast_batch_max = 4096, fast_batch_div = 8;
     uint64_t rng[4] = {0, 0, 0, 0};
     uint64_t hbm_bytes = 0;
@@ -288,9 +291,13 @@ uint32_t pick_lnb(const hnsw_index *h, int R, int T, bool ins, uint32_t nwaves)
     const size_t fixed = lds_fixed_bytes(R, T, h->dim, ins);
     if (h->lds_buckets_override >= 2) return (uint32_t)h->lds_buckets_override;
     // measured on MI355X: 40448 B per 64-thread block still gives 4 blocks per CU, 40960 B does not
-    const size_t tiers[4] = {160 * 1024 - 2048, 80896, 53760, 40448};   // 1, 2, 3, 4 waves per CU
+    // (163840 / n - 512); 5..8 per CU follow the same rule, rounded down to 256 B
+    const size_t tiers[8] = {160 * 1024 - 2048, 80896, 53760, 40448, 32256, 26624, 22784, 19968};
+    // the insert kernels keep the exact HBM spill path: give them the larger table
+    const uint32_t max_per_cu = ins ? std::min(h->max_waves_per_cu, 4u) : h->max_waves_per_cu;
+    if (!ins) nwaves *= h->launch_concurrency;   // searches the caller overlaps on several streams share the CUs
     uint32_t per_cu = (nwaves + 255) / 256;
-    per_cu = std::min(std::max(per_cu, 1u), 4u);
+    per_cu = std::min(std::max(per_cu, 1u), max_per_cu);
     size_t budget = tiers[per_cu - 1];
     while (budget <= fixed + 64 && per_cu > 1) budget = tiers[--per_cu - 1];
     const uint32_t fit = (uint32_t)((budget - fixed) / 32);
@@ -404,7 +411,7 @@ hnsw_status launch_search_t(hnsw_index *h, const float *dQ, uint32_t B, uint32_t
     if (ss != HNSW_OK) return ss;
     HIP_TRY(h, hipEventRecord(h->ev0, st));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, st, gv, dQ, B, k, h->efc, lnb, vc.lcap, spill,
-                       h->spill_gnb, d_ids, d_sims, d_nout);
+                       h->spill_gnb, d_ids, d_sims, d_nout, h->visited_bounded ? 1u : 0u);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->ev1, st));
     if ((ss = spill_release(h, st, region)) != HNSW_OK) return ss;
@@ -594,6 +601,9 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
     if (!std::strcmp(key, "lds_buckets")) { h->lds_buckets_override = (int)value; return HNSW_OK; }
     if (!std::strcmp(key, "lds_hash_bits")) { h->lds_buckets_override = std::max<int>(2, (int)((1ll << value) / 8)); return HNSW_OK; }
     if (!std::strcmp(key, "grid")) { h->grid_override = (int)value; return HNSW_OK; }
+    if (!std::strcmp(key, "launch_concurrency")) { h->launch_concurrency = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 8); return HNSW_OK; }
+    if (!std::strcmp(key, "visited_bounded")) { h->visited_bounded = value != 0; return HNSW_OK; }
+    if (!std::strcmp(key, "waves_per_cu")) { h->max_waves_per_cu = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 8); return HNSW_OK; }
     if (!std::strcmp(key, "fast_seed")) { h->fast_seed = (uint32_t)std::max<int64_t>(value, 1); return HNSW_OK; }
     if (!std::strcmp(key, "fast_batch_max")) { h->fast_batch_max = (uint32_t)std::max<int64_t>(value, 1); return HNSW_OK; }
     if (!std::strcmp(key, "fast_batch_div")) { h->fast_batch_div = (uint32_t)std::max<int64_t>(value, 1); return HNSW_OK; }

@@ -158,6 +158,8 @@ __global__ __launch_bounds__(64, 1) void k_insert_plan(GraphView g, uint32_t fir
     vis.glob_dirty = false;
     vis.spilled = false;
     vis.count = 0;
+    vis.bounded = false;
+    vis.lossy = false;
 
     WorkCtr ctr = {};
     const uint32_t lmax = g.hdr->max_layer;                 // core.rs:496
@@ -298,6 +300,8 @@ __global__ __launch_bounds__(64, 1) void k_insert_commit_exact(GraphView g, uint
     vis.glob_dirty = false;
     vis.spilled = false;
     vis.count = 0;
+    vis.bounded = false;
+    vis.lossy = false;
 
     WorkCtr ctr = {};
     uint32_t skipped = 0;  // econn evaluations the reference makes but whose result it never uses (:549-557 when deg <= m_max)
@@ -400,6 +404,8 @@ __global__ __launch_bounds__(64, 1) void k_delete_exact(GraphView g, uint32_t id
     vis.glob_dirty = false;
     vis.spilled = false;
     vis.count = 0;
+    vis.bounded = false;
+    vis.lossy = false;
     WorkCtr ctr = {};
     uint32_t nt = 0;
     bool fail = false;

@@ -13,7 +13,7 @@ __global__ __launch_bounds__(64) void k_search(GraphView g, const float *__restr
                                                uint32_t k, uint32_t ef, uint32_t lnb, uint32_t lcap,
                                                uint32_t *__restrict__ gspill, uint32_t gnb,
                                                uint32_t *__restrict__ out_ids, float *__restrict__ out_sims,
-                                               uint32_t *__restrict__ out_n)
+                                               uint32_t *__restrict__ out_n, uint32_t bounded)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -25,6 +25,10 @@ __global__ __launch_bounds__(64) void k_search(GraphView g, const float *__restr
     vis.glob_dirty = false;
     vis.spilled = false;
     vis.count = 0;
+    vis.lossy = false;
+    // bounded: a full LDS table stops recording instead of moving to HBM (register-resident W only:
+    // search_level_v2 drops re-met members of W itself)
+    vis.bounded = bounded != 0 && MODE == MODE_AVX;
 
     WorkCtr ctr = {};
 #ifdef HNSW_PHASE_TIMERS

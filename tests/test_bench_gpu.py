@@ -1,0 +1,38 @@
+"""bench.py's N>1 control flow on a single-GPU box: `--gpus 2` spawns two ranks itself (they share
+cuda:0, gloo collectives), and the gathered top-k equals the unsharded search."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--nodes", "20000", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--no-clustered"] + extra
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_spawns_two_ranks_and_gather_matches_unsharded():
+    out = _run(["--gpus", "2", "--verify-gather"])
+    assert out["n_gpus"] == 2
+    assert out["gather_verified"] is True
+    assert out["scaling"] == "weak" and out["value"] > 0
+    assert out["roofline"]["bound"] == "hbm"
+
+
+def test_bench_single_rank_line_has_the_contract_fields():
+    out = _run(["--gpus", "1"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in out
+    assert out["n_gpus"] == 1 and out["dtype"] == "f32" and "workload" in out["config"]

@@ -110,6 +110,7 @@ def test_search_visited_spill_is_exact(eng, oracle_mod, built):
     gi = eng.Index("foo", dim, m, ef)
     gi.import_graph(o.export())
     Q = make_data(nq, dim, seed=3)
+    gi.set_tuning("visited_bounded", 0)          # the HBM spill path (the insert kernels' mode)
     gi.set_tuning("lds_hash_bits", 8)
     gi.reset_counters()
     ids, sims, n_out = gi.search_batch(Q, k)
@@ -133,6 +134,7 @@ def test_tag_table_spill_and_decode_is_exact(eng, oracle_mod, built, bb):
     gi = eng.Index("foo", dim, m, ef)
     gi.import_graph(o.export())
     Q = make_data(nq, dim, seed=3)
+    gi.set_tuning("visited_bounded", 0)
     gi.set_tuning("tag_bb", bb)
     gi.reset_counters()
     ids, sims, n_out = gi.search_batch(Q, k)
@@ -141,6 +143,53 @@ def test_tag_table_spill_and_decode_is_exact(eng, oracle_mod, built, bb):
     oids, osims, on, oct = o.search_batch(Q, k)
     assert np.array_equal(ids, oids) and np.array_equal(_bits(sims), _bits(osims))
     assert (sc.n_dist, sc.n_ids, sc.n_expand) == (oct.n_dist, oct.n_ids, oct.n_expand)
+    gi.close()
+
+
+@pytest.mark.parametrize("knob,val", [("tag_bb", 3), ("tag_bb", 6), ("tag_bb", 8), ("lds_hash_bits", 8)])
+@pytest.mark.parametrize("cfg", [(2000, 128, 16, 200, 10), (900, 768, 32, 400, 100), (1200, 32, 5, 16, 5)])
+def test_bounded_visited_table_is_exact(eng, oracle_mod, built, knob, val, cfg):
+    """The search's default: a full LDS visited table stops recording instead of moving to HBM.  A node
+    met again is evaluated again: it fails the accept test again (W's furthest only improves) unless it
+    still is a member of W, and those are dropped by key equality -- so ids, similarities, n_out, the
+    expansions and the ids scanned are the reference's; only the distance evaluations can exceed it."""
+    n, dim, m, ef, k = cfg
+    nq = 48
+    V, o, lv = built(n, dim, m, ef)
+    gi = eng.Index("foo", dim, m, ef)
+    gi.import_graph(o.export())
+    Q = make_data(nq, dim, seed=3)
+    if knob == "lds_hash_bits":
+        gi.set_tuning("tag_table", 0)
+    gi.set_tuning(knob, val)
+    gi.reset_counters()
+    ids, sims, n_out = gi.search_batch(Q, k)
+    sc, _ = gi.counters()
+    oids, osims, on, oct = o.search_batch(Q, k)
+    assert np.array_equal(n_out, on)
+    assert np.array_equal(ids, oids) and np.array_equal(_bits(sims), _bits(osims))
+    if not (knob == "tag_bb" and n <= (1 << val) * 6):
+        assert sc.n_spill > 0, "the table was meant to fill up"
+    assert (sc.n_ids, sc.n_expand) == (oct.n_ids, oct.n_expand)
+    assert sc.n_dist >= oct.n_dist
+    if sc.n_spill == 0:
+        assert sc.n_dist == oct.n_dist
+    gi.close()
+
+
+def test_default_table_never_forgets_at_c2_scale_batch(eng, oracle_mod, built):
+    """With the default table (sized for the batch) nothing is forgotten: all three counters are the oracle's."""
+    n, dim, m, ef, k, nq = 2000, 128, 16, 200, 10, 128
+    V, o, lv = built(n, dim, m, ef)
+    gi = eng.Index("foo", dim, m, ef)
+    gi.import_graph(o.export())
+    Q = make_data(nq, dim, seed=5)
+    gi.reset_counters()
+    ids, sims, n_out = gi.search_batch(Q, k)
+    sc, _ = gi.counters()
+    oids, osims, on, oct = o.search_batch(Q, k)
+    assert np.array_equal(ids, oids) and np.array_equal(_bits(sims), _bits(osims))
+    assert sc.n_spill == 0 and (sc.n_dist, sc.n_ids, sc.n_expand) == (oct.n_dist, oct.n_ids, oct.n_expand)
     gi.close()
 
 
