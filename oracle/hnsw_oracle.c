@@ -133,6 +133,22 @@ static inline int nearer(simpair a, simpair b)
     return a.sim > b.sim || (a.sim == b.sim && a.id < b.id);
 }
 
+/* "Reference-strict ties" (a test switch, off by default).  The reference compares on sim ALONE at
+ * core.rs:635 (stop), :657 (accept) and :733 (select); the oracle's default applies its (sim, id) total
+ * order there too.  With the switch on those three tests use sim only, exactly as written in the
+ * reference, and the id order is left to the heaps (where Rust leaves it unspecified).  The two variants
+ * can only differ when similarities tie; tests/test_oracle_kat.py shows whether they do.            */
+static int g_strict_ties = 0;
+void hnsw_oracle_set_strict_ties(int on) { g_strict_ties = on; }
+static inline int stop_test(simpair c, simpair f)      /* core.rs:635  c.sim < f.sim */
+{
+    return g_strict_ties ? c.sim < f.sim : nearer(f, c);
+}
+static inline int accept_test(simpair e, simpair f)    /* core.rs:657  esim > f.sim  */
+{
+    return g_strict_ties ? e.sim > f.sim : nearer(e, f);
+}
+
 /* binary heap; top = nearest (BinaryHeap<SimPair>) or top = furthest
  * (BinaryHeap<Reverse<SimPair>>), core.rs:625-628                            */
 typedef struct { simpair *a; uint32_t n, cap; int furthest_top; } heap;
@@ -334,7 +350,7 @@ static void search_level(const hnsw_oracle *o, scratch *s, const float *query,
     while (C->n) {                                      /* :630 */
         simpair c = heap_pop(C);                        /* :631 nearest        */
         simpair f = heap_peek(W);                       /* :632 furthest       */
-        if (nearer(f, c)) break;                        /* :635 c.sim < f.sim  */
+        if (stop_test(c, f)) break;                     /* :635 c.sim < f.sim  */
         ct->n_expand++;
         const nrow *nb = row_of(o, c.id, level);        /* :642-645            */
         for (uint32_t i = 0; i < nb->n; i++) {          /* :646 stored order   */
@@ -344,7 +360,7 @@ static void search_level(const hnsw_oracle *o, scratch *s, const float *query,
             f = heap_peek(W);                           /* :651                */
             simpair ep2 = { hnsw_oracle_euclidean(query, vec(o, e), o->dim), e }; /* :652 */
             ct->n_dist++;
-            if (nearer(ep2, f) || W->n < ef) {          /* :657                */
+            if (accept_test(ep2, f) || W->n < ef) {     /* :657                */
                 heap_push(C, ep2);                      /* :659                */
                 heap_push(W, ep2);                      /* :660                */
                 if (W->n > ef) heap_pop(W);             /* :662-664            */
@@ -404,7 +420,7 @@ static void select_neighbors(hnsw_oracle *o, scratch *s, uint32_t query,
         /* :733  `enr.sim > r.peek().sim`: r is nearest-top, so after the first
          * element this never holds on sim; on the (sim,id) key it cannot hold
          * either because w pops in key order.                                 */
-        if (r->n == 0 || nearer(e, heap_peek(r))) heap_push(r, e);
+        if (r->n == 0 || accept_test(e, heap_peek(r))) heap_push(r, e);
         else heap_push(wd, e);
     }
     /* :741-754 keep_pruned_connections */
@@ -665,49 +681,110 @@ uint32_t hnsw_oracle_search(const hnsw_oracle *o, const float *q, uint32_t k,
     return n;
 }
 
+/* Baseline B: T independent searches at a time over the shared read-only graph.  The
+ * workers are persistent and each keeps its own scratch (visited stamps + heaps) across calls -- a
+ * fresh scratch per call costs a node_count-sized memset per thread, which at 256 threads and 1024
+ * queries is more work than the searches themselves.                                              */
 typedef struct {
-    const hnsw_oracle *o; const float *Q; uint32_t lo, hi, k;
-    uint32_t *ids; float *sims; uint32_t *n_out; hnsw_oracle_counters ct;
+    const hnsw_oracle *o; const float *Q; uint32_t B, k;
+    uint32_t *ids; float *sims; uint32_t *n_out;
 } batch_job;
 
-static void *batch_worker(void *arg)
+typedef struct pool_worker {
+    pthread_t th; uint32_t idx; scratch sc; hnsw_oracle_counters ct; uint64_t seen_gen;
+} pool_worker;
+
+static struct {
+    pthread_mutex_t mu; pthread_cond_t go, done;
+    pool_worker *w; uint32_t n;           /* workers alive                          */
+    uint32_t active;                      /* workers taking part in the current job */
+    uint64_t gen; uint32_t pending;
+    volatile uint32_t next;               /* next query index (dynamic chunks)      */
+    batch_job job;
+} g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, NULL, 0, 0, 0, 0, 0, {0} };
+
+static void run_slice(pool_worker *w, const batch_job *j)
 {
-    batch_job *j = (batch_job *)arg;
-    scratch s;
-    scratch_init(&s);
-    memset(&j->ct, 0, sizeof j->ct);
-    for (uint32_t i = j->lo; i < j->hi; i++) {
-        if (j->o->enterpoint < 0 || j->o->node_count == 0) { j->n_out[i] = 0; continue; }
-        j->n_out[i] = search_knn_internal(j->o, &s, j->Q + (size_t)i * j->o->dim, j->k,
-                                          j->o->ef_construction, j->ids + (size_t)i * j->k,
-                                          j->sims + (size_t)i * j->k, &j->ct);
+    memset(&w->ct, 0, sizeof w->ct);
+    for (;;) {
+        /* chunks of 4 queries: balances the uneven cost of queries without contention */
+        uint32_t lo = __atomic_fetch_add(&g_pool.next, 4, __ATOMIC_RELAXED);
+        if (lo >= j->B) break;
+        uint32_t hi = lo + 4 < j->B ? lo + 4 : j->B;
+        for (uint32_t i = lo; i < hi; i++) {
+            if (j->o->enterpoint < 0 || j->o->node_count - j->o->n_dead == 0) { j->n_out[i] = 0; continue; }
+            j->n_out[i] = search_knn_internal(j->o, &w->sc, j->Q + (size_t)i * j->o->dim, j->k,
+                                              j->o->ef_construction, j->ids + (size_t)i * j->k,
+                                              j->sims + (size_t)i * j->k, &w->ct);
+        }
     }
-    scratch_free(&s);
+}
+
+static void *pool_main(void *arg)
+{
+    pool_worker *w = (pool_worker *)arg;
+    pthread_mutex_lock(&g_pool.mu);
+    for (;;) {
+        while (w->seen_gen == g_pool.gen) pthread_cond_wait(&g_pool.go, &g_pool.mu);
+        w->seen_gen = g_pool.gen;
+        int take = w->idx < g_pool.active;
+        batch_job j = g_pool.job;
+        pthread_mutex_unlock(&g_pool.mu);
+        if (take) run_slice(w, &j);
+        pthread_mutex_lock(&g_pool.mu);
+        if (take && --g_pool.pending == 0) pthread_cond_signal(&g_pool.done);
+    }
     return NULL;
+}
+
+/* grow the pool to `threads` workers (never shrinks; idle workers sleep on the condition variable) */
+static void pool_ensure(uint32_t threads)
+{
+    if (g_pool.n >= threads) return;
+    /* workers hold pointers into the array: allocate it once, large enough */
+    if (!g_pool.w) g_pool.w = (pool_worker *)calloc(1024, sizeof(pool_worker));
+    if (threads > 1024) threads = 1024;
+    for (uint32_t t = g_pool.n; t < threads; t++) {
+        pool_worker *w = &g_pool.w[t];
+        w->idx = t; w->seen_gen = g_pool.gen;
+        scratch_init(&w->sc);
+        pthread_create(&w->th, NULL, pool_main, w);
+    }
+    g_pool.n = threads;
 }
 
 void hnsw_oracle_search_batch(const hnsw_oracle *o, const float *Q, uint32_t B,
                               uint32_t k, uint32_t *ids, float *sims, uint32_t *n_out,
                               uint32_t threads, hnsw_oracle_counters *ctrs)
 {
-    if (threads < 1) threads = 1;
-    if (threads > B) threads = B ? B : 1;
-    batch_job *jobs = (batch_job *)calloc(threads, sizeof(batch_job));
-    pthread_t *th = (pthread_t *)calloc(threads, sizeof(pthread_t));
-    for (uint32_t t = 0; t < threads; t++) {
-        jobs[t].o = o; jobs[t].Q = Q; jobs[t].k = k; jobs[t].ids = ids; jobs[t].sims = sims; jobs[t].n_out = n_out;
-        jobs[t].lo = (uint32_t)((uint64_t)B * t / threads);
-        jobs[t].hi = (uint32_t)((uint64_t)B * (t + 1) / threads);
-        if (threads == 1) batch_worker(&jobs[t]);
-        else pthread_create(&th[t], NULL, batch_worker, &jobs[t]);
-    }
     hnsw_oracle_counters sum = { 0, 0, 0 };
-    for (uint32_t t = 0; t < threads; t++) {
-        if (threads > 1) pthread_join(th[t], NULL);
-        sum.n_dist += jobs[t].ct.n_dist; sum.n_ids += jobs[t].ct.n_ids; sum.n_expand += jobs[t].ct.n_expand;
+    if (threads < 1) threads = 1;
+    if (threads > 1024) threads = 1024;
+    if (threads > B) threads = B ? B : 1;
+    if (threads == 1) {
+        /* Baseline A: the reference's single command thread; the index's own scratch persists */
+        for (uint32_t i = 0; i < B; i++) {
+            if (o->enterpoint < 0 || o->node_count - o->n_dead == 0) { n_out[i] = 0; continue; }
+            n_out[i] = search_knn_internal(o, (scratch *)&o->sc, Q + (size_t)i * o->dim, k, o->ef_construction,
+                                           ids + (size_t)i * k, sims + (size_t)i * k, &sum);
+        }
+        if (ctrs) *ctrs = sum;
+        return;
     }
+    pthread_mutex_lock(&g_pool.mu);
+    pool_ensure(threads);
+    g_pool.job = (batch_job){ o, Q, B, k, ids, sims, n_out };
+    g_pool.active = threads;
+    g_pool.pending = threads;
+    g_pool.next = 0;
+    g_pool.gen++;
+    pthread_cond_broadcast(&g_pool.go);
+    while (g_pool.pending) pthread_cond_wait(&g_pool.done, &g_pool.mu);
+    for (uint32_t t = 0; t < threads; t++) {
+        sum.n_dist += g_pool.w[t].ct.n_dist; sum.n_ids += g_pool.w[t].ct.n_ids; sum.n_expand += g_pool.w[t].ct.n_expand;
+    }
+    pthread_mutex_unlock(&g_pool.mu);
     if (ctrs) *ctrs = sum;
-    free(jobs); free(th);
 }
 
 /* ========================================================================= */

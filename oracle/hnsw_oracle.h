@@ -58,6 +58,9 @@ float hnsw_oracle_sim_avx_emulated(const float *a, const float *b, size_t n);
 /* metrics.rs:14-23 : dispatch; AVX order iff n % 32 == 0                    */
 float hnsw_oracle_euclidean(const float *a, const float *b, size_t n);
 
+/* test switch: compare on sim alone at core.rs:635, :657, :733 (see hnsw_oracle.c); default off */
+void hnsw_oracle_set_strict_ties(int on);
+
 /* ---- index: src/hnsw/core.rs -------------------------------------------- */
 /* core.rs:322-347. seed feeds the oracle's own level generator (used only
  * when add() is called with level < 0).                                     */

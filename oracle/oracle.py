@@ -77,8 +77,14 @@ def lib():
     L.hnsw_oracle_import.restype = C.c_void_p
     L.hnsw_oracle_import.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, fp, u32p,
                                      C.c_int64, C.c_uint32, C.POINTER(u64p), C.POINTER(u32p)]
+    L.hnsw_oracle_set_strict_ties.argtypes = [C.c_int]
     _lib = L
     return L
+
+
+def set_strict_ties(on):
+    """test switch: sim-only comparisons at core.rs:635, :657, :733 (default: the (sim, id) total order)"""
+    lib().hnsw_oracle_set_strict_ties(1 if on else 0)
 
 
 def _fp(a):

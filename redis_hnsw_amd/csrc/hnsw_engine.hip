@@ -35,6 +35,8 @@ struct hnsw_index {
     // HBM spill tables of the visited sets: kSpillRegions regions, handed out round-robin so that
     // launches overlapping on different streams never share one (an event per region orders reuse)
     uint32_t *d_spill = nullptr;
+    uint32_t *d_spill_one = nullptr;   // one table for the single-wave exact insert / delete kernels: holds every id of the index
+    uint32_t spill_one_gnb = 0;
     uint32_t spill_gnb = 0, spill_slots = 0;
     hipEvent_t spill_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool spill_busy[4] = {false, false, false, false};
@@ -56,7 +58,7 @@ struct hnsw_index {
     int lds_buckets_override = -1;
     bool tag_table = true;          // 16-bit tag visited table when the id range allows it
     int tag_bb_override = -1;       // tests: force log2(buckets) of the tag table
-    bool fast_built = false;        // the fast build prunes one-directionally: links may be asymmetric
+    bool asymmetric = false;        // links may be one-directional (the fast build prunes that way; imports are checked)
     uint32_t lds_fill_x2 = 13;       // LDS visited table holds lnb * fill/2 ids (of 7 per bucket) before spilling
     int grid_override = -1;
     bool visited_bounded = true;     // k_search: a full LDS visited table stops recording (exact results)
@@ -392,6 +394,24 @@ hnsw_status ensure_spill(hnsw_index *h)
     return HNSW_OK;
 }
 
+// The exact insert / delete kernels are one wave: their table is sized so that it cannot overflow
+// (a visited set never holds more ids than the index has nodes; load <= 1/2).
+hnsw_status ensure_spill_one(hnsw_index *h)
+{
+    const uint32_t gnb = (uint32_t)(2ull * std::max(h->cap, 1024u) / 6) + 16;
+    if (h->d_spill_one && h->spill_one_gnb >= gnb) return HNSW_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    dev_free(h, h->d_spill_one, (size_t)h->spill_one_gnb * 8);
+    h->spill_one_gnb = 0;
+    hnsw_status s = dev_alloc(h, &h->d_spill_one, (size_t)gnb * 8);
+    if (s != HNSW_OK) return s;
+    hipLaunchKernelGGL(k_fill_buckets, dim3(1024), dim3(256), 0, h->stream, reinterpret_cast<uint4 *>(h->d_spill_one),
+                       (size_t)gnb * 2);
+    HIP_TRY(h, hipGetLastError());
+    h->spill_one_gnb = gnb;
+    return HNSW_OK;
+}
+
 template <int MODE, int T, int R>
 hnsw_status launch_search_t(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t *d_ids,
                             float *d_sims, uint32_t *d_nout, hipStream_t st)
@@ -497,9 +517,12 @@ hnsw_status pull_header(hnsw_index *h, DevHeader *out = nullptr)
     return HNSW_OK;
 }
 
+// The status word is per call: whatever a call reports is cleared on the device, so one failed (or merely
+// informational) call does not fail every later one.
 hnsw_status check_dev_status(hnsw_index *h, const DevHeader &hd)
 {
     if (hd.status == 0) return HNSW_OK;
+    HIP_TRY(h, hipMemsetAsync((char *)h->d_hdr + offsetof(DevHeader, status), 0, sizeof(uint32_t), h->stream));
     char buf[160];
     snprintf(buf, sizeof buf, "device status 0x%x:%s%s%s%s", hd.status,
              (hd.status & ST_VISITED_OVERFLOW) ? " visited-set overflow" : "",
@@ -508,7 +531,7 @@ hnsw_status check_dev_status(hnsw_index *h, const DevHeader &hd)
              (hd.status & ST_ASYMMETRIC) ? " asymmetric link" : "");
     // ROW_DROPPED is informational for the fast build, and so is a missing back link on a graph the
     // fast build produced (the reference would panic there, core.rs:150; its own graphs are symmetric)
-    uint32_t benign = ST_ROW_DROPPED | (h->fast_built ? ST_ASYMMETRIC : 0u);
+    uint32_t benign = ST_ROW_DROPPED | (h->asymmetric ? ST_ASYMMETRIC : 0u);
     if ((hd.status & ~benign) == 0) return HNSW_OK;
     return fail(h, HNSW_ERR_CAPACITY, buf);
 }
@@ -576,7 +599,7 @@ void hnsw_destroy(hnsw_index *h)
     }
     (void)hipFree(h->d_vec); (void)hipFree(h->d_adj0); (void)hipFree(h->d_adjU);
     (void)hipFree(h->d_upper_base); (void)hipFree(h->d_levels); (void)hipFree(h->d_hdr);
-    (void)hipFree(h->d_spill); (void)hipFree(h->d_Q); (void)hipFree(h->d_ids); (void)hipFree(h->d_sims);
+    (void)hipFree(h->d_spill); (void)hipFree(h->d_spill_one); (void)hipFree(h->d_Q); (void)hipFree(h->d_ids); (void)hipFree(h->d_sims);
     (void)hipFree(h->d_nout); (void)hipFree(h->d_plan); (void)hipFree(h->d_touched); (void)hipFree(h->d_work);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -663,7 +686,7 @@ hnsw_status hnsw_add_batch(hnsw_index *h, const float *V, uint32_t n, uint32_t d
     if (done == n) return HNSW_OK;
 
     // ---- fast build ---------------------------------------------------------
-    h->fast_built = true;
+    h->asymmetric = true;
     const uint32_t first = h->n, rest = n - done;
     if (std::max(h->stride0, h->strideU) > 129) return fail(h, HNSW_ERR_INVALID, "fast build needs row strides <= 129");
     std::vector<uint32_t> lv(rest);
@@ -726,12 +749,9 @@ hnsw_status hnsw_delete(hnsw_index *h, uint32_t id, uint32_t *touched, uint32_t 
         return fail(h, HNSW_ERR_NOT_FOUND, buf);
     }
     HIP_TRY(h, hipSetDevice(h->device));
-    hnsw_status s = delete_exact(h, id);
+    uint32_t nt = 0;
+    hnsw_status s = delete_exact(h, id, &nt);
     if (s != HNSW_OK) return s;
-    DevHeader hd;
-    if ((s = pull_header(h, &hd)) != HNSW_OK) return s;
-    if ((s = check_dev_status(h, hd)) != HNSW_OK) return s;
-    uint32_t nt = hd.n_touched;
     if (touched && nt) {
         uint32_t have = std::min(nt, h->touched_cap);
         std::vector<uint32_t> tmp(have);
@@ -770,7 +790,9 @@ hnsw_status hnsw_search_batch_device(hnsw_index *h, const float *dQ, uint32_t B,
     if (h->n == h->n_dead || h->enterpoint < 0) { // core.rs:481-483
         HIP_TRY(h, hipMemsetAsync(d_n_out, 0, (size_t)B * 4, st));
         HIP_TRY(h, hipMemsetAsync(d_ids, 0xFF, (size_t)B * k * 4, st));
-        HIP_TRY(h, hipMemsetAsync(d_sims, 0xFF, (size_t)B * k * 4, st));
+        hipLaunchKernelGGL(k_fill_f32, dim3(std::min<uint32_t>(1024, (uint32_t)(((size_t)B * k + 255) / 256))), dim3(256), 0, st,
+                           d_sims, (size_t)B * k, -__builtin_inff());
+        HIP_TRY(h, hipGetLastError());
         return HNSW_OK;
     }
     return launch_search(h, dQ, B, k, d_ids, d_sims, d_n_out, st);
@@ -830,18 +852,32 @@ hnsw_status hnsw_import(hnsw_index *h, uint32_t n, const float *vectors, const u
     if (enterpoint < 0 || enterpoint >= (int64_t)n || n_layers == 0 || n_layers > kMaxLayers)
         return fail(h, HNSW_ERR_INVALID, "bad enterpoint / layer count");
     HIP_TRY(h, hipSetDevice(h->device));
+    // Validate everything before any state changes: the blob may come from a file.
+    if (!vectors || !levels || !row_ptr || !col) return fail(h, HNSW_ERR_INVALID, "null argument");
+    for (uint32_t i = 0; i < n; ++i)
+        if (levels[i] >= kMaxLayers) return fail(h, HNSW_ERR_INVALID, "level too large");
+    if (levels[enterpoint] + 1 > n_layers) return fail(h, HNSW_ERR_INVALID, "the enterpoint's level exceeds the layer count");
+    for (uint32_t i = 0; i < n; ++i)
+        if (levels[i] > levels[enterpoint]) return fail(h, HNSW_ERR_INVALID, "a node above the enterpoint's level (core.rs:587-593 keeps the enterpoint on top)");
+    if (!all_finite(vectors, (size_t)n * h->dim)) return fail(h, HNSW_ERR_INVALID, "non-finite vector component");
     // degrees decide the row strides
     uint32_t md0 = 0, mdU = 0;
-    for (uint32_t l = 0; l < n_layers; ++l)
+    for (uint32_t l = 0; l < n_layers; ++l) {
+        if (!row_ptr[l] || (!col[l] && row_ptr[l][n] != 0)) return fail(h, HNSW_ERR_INVALID, "null layer arrays");
+        if (row_ptr[l][0] != 0) return fail(h, HNSW_ERR_INVALID, "row_ptr must start at 0");
         for (uint32_t i = 0; i < n; ++i) {
+            if (row_ptr[l][i + 1] < row_ptr[l][i]) return fail(h, HNSW_ERR_INVALID, "row_ptr is not monotonic");
             uint64_t d = row_ptr[l][i + 1] - row_ptr[l][i];
             if (d > 0 && levels[i] < l) return fail(h, HNSW_ERR_INVALID, "node has links above its level");
             if (d > kAuxWords - 2) return fail(h, HNSW_ERR_INVALID, "degree > 510 is not supported");
-            for (uint64_t e = row_ptr[l][i]; e < row_ptr[l][i + 1]; ++e)
+            for (uint64_t e = row_ptr[l][i]; e < row_ptr[l][i + 1]; ++e) {
                 if (col[l][e] >= n || col[l][e] == i) return fail(h, HNSW_ERR_INVALID, "neighbour id out of range (or a self link)");
+                if (levels[col[l][e]] < l) return fail(h, HNSW_ERR_INVALID, "link to a node that does not reach this layer");
+            }
             if (l == 0) md0 = std::max<uint32_t>(md0, (uint32_t)d);
             else mdU = std::max<uint32_t>(mdU, (uint32_t)d);
         }
+    }
     uint32_t ns0 = default_stride(h->m_max0, h->m, md0), nsU = default_stride(h->m_max, h->m, mdU);
     hnsw_status s;
     // (re)allocate at the right strides before any data lands
@@ -854,10 +890,8 @@ hnsw_status hnsw_import(hnsw_index *h, uint32_t n, const float *vectors, const u
     h->h_dead.assign(n, 0);
     h->n_dead = 0;
     uint32_t used = 0;
-    for (uint32_t i = 0; i < n; ++i) {
-        if (levels[i] >= kMaxLayers) return fail(h, HNSW_ERR_INVALID, "level too large");
+    for (uint32_t i = 0; i < n; ++i)
         if (levels[i] > 0) { h->h_upper_base[i] = used; used += levels[i]; }
-    }
     if ((s = ensure_upper_cap(h, std::max(used, 1u))) != HNSW_OK) return s;
     h->upper_used = used;
     HIP_TRY(h, hipMemcpyAsync(h->d_vec, vectors, (size_t)n * h->dim * 4, hipMemcpyHostToDevice, h->stream));
@@ -887,6 +921,27 @@ hnsw_status hnsw_import(hnsw_index *h, uint32_t n, const float *vectors, const u
     h->max_layer = levels[enterpoint];           // the enterpoint is the top node (core.rs:587-593)
     h->max_deg0 = md0;
     h->max_degU = mdU;
+    // Graphs the reference builds are symmetric (core.rs:770-772, 793-795); a fast-built one need not be.
+    // The exact insert / delete kernels must know (a missing back link is an error only on symmetric graphs).
+    {
+        DevScratch<unsigned long long> bad;
+        HIP_TRY(h, bad.alloc(1));
+        HIP_TRY(h, hipMemsetAsync(bad.p, 0, 8, h->stream));
+        const uint32_t blocks = (uint32_t)(((uint64_t)n * 64 + 255) / 256);
+        for (uint32_t l = 0; l < n_layers; ++l) {
+            if (l == 0)
+                hipLaunchKernelGGL(k_count_asymmetric, dim3(blocks), dim3(256), 0, h->stream, h->d_adj0, h->stride0,
+                                   (const uint32_t *)nullptr, 0u, h->d_levels, 0u, n, bad.p);
+            else
+                hipLaunchKernelGGL(k_count_asymmetric, dim3(blocks), dim3(256), 0, h->stream, h->d_adjU, h->strideU,
+                                   h->d_upper_base, l - 1, h->d_levels, l, n, bad.p);
+        }
+        HIP_TRY(h, hipGetLastError());
+        unsigned long long nbad = 0;
+        HIP_TRY(h, hipMemcpyAsync(&nbad, bad.p, 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        h->asymmetric = nbad != 0;
+    }
     return push_header(h);
 }
 
@@ -1080,10 +1135,25 @@ hnsw_status hnsw_deserialize(const void *buf, uint64_t bytes, uint64_t seed, int
     hnsw_index *h = *out;
     std::memcpy(h->rng, hd.rng, sizeof hd.rng);
     if (hd.n == 0) return HNSW_OK;
-    if ((uint64_t)(end - p) < pad8((uint64_t)hd.n * 4) + pad8(hd.n) + pad8((uint64_t)hd.n * hd.dim * 4)) return fail(h, HNSW_ERR_INVALID, "truncated snapshot");
+    // the blob is untrusted: every size is checked against what is left before it is used
+    const uint64_t left0 = (uint64_t)(end - p);
+    const uint64_t need0 = pad8((uint64_t)hd.n * 4) + pad8(hd.n) + pad8((uint64_t)hd.n * hd.dim * 4);
+    if (left0 < need0) return fail(h, HNSW_ERR_INVALID, "truncated snapshot");
+    if (hd.n_layers == 0 || hd.n_layers > kMaxLayers || hd.max_layer >= hd.n_layers || hd.n_dead > hd.n ||
+        hd.enterpoint >= (int64_t)hd.n || hd.enterpoint < -1)
+        return fail(h, HNSW_ERR_INVALID, "inconsistent snapshot header");
     const uint32_t *levels = reinterpret_cast<const uint32_t *>(p); p += pad8((uint64_t)hd.n * 4);
     const unsigned char *dead = p; p += pad8(hd.n);
     const float *vectors = reinterpret_cast<const float *>(p); p += pad8((uint64_t)hd.n * hd.dim * 4);
+    uint32_t dead_count = 0;
+    for (uint32_t i = 0; i < hd.n; ++i) {
+        if (dead[i] > 1) return fail(h, HNSW_ERR_INVALID, "bad tombstone byte");
+        dead_count += dead[i];
+    }
+    if (dead_count != hd.n_dead) return fail(h, HNSW_ERR_INVALID, "tombstone count does not match the header");
+    if ((hd.enterpoint < 0) != (hd.n_dead == hd.n)) return fail(h, HNSW_ERR_INVALID, "enterpoint / live count mismatch");
+    if (hd.enterpoint >= 0 && (dead[hd.enterpoint] || levels[hd.enterpoint] != hd.max_layer))
+        return fail(h, HNSW_ERR_INVALID, "the enterpoint must be a live node of the top layer");
     std::vector<const uint64_t *> rps(hd.n_layers);
     std::vector<const uint32_t *> cols(hd.n_layers);
     for (uint32_t l = 0; l < hd.n_layers; ++l) {
@@ -1091,16 +1161,28 @@ hnsw_status hnsw_deserialize(const void *buf, uint64_t bytes, uint64_t seed, int
         uint64_t nnz;
         std::memcpy(&nnz, p, 8); p += 8;
         rps[l] = reinterpret_cast<const uint64_t *>(p); p += ((size_t)hd.n + 1) * 8;
-        if ((uint64_t)(end - p) < pad8(nnz * 4)) return fail(h, HNSW_ERR_INVALID, "truncated snapshot");
+        if (nnz > (uint64_t)(end - p) / 4 || rps[l][hd.n] != nnz) return fail(h, HNSW_ERR_INVALID, "truncated snapshot (layer)");
         cols[l] = reinterpret_cast<const uint32_t *>(p); p += pad8(nnz * 4);
+        if (p > end) return fail(h, HNSW_ERR_INVALID, "truncated snapshot (padding)");
     }
-    // an index whose every node was deleted has no enterpoint: import a placeholder, then fix up
-    int64_t ep = hd.enterpoint;
-    if (ep < 0) {
-        ep = 0;
+    // hnsw_import wants the enterpoint on the top layer.  Tombstones keep their level, which can be above the
+    // live graph's top (the enterpoint was deleted and a lower node elected, core.rs:449-472): import with the
+    // highest node as a placeholder and empty rows for the layers only tombstones reach, then fix up.
+    int64_t ep = 0;
+    uint32_t top = 0;
+    for (uint32_t i = 0; i < hd.n; ++i) {
+        if (levels[i] >= kMaxLayers) return fail(h, HNSW_ERR_INVALID, "level too large");
+        if (levels[i] > top) { top = levels[i]; ep = i; }
+        if (!dead[i] && levels[i] > hd.max_layer) return fail(h, HNSW_ERR_INVALID, "live node above max_layer");
     }
-    // hnsw_import derives max_layer from the enterpoint's level; a deleted enterpoint cannot occur
-    if ((s = hnsw_import(h, hd.n, vectors, levels, ep, hd.n_layers ? hd.n_layers : 1, rps.data(), cols.data())) != HNSW_OK) return s;
+    if (hd.enterpoint >= 0 && levels[hd.enterpoint] == top) ep = hd.enterpoint;
+    std::vector<uint64_t> zero_rp;
+    if (top + 1 > hd.n_layers) {
+        zero_rp.assign((size_t)hd.n + 1, 0);
+        rps.resize(top + 1, zero_rp.data());
+        cols.resize(top + 1, nullptr);
+    }
+    if ((s = hnsw_import(h, hd.n, vectors, levels, ep, (uint32_t)rps.size(), rps.data(), cols.data())) != HNSW_OK) return s;
     h->h_dead.assign(dead, dead + hd.n);
     h->n_dead = hd.n_dead;
     h->enterpoint = hd.enterpoint;

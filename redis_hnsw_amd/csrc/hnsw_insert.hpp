@@ -303,6 +303,9 @@ __global__ __launch_bounds__(64, 1) void k_insert_commit_exact(GraphView g, uint
     vis.bounded = false;
     vis.lossy = false;
 
+    // the plan failed (its visited set outgrew even the HBM table): nothing is linked, the host reports it
+    if (g.hdr->status & (ST_VISITED_OVERFLOW | ST_ROW_OVERFLOW)) return;
+
     WorkCtr ctr = {};
     uint32_t skipped = 0;  // econn evaluations the reference makes but whose result it never uses (:549-557 when deg <= m_max)
     uint32_t nt = 0;

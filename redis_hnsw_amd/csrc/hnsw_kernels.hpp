@@ -184,6 +184,71 @@ __global__ void k_restride(const uint32_t *__restrict__ src, uint32_t sstride, u
     for (uint32_t i = lane; i < dstride; i += 64) d[i] = i < n ? s[i] : 0u;
 }
 
+// HNSW.NODE.DEL on a graph with one-directional links (fast build): k_delete_exact walks the deleted
+// node's own rows, which finds every neighbour only if links are symmetric (core.rs:770-772 keeps the
+// reference's so).  This pass removes what is left of `id` from every row of a table, keeping the stored
+// order.  One wave per row.
+__global__ void k_purge_inbound(uint32_t *adj, uint32_t stride, uint64_t rows, uint32_t id, uint32_t *n_removed)
+{
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= rows) return;
+    uint32_t *row = adj + wave * stride;
+    uint32_t cnt = row[0];
+    if (cnt > stride - 1) cnt = stride - 1;
+    uint32_t kept = 0, removed = 0;
+    for (uint32_t base = 0; base < cnt; base += 64) {
+        const uint32_t i = base + lane;
+        const uint32_t x = i < cnt ? row[1 + i] : kEmpty;
+        const bool keep = i < cnt && x != id;
+        const uint64_t kb = __ballot(keep);
+        removed += (uint32_t)__popcll(__ballot(i < cnt && x == id));
+        // in-place compaction is safe: destinations never pass the chunk being read
+        if (keep && removed) row[1 + kept + __popcll(kb & ((1ull << lane) - 1ull))] = x;
+        kept += (uint32_t)__popcll(kb);
+    }
+    if (removed && lane == 0) { row[0] = kept; atomicAdd(n_removed, removed); }
+}
+
+// number of links i -> j whose reverse j -> i is missing (0 for every graph the reference can produce)
+__global__ void k_count_asymmetric(const uint32_t *__restrict__ adj, uint32_t stride,
+                                   const uint32_t *__restrict__ slot_of_node, uint32_t layer_off,
+                                   const uint32_t *__restrict__ levels, uint32_t layer, uint32_t n,
+                                   unsigned long long *__restrict__ out)
+{
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= n || levels[wave] < layer) return;
+    const uint32_t slot = slot_of_node ? slot_of_node[wave] : wave;
+    if (slot_of_node && slot == kNoUpper) return;
+    const uint32_t *row = adj + (size_t)(slot + layer_off) * stride;
+    uint32_t cnt = row[0];
+    if (cnt > stride - 1) cnt = stride - 1;
+    uint32_t bad = 0;
+    for (uint32_t a = 0; a < cnt; ++a) {
+        const uint32_t j = row[1 + a];
+        bool found = false;
+        if (j < n && levels[j] >= layer) {
+            const uint32_t js = slot_of_node ? slot_of_node[j] : j;
+            if (!(slot_of_node && js == kNoUpper)) {
+                const uint32_t *jr = adj + (size_t)(js + layer_off) * stride;
+                uint32_t jc = jr[0];
+                if (jc > stride - 1) jc = stride - 1;
+                for (uint32_t b = lane; b < jc; b += 64) found |= jr[1 + b] == wave;
+            }
+        }
+        if (!__ballot(found)) ++bad;
+    }
+    if (bad && lane == 0) atomicAdd(out, (unsigned long long)bad);
+}
+
+// -inf fill (similarities of an empty result)
+__global__ void k_fill_f32(float *p, size_t n, float v)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
 // per-row degrees of one layer (export)
 __global__ void k_degrees(const uint32_t *__restrict__ adj, uint32_t stride, const uint32_t *__restrict__ slot_of_node,
                           uint32_t layer_off, const uint32_t *__restrict__ levels, uint32_t layer, uint32_t n,

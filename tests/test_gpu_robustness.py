@@ -1,0 +1,180 @@
+"""GPU tests of the behaviour around the hot path: deletes on fast-built graphs, per-call device status,
+untrusted snapshots, drawn levels, snapshots continued against the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.util import graphs_equal, make_data
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from redis_hnsw_amd import index as idxmod
+    return idxmod
+
+
+def test_delete_after_fast_build_leaves_no_inbound_links(eng):
+    """The fast build prunes one-directionally, so a deleted node can still be pointed at by rows that are
+    not among its own neighbours: HNSW.NODE.DEL sweeps those links too and searches never return it."""
+    n, dim, m, ef, k = 6000, 32, 8, 64, 10
+    V = make_data(n, dim, seed=11)
+    gi = eng.Index("foo", dim, m, ef)
+    gi.set_tuning("fast_seed", 128)
+    gi.add_batch(V, mode="fast")
+    Q = make_data(200, dim, seed=2)
+    ids0, _, _ = gi.search_batch(Q, k)
+    # delete the most frequently returned nodes (the hubs: the ones most rows point at)
+    uniq, cnt = np.unique(ids0.ravel(), return_counts=True)
+    victims = [int(x) for x in uniq[np.argsort(-cnt)][:150]]
+    for v in victims:
+        gi.delete_node("node%d" % v)
+    g = gi.export_graph()
+    dead = set(victims)
+    for col in g["col"]:
+        assert not (set(col.tolist()) & dead), "a row still points at a deleted node"
+    ids1, sims1, n1 = gi.search_batch(Q, k)
+    assert not (set(ids1[ids1 != 0xFFFFFFFF].tolist()) & dead)
+    assert np.all(n1 == k)
+    # and the index keeps working in the reference's exact mode afterwards
+    W = make_data(40, dim, seed=12)
+    for i in range(40):
+        gi.add_node("late%d" % i, W[i])
+    ids2, _, _ = gi.search_batch(W, 1)
+    assert gi.node_count == n - len(victims) + 40
+    assert not (set(ids2.ravel().tolist()) & dead)
+    gi.close()
+
+
+def test_status_is_per_call_and_reimported_fast_graph_accepts_exact_ops(eng):
+    """A fast-built graph that is exported and imported again (what a replica does) is recognised as having
+    one-directional links; exact adds and deletes on it succeed and keep host names and engine ids in step."""
+    n, dim, m, ef = 4000, 32, 8, 64
+    V = make_data(n + 50, dim, seed=21)
+    a = eng.Index("a", dim, m, ef)
+    a.set_tuning("fast_seed", 128)
+    a.add_batch(V[:n], mode="fast")
+    g = a.export_graph()
+    g["vectors"] = V[:n]
+    b = eng.Index("b", dim, m, ef)
+    b.import_graph(g)
+    for i in range(n, n + 50):
+        b.add_node("x%d" % i, V[i])                        # used to trip ST_ASYMMETRIC for good
+    for i in range(0, 300, 7):
+        b.delete_node("node%d" % i)
+    for i in range(10):
+        b.add_node("y%d" % i, V[i] + 0.5)
+    assert b.node_count == n + 50 - len(range(0, 300, 7)) + 10
+    ids, _, n_out = b.search_batch(V[n:n + 50], 1)
+    assert np.array_equal(ids[:, 0], np.arange(n, n + 50))   # every late node finds itself
+    r = b.search_knn(V[n + 3], 1)
+    assert r[0].name == "x%d" % (n + 3)
+    a.close(); b.close()
+
+
+def test_corrupt_snapshots_are_rejected(eng):
+    n, dim, m, ef = 300, 16, 5, 16
+    V = make_data(n, dim, seed=31)
+    a = eng.Index("s", dim, m, ef, seed=4)
+    for i in range(n):
+        a.add_node("n%d" % i, V[i])
+    blob = bytearray(a.serialize())
+    good = eng.Index.deserialize(bytes(blob))
+    assert good.node_count == n
+    good.close()
+    nsnap = int.from_bytes(blob[:8], "little")
+    hdr = 8                                   # [u64 length][SnapHeader ...]
+    # SnapHeader: magic[8], version, dim, m, efc, n, n_dead, max_layer, n_layers, enterpoint(i64), rng[4]
+    off = {"n": hdr + 8 + 16, "n_dead": hdr + 8 + 20, "max_layer": hdr + 8 + 24, "n_layers": hdr + 8 + 28,
+           "enterpoint": hdr + 8 + 32}
+
+    def mutated(field, value, width=4):
+        b = bytearray(blob)
+        b[off[field]:off[field] + width] = int(value).to_bytes(width, "little", signed=value < 0)
+        return bytes(b)
+
+    bad = [mutated("max_layer", 31), mutated("n_layers", 99), mutated("n_dead", 5), mutated("enterpoint", n + 7, 8),
+           mutated("n", n + 1000), (nsnap // 2).to_bytes(8, "little") + bytes(blob[8:8 + nsnap // 2]) + bytes(blob[8 + nsnap:])]
+    # a row_ptr that runs backwards (first layer's table starts after levels, tombstones, vectors)
+    pad8 = lambda x: (x + 7) & ~7
+    rp0 = hdr + 80 + pad8(n * 4) + pad8(n) + pad8(n * dim * 4) + 8
+    b2 = bytearray(blob)
+    b2[rp0 + 8 * 5:rp0 + 8 * 6] = (1 << 40).to_bytes(8, "little")
+    bad.append(bytes(b2))
+    for i, bb in enumerate(bad):
+        with pytest.raises(eng.HNSWError):
+            eng.Index.deserialize(bb)
+    a.close()
+
+
+def test_empty_index_device_search_pads_with_minus_inf(eng):
+    import torch
+    gi = eng.Index("e", 32, 5, 16)
+    dev = torch.device("cuda", 0)
+    q = torch.zeros((4, 32), dtype=torch.float32, device=dev)
+    ids = torch.zeros((4, 3), dtype=torch.int32, device=dev)
+    sims = torch.zeros((4, 3), dtype=torch.float32, device=dev)
+    nn = torch.ones(4, dtype=torch.int32, device=dev)
+    gi.search_batch_device(q.data_ptr(), 4, 3, ids.data_ptr(), sims.data_ptr(), nn.data_ptr(),
+                           torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert nn.cpu().tolist() == [0, 0, 0, 0]                           # core.rs:481-483: not an error
+    assert np.all(np.isneginf(sims.cpu().numpy()))
+    assert np.all(ids.cpu().numpy().view(np.uint32) == 0xFFFFFFFF)
+    gi.close()
+
+
+@pytest.mark.parametrize("seed", [0, 7, 123456789])
+def test_engine_and_oracle_draw_the_same_levels(eng, oracle_mod, seed):
+    """level = floor(-ln U / ln m) (core.rs:601-605) from the same seeded generator on both sides: letting both
+    DRAW (no explicit levels) must end in identical graphs."""
+    n, dim, m, ef = 500, 32, 4, 24
+    V = make_data(n, dim, seed=41)
+    o = oracle_mod.OracleIndex(dim, m, ef, seed=seed)
+    gi = eng.Index("d", dim, m, ef, seed=seed)
+    for i in range(n):
+        o.add(V[i])                                          # level = -1: draw
+        gi.add_node("n%d" % i, V[i])
+    go, gg = o.export(), gi.export_graph()
+    assert go["max_layer"] >= 2                              # m = 4: several layers are in play
+    ok, why = graphs_equal(go, gg)
+    assert ok, why
+    gi.close()
+
+
+def test_snapshot_restored_engine_continues_like_the_oracle(eng, oracle_mod):
+    """Restore from a snapshot (with tombstones, including a deleted enterpoint), then keep inserting and
+    deleting: the restored engine must stay identical to the ORACLE that never stopped."""
+    n, dim, m, ef = 500, 32, 5, 24
+    V = make_data(n + 120, dim, seed=51)
+    lv = oracle_mod.draw_levels(n + 120, m, 3)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    a = eng.Index("snap", dim, m, ef)
+    o.add_batch(V[:n], lv[:n])
+    a.add_batch(V[:n], levels=lv[:n], mode="exact")
+    for i in (5, 99, o.enterpoint, 301):
+        o.delete(int(i))
+        a.delete_node("node%d" % i)
+    b = eng.Index.deserialize(a.serialize())
+    a.close()
+    ok, why = graphs_equal(o.export(), b.export_graph())
+    assert ok, why
+    for i in range(n, n + 120):
+        o.add(V[i], int(lv[i]))
+        b.add_node("node%d" % i, V[i], level=int(lv[i]))
+        if i % 10 == 0:
+            o.delete(i - 7)
+            b.delete_node("node%d" % (i - 7))
+    ok, why = graphs_equal(o.export(), b.export_graph())
+    assert ok, why
+    Q = make_data(40, dim, seed=2)
+    ids, sims, n_out = b.search_batch(Q, 5)
+    oids, osims, on, _ = o.search_batch(Q, 5)
+    assert np.array_equal(n_out, on) and np.array_equal(ids, oids) and np.array_equal(_bits(sims), _bits(osims))
+    b.close()
