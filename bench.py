@@ -1,11 +1,21 @@
 #!/usr/bin/env python3
-"""bench.py -- HNSW.SEARCH throughput of the MI355X engine on BASELINE.json's
-headline configuration (C2: 1M x 128 f32, M=16, ef=200, k=10, 1024-query batches).
+"""bench.py -- HNSW.SEARCH throughput of the MI355X engine on BASELINE.json's headline configuration
+(C2: 1M x 128 f32, M=16, ef=200, k=10, 1024-query batches).
 
-A step = one pass of the hot path (hnsw_search_batch_device) over one batch of
-queries already resident in HBM.  One process per GPU; the index is replicated,
-every rank serves its own batch (weak scaling) and the [B,k] results are
-all-gathered over RCCL.  Prints ONE JSON line on rank 0.
+A step = one pass of the hot path (hnsw_search_batch_device = one k_search launch) over one batch of
+1024 queries already resident in HBM.  Consecutive steps are issued round-robin on `--streams` HIP streams
+(default 2), so two batches are in flight at a time -- a lone 1024-query launch puts one wavefront on each
+SIMD, and a SIMD needs two to keep issuing.  One process per GPU; the index is
+replicated, every rank serves its own batches (weak scaling) and the [B,k] results are all-gathered over
+RCCL.  Prints ONE JSON line on rank 0.
+
+The graph the headline runs on (--graph):
+  reference  the REFERENCE-ORDER graph (core.rs:489-599, one insert after the other): read from the fixture
+             data/c2_ref_graph_1m.npz that tests/fixtures/make_ref_graph.py writes (the CPU oracle's serial
+             build of the same seeded vectors and levels, ~35 min on one core -- too long to repeat inside
+             a bench run), imported through hnsw_import.  Default when the fixture is present.
+  exact      built here on the GPU in the reference's order (hnsw_add_batch mode 0).
+  fast       the batched GPU build (hnsw_add_batch mode 1): not the reference's graph, recall parity only.
 """
 import argparse
 import json
@@ -20,6 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+FIXTURES = {(1_000_000, 128, 16, 200): os.path.join(ROOT, "data", "c2_ref_graph_1m.npz")}
 
 
 def draw_levels(n, m, seed=7):
@@ -46,6 +57,51 @@ def brute_force_gt(torch, V_dev, Q_dev, k):
         d = vn[None, :] - 2.0 * (q @ V_dev.T)
         out.append(d.topk(k, dim=1, largest=False).indices)
     return torch.cat(out).cpu().numpy()
+
+
+def load_graph_fixture(path, V):
+    """levels / enterpoint / per-layer CSR written by tests/fixtures/make_ref_graph.py (+ this run's vectors)"""
+    z = np.load(path)
+    n = int(z["nodes"])
+    row_ptr, col = [], []
+    for l in range(int(z["max_layer"]) + 1):
+        rp = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(z["deg%d" % l].astype(np.uint64), out=rp[1:])
+        row_ptr.append(rp)
+        col.append(z["col%d" % l].astype(np.uint32))
+    return dict(vectors=V[:n], levels=z["levels"].astype(np.uint32), enterpoint=int(z["enterpoint"]),
+                max_layer=int(z["max_layer"]), row_ptr=row_ptr, col=col), float(z["build_seconds"])
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def usable_cores():
+    """host threads this process may really use: the affinity mask, capped by the cgroup CPU quota
+    (a container that sees 256 CPUs but has a 16-CPU quota is throttled beyond 16 busy threads)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
 
 
 def spawn_ranks(args):
@@ -85,10 +141,12 @@ def main():
     ap.add_argument("--ef", type=int, default=200)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--streams", type=int, default=2, help="steps in flight (HIP streams used round-robin)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clustered", action="store_true")
-    ap.add_argument("--build", default="fast", choices=["fast", "exact"])
+    ap.add_argument("--no-extras", action="store_true", help="skip the informational legs (large batch, fast build, C1)")
+    ap.add_argument("--graph", "--build", dest="graph", default="auto", choices=["auto", "reference", "exact", "fast"])
     ap.add_argument("--verify-gather", action="store_true",
                     help="N>1: rank 0 re-runs every rank's first batch on its own replica and compares with the gathered result")
     args = ap.parse_args()
@@ -123,8 +181,9 @@ def main():
             print("[bench %.1fs] %s" % (time.time() - t00, msg), file=sys.stderr, flush=True)
 
     t00 = time.time()
-    from redis_hnsw_amd import Index
+    from redis_hnsw_amd import Index, shard
     N, dim, M, ef, k, B = args.nodes, args.dim, args.m, args.ef, args.k, args.batch
+    S = max(1, args.streams)
     cfg_is_c2 = (N, dim, M, ef, k, B) == (1_000_000, 128, 16, 200, 10, 1024)
     t0 = time.time()
     V = np.random.default_rng(1).random((N, dim), dtype=np.float32)
@@ -132,80 +191,96 @@ def main():
     Qall = np.random.default_rng(2).random((n_qbatches * B * world, dim), dtype=np.float32)
     levels = draw_levels(N, M, 7)
 
-    # ---- build (HNSW.NODE.ADD on the GPU), replicate ---------------------------------
+    # ---- the graph -------------------------------------------------------------------
+    fixture = FIXTURES.get((N, dim, M, ef))
+    mode = args.graph
+    if mode == "auto":
+        mode = "reference" if fixture and os.path.exists(fixture) else "fast"
+    if mode == "reference" and not (fixture and os.path.exists(fixture)):
+        raise SystemExit("--graph reference needs %s (python tests/fixtures/make_ref_graph.py --out ...)" % fixture)
     index = Index("bench", dim, M, ef, device=local_rank)
+    index.set_tuning("launch_concurrency", S)
     graph = None
     t_build = None
-    if rank == 0:
+    graph_desc = {"reference": "reference-order (serial core.rs:489-599 order; fixture built by the CPU oracle, imported with hnsw_import)",
+                  "exact": "reference-order, built on the GPU (hnsw_add_batch mode 0)",
+                  "fast": "batched GPU build (hnsw_add_batch mode 1; NOT the reference's graph)"}[mode]
+    if mode == "reference":
+        # every rank reads the fixture itself: the one-time index distribution of a deployment
+        graph, oracle_build_s = load_graph_fixture(fixture, V)
         tb = time.time()
-        index.add_batch(V, levels=levels, mode=args.build)
+        index.import_graph(graph)
         torch.cuda.synchronize()
-        t_build = time.time() - tb
-        log("built %d nodes in %.2f s (%s)" % (N, t_build, args.build))
-        if world > 1 or not args.no_cpu_baseline:
-            graph = index.export_graph(with_vectors=False)
-    if world > 1:
-        # one-time index distribution: rank 0's graph to every replica over RCCL
-        from redis_hnsw_amd import shard
-        g = shard.broadcast_graph(dist, graph, N, src=0, device=coll_dev)
-        if rank != 0:
-            g["vectors"] = V
-            index.import_graph(g)
-        dist.barrier()
+        log("imported the reference-order graph (%d nodes) in %.2f s" % (N, time.time() - tb))
+    else:
+        if rank == 0:
+            tb = time.time()
+            index.add_batch(V, levels=levels, mode=mode)
+            torch.cuda.synchronize()
+            t_build = time.time() - tb
+            log("built %d nodes in %.2f s (%s)" % (N, t_build, mode))
+            if world > 1 or not args.no_cpu_baseline:
+                graph = index.export_graph(with_vectors=False)
+        if world > 1:
+            # one-time index distribution: rank 0's graph to every replica over RCCL
+            g = shard.broadcast_graph(dist, graph, N, src=0, device=coll_dev)
+            if rank != 0:
+                g["vectors"] = V
+                index.import_graph(g)
+            dist.barrier()
 
     # ---- device-resident inputs/outputs ---------------------------------------------
     dev = torch.device("cuda", local_rank)
     myQ = torch.from_numpy(Qall[rank * n_qbatches * B:(rank + 1) * n_qbatches * B]).to(dev)
+    streams = [torch.cuda.Stream() for _ in range(S)]
     # ids and similarities share one buffer so that a single all-gather moves both
-    d_out = torch.empty((2, B, k), dtype=torch.int32, device=dev)
-    d_ids = d_out[0]
-    d_sims = d_out[1].view(torch.float32)
-    d_n = torch.empty((B,), dtype=torch.int32, device=dev)
-    g_out = torch.empty((world * 2, B, k), dtype=torch.int32, device=coll_dev) if world > 1 else None
-    stream = torch.cuda.current_stream()
+    bufs = [torch.empty((2, B, k), dtype=torch.int32, device=dev) for _ in range(S)]
+    d_ns = [torch.empty((B,), dtype=torch.int32, device=dev) for _ in range(S)]
+    d_out = bufs[0]
+    d_ids, d_sims, d_n = d_out[0], d_out[1].view(torch.float32), d_ns[0]
+    cur = torch.cuda.current_stream()
 
-    # N > 1: the gather of step i runs on its own stream while step i+1 searches (two result buffers)
-    overlap = world > 1
-    if overlap:
+    # N > 1: the gather of step i runs on its own stream while later steps search
+    if world > 1:
         comm_stream = torch.cuda.Stream()
-        bufs = [d_out, torch.empty_like(d_out)]
-        gouts = [g_out, torch.empty_like(g_out)]
-        ready = [torch.cuda.Event(), torch.cuda.Event()]
-        gathered = [torch.cuda.Event(), torch.cuda.Event()]
+        gouts = [torch.empty((world * 2, B, k), dtype=torch.int32, device=coll_dev) for _ in range(S)]
+        ready = [torch.cuda.Event() for _ in range(S)]
+        gathered = [torch.cuda.Event() for _ in range(S)]
 
     def step(i):
         q = myQ[(i % n_qbatches) * B:(i % n_qbatches + 1) * B]
-        if not overlap:
-            index.search_batch_device(q.data_ptr(), B, k, d_ids.data_ptr(), d_sims.data_ptr(), d_n.data_ptr(),
-                                      stream.cuda_stream)
-            return
-        s_ = i % 2
-        buf = bufs[s_]
-        if i >= 2:
-            stream.wait_event(gathered[s_])          # the gather that last read this buffer is done
-        index.search_batch_device(q.data_ptr(), B, k, buf[0].data_ptr(), buf[1].data_ptr(), d_n.data_ptr(),
-                                  stream.cuda_stream)
-        ready[s_].record(stream)
-        with torch.cuda.stream(comm_stream):
-            comm_stream.wait_event(ready[s_])
-            # the path's one real exchange: gather every shard's top-k (host copies in the gloo test mode)
-            shard.gather_packed(dist, buf if backend == "nccl" else buf.cpu(), world, gouts[s_])
-            gathered[s_].record(comm_stream)
+        s_ = i % S
+        st, buf = streams[s_], bufs[s_]
+        if world > 1 and i >= S:
+            st.wait_event(gathered[s_])              # the gather that last read this buffer is done
+        index.search_batch_device(q.data_ptr(), B, k, buf[0].data_ptr(), buf[1].data_ptr(), d_ns[s_].data_ptr(),
+                                  st.cuda_stream)
+        if world > 1:
+            ready[s_].record(st)
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(ready[s_])
+                # the path's one real exchange: gather every shard's top-k (host copies in the gloo test mode)
+                shard.gather_packed(dist, buf if backend == "nccl" else buf.cpu(), world, gouts[s_])
+                gathered[s_].record(comm_stream)
 
     log("inputs resident; warm-up")
-    for i in range(args.warmup):
+    for i in range(max(args.warmup, 0)):
         step(i)
     torch.cuda.synchronize()
     index.reset_counters()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
+    per_stream = [len(range(s_, args.steps, S)) for s_ in range(S)]
     t_start = time.perf_counter()
-    ev0.record(stream)
+    for s_ in range(S):
+        ev0[s_].record(streams[s_])
     for i in range(args.steps):
         step(args.warmup + i)
-    ev1.record(stream)
+    for s_ in range(S):
+        ev1[s_].record(streams[s_])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -214,12 +289,17 @@ def main():
         tt = torch.tensor([t_wall], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_wall = float(tt.item())
-    stream_ms = ev0.elapsed_time(ev1)
+    # average duration of ONE k_search launch: launches on a stream run back to back, so the stream's
+    # elapsed time / its launches (what rocprofv3 --kernel-trace reports as the kernel's average)
+    kernel_ms = float(np.mean([ev0[s_].elapsed_time(ev1[s_]) / per_stream[s_] for s_ in range(S) if per_stream[s_]]))
+    log("timed region done: %.3f ms/step, %.3f ms per launch with %d in flight" % (1e3 * t_wall / args.steps, kernel_ms, S))
+    sc, _ = index.counters()
+
     gather_ok = None
     if world > 1 and args.verify_gather:
         # every rank searches its first batch, one gather; rank 0 repeats all of them on its own replica
         index.search_batch_device(myQ[:B].data_ptr(), B, k, d_ids.data_ptr(), d_sims.data_ptr(), d_n.data_ptr(),
-                                  stream.cuda_stream)
+                                  cur.cuda_stream)
         torch.cuda.synchronize()
         got = shard.gather_packed(dist, d_out if backend == "nccl" else d_out.cpu(), world).cpu().numpy()
         if rank == 0:
@@ -227,12 +307,30 @@ def main():
             for r in range(world):
                 q = torch.from_numpy(Qall[r * n_qbatches * B:r * n_qbatches * B + B]).to(dev)
                 index.search_batch_device(q.data_ptr(), B, k, d_ids.data_ptr(), d_sims.data_ptr(), d_n.data_ptr(),
-                                          stream.cuda_stream)
+                                          cur.cuda_stream)
                 torch.cuda.synchronize()
                 gather_ok = gather_ok and bool(np.array_equal(got[r], d_out.cpu().numpy()))
             log("gathered == unsharded: %s" % gather_ok)
-    log("timed region done: %.3f ms/step" % (1e3 * t_wall / args.steps))
-    sc, _ = index.counters()
+
+    def search_now(q_dev, nq):
+        index.search_batch_device(q_dev.data_ptr(), nq, k, d_ids.data_ptr(), d_sims.data_ptr(), d_n.data_ptr(), cur.cuda_stream)
+        torch.cuda.synchronize()
+
+    # ---- exact work counters of the timed batches (one launch at a time, nothing forgotten) -------
+    # With several launches sharing the CUs the LDS visited table is the bounded one: a
+    # re-met node may be evaluated twice, so the timed region's n_dist can exceed the reference's.  The
+    # algorithmic bytes are the reference's: count them in a pass where the table holds everything.
+    index.set_tuning("launch_concurrency", 1)
+    index.set_tuning("waves_per_cu", 4)
+    index.reset_counters()
+    nb_exact = min(n_qbatches, args.steps)
+    for b in range(nb_exact):
+        search_now(myQ[b * B:(b + 1) * B], B)
+    sx, _ = index.counters()
+    index.set_tuning("waves_per_cu", 8)
+    index.set_tuning("launch_concurrency", S)
+    n_dist_q, n_ids_q, n_exp_q = sx.n_dist / (nb_exact * B), sx.n_ids / (nb_exact * B), sx.n_expand / (nb_exact * B)
+    redo = sc.n_dist / (args.steps * B) / n_dist_q - 1.0 if args.steps else 0.0
 
     # ---- recall@k against brute force (rank 0's batches) ------------------------------
     recall = None
@@ -242,9 +340,7 @@ def main():
         hits = tot = 0
         for b in range(nb):
             q = myQ[b * B:(b + 1) * B]
-            index.search_batch_device(q.data_ptr(), B, k, d_ids.data_ptr(), d_sims.data_ptr(), d_n.data_ptr(),
-                                      stream.cuda_stream)
-            torch.cuda.synchronize()
+            search_now(q, B)
             got = d_ids.cpu().numpy().astype(np.int64)
             gt = brute_force_gt(torch, V_dev, q, k)
             for a, bb in zip(got, gt):
@@ -260,28 +356,73 @@ def main():
             dist.destroy_process_group()
         return
 
+    extras = world == 1 and not args.no_extras
+    # ---- informational: one large batch in one launch (the kernel alone on the GPU, 8 waves per CU) ----
+    big = None
+    if extras:
+        Bb = 4096
+        Qb = torch.from_numpy(np.random.default_rng(5).random((Bb, dim), dtype=np.float32)).to(dev)
+        bi = torch.empty((Bb, k), dtype=torch.int32, device=dev)
+        bs = torch.empty((Bb, k), dtype=torch.float32, device=dev)
+        bn = torch.empty((Bb,), dtype=torch.int32, device=dev)
+        index.set_tuning("launch_concurrency", 1)
+        for _ in range(2):
+            index.search_batch_device(Qb.data_ptr(), Bb, k, bi.data_ptr(), bs.data_ptr(), bn.data_ptr(), cur.cuda_stream)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        e0.record(cur)
+        for _ in range(reps):
+            index.search_batch_device(Qb.data_ptr(), Bb, k, bi.data_ptr(), bs.data_ptr(), bn.data_ptr(), cur.cuda_stream)
+        e1.record(cur)
+        torch.cuda.synchronize()
+        msb = e0.elapsed_time(e1) / reps
+        byb = Bb * (n_dist_q * 4 * dim + n_ids_q * 4 + 4 * dim + 8 * k)
+        big = dict(batch=Bb, launches_in_flight=1, kernel_ms=round(msb, 4), value=round(Bb / msb * 1e3, 1), unit="queries/s",
+                   achieved=round(byb / (msb * 1e-3) / 1e9, 1), frac=round(byb / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+        index.set_tuning("launch_concurrency", S)
+        log("one %d-query launch: %.3f ms, %.0f GB/s" % (Bb, msb, big["achieved"]))
+
     # ---- informational: the same configuration on clustered data, where the reference algorithm's
-    # recall is high enough for recall parity to mean something (uniform 128-d: 0.27 at 1 M)
+    # recall is high enough for recall parity to mean something (uniform 128-d: 0.22-0.27 at 1 M)
     clus = None
-    if cfg_is_c2 and not args.no_clustered and world == 1:
+    fast_build = None
+    if cfg_is_c2 and extras:
+        tb = time.time()
+        ifast = Index("bench-fast", dim, M, ef, device=local_rank)
+        ifast.add_batch(V, levels=levels, mode="fast")
+        torch.cuda.synchronize()
+        tfb = time.time() - tb
+        ifast.search_batch_device(myQ[:B].data_ptr(), B, k, d_ids.data_ptr(), d_sims.data_ptr(), d_n.data_ptr(), cur.cuda_stream)
+        torch.cuda.synchronize()
+        V_dev = torch.from_numpy(V).to(dev)
+        gotf = d_ids.cpu().numpy().astype(np.int64)
+        gtf = brute_force_gt(torch, V_dev, myQ[:B], k)
+        del V_dev
+        fast_build = dict(build_seconds=round(tfb, 2), inserts_per_s=round(N / tfb, 1),
+                          recall_at_10=round(sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(gotf, gtf)) / (B * k), 4),
+                          note="hnsw_add_batch mode 1 (batched GPU build, BASELINE config 5): not the reference's insert order")
+        ifast.close()
+        log("fast GPU build: %.2f s, recall@10 %.4f" % (tfb, fast_build["recall_at_10"]))
+    if cfg_is_c2 and extras and not args.no_clustered:
         centers = np.random.default_rng(3).random((64, dim), dtype=np.float32)
         Vc = clustered(N, dim, 3, centers)
         Qc = torch.from_numpy(clustered(B, dim, 4, centers)).to(dev)
         ic = Index("bench-clustered", dim, M, ef, device=local_rank)
-        ic.add_batch(Vc, levels=levels, mode=args.build)
+        ic.add_batch(Vc, levels=levels, mode="fast")
         for _ in range(2):
-            ic.search_batch_device(Qc.data_ptr(), B, k, d_ids.data_ptr(), d_sims.data_ptr(), d_n.data_ptr(), stream.cuda_stream)
+            ic.search_batch_device(Qc.data_ptr(), B, k, d_ids.data_ptr(), d_sims.data_ptr(), d_n.data_ptr(), cur.cuda_stream)
         torch.cuda.synchronize()
         tc0 = time.perf_counter()
         for _ in range(5):
-            ic.search_batch_device(Qc.data_ptr(), B, k, d_ids.data_ptr(), d_sims.data_ptr(), d_n.data_ptr(), stream.cuda_stream)
+            ic.search_batch_device(Qc.data_ptr(), B, k, d_ids.data_ptr(), d_sims.data_ptr(), d_n.data_ptr(), cur.cuda_stream)
         torch.cuda.synchronize()
         tcl = (time.perf_counter() - tc0) / 5
         Vc_dev = torch.from_numpy(Vc).to(dev)
         gtc = brute_force_gt(torch, Vc_dev, Qc, k)
         gotc = d_ids.cpu().numpy().astype(np.int64)
         hit = sum(len(set(a.tolist()) & set(bb.tolist())) for a, bb in zip(gotc, gtc))
-        clus = dict(data="64-cluster Gaussian mixture, sigma 0.1", recall_at_10=round(hit / (B * k), 4),
+        clus = dict(data="64-cluster Gaussian mixture, sigma 0.1 (fast GPU build)", recall_at_10=round(hit / (B * k), 4),
                     value=round(B / tcl, 1), unit="queries/s")
         log("clustered data: recall@%d = %.4f, %.3f ms/step" % (k, hit / (B * k), 1e3 * tcl))
         del Vc_dev, Vc
@@ -296,28 +437,36 @@ def main():
     host_qps = 5 * B / (time.perf_counter() - th)
 
     # ---- roofline of the dominant kernel (k_search) -------------------------------------
-    launches = args.steps
-    bytes_per_launch = (sc.n_dist * 4 * dim + sc.n_ids * 4) / launches + B * (4 * dim + 8 * k)
-    kernel_ms = stream_ms / launches     # HIP events on the launch stream around the timed region
-    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    # algorithmic bytes per launch = B x (n_dist*4*dim + n_ids*4 + 4*dim + 8*k)  (SURVEY 8d), the reference's counts
+    bytes_per_launch = B * (n_dist_q * 4 * dim + n_ids_q * 4 + 4 * dim + 8 * k)
+    in_flight = min(S, args.steps) if args.steps else 1
+    per_launch = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    achieved = in_flight * per_launch            # the kernel runs `in_flight` launches at a time
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
     # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, see profiles/); null for other workloads
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        if all(tj["config"].get(kk) == vv for kk, vv in dict(nodes=N, dim=dim, M=M, ef=ef, k=k, batch=B).items()):
-            traffic = tj["k_search_hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
+        want = dict(nodes=N, dim=dim, M=M, ef=ef, k=k, batch=B, graph=mode, streams=S)
+        for ent in tj["entries"]:
+            if all(ent["config"].get(kk) == vv for kk, vv in want.items()):
+                traffic = ent["k_search_hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError, TypeError):
         pass
     roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                    kernel="k_search", kernel_ms=round(kernel_ms, 4),
+                    kernel="k_search", kernel_ms=round(kernel_ms, 4), launches_in_flight=in_flight,
+                    per_launch_gbs=round(per_launch, 1),
+                    note="achieved = launches_in_flight x algorithmic_bytes_per_launch / kernel_ms (average duration of one launch, HIP events per stream)",
                     algorithmic_bytes_per_launch=int(bytes_per_launch),
-                    n_dist_per_query=round(sc.n_dist / (launches * B), 1),
-                    n_ids_per_query=round(sc.n_ids / (launches * B), 1))
+                    n_dist_per_query=round(n_dist_q, 1), n_ids_per_query=round(n_ids_q, 1),
+                    n_expand_per_query=round(n_exp_q, 1),
+                    re_evaluated_fraction=round(max(redo, 0.0), 5),
+                    single_launch_4096=big)
 
     # ---- CPU baseline: the oracle (C restatement of the Rust path), bounded sample -------
     cpu = None
+    c1 = None
     if not args.no_cpu_baseline and world == 1:   # timed at N=1 only: the other ranks would idle in the barrier
         from oracle import oracle
         graph["vectors"] = V
@@ -334,7 +483,8 @@ def main():
             if time.perf_counter() - tc > args.cpu_seconds:
                 break
         t1 = time.perf_counter() - tc
-        cores = os.cpu_count() or 1
+        cores = usable_cores()
+        o.search_batch(Qs, k, threads=cores)               # starts the persistent workers
         tc = time.perf_counter()
         reps = 0
         while True:
@@ -345,7 +495,37 @@ def main():
         tN = time.perf_counter() - tc
         cpu = dict(value=round(done / t1, 1), unit="queries/s", cores=1, kind="port",
                    sample="%d queries of the same 1024-query batch on the same graph, 1 thread, %.1f s" % (done, t1),
-                   all_cores=dict(value=round(reps * B / tN, 1), cores=cores))
+                   cpu_model=cpu_model(),
+                   all_cores=dict(value=round(reps * B / tN, 1), cores=cores, visible_cpus=os.cpu_count(),
+                                  sample="%d passes over the batch, persistent workers with per-thread scratch; "
+                                         "cores = affinity mask capped by the cgroup CPU quota" % reps))
+        o.close()
+        # ---- C1 (BASELINE config 1): 10k x 128, M=5, ef=200, k=10, ONE query per call (the shape of a
+        # HNSW.SEARCH command): hnsw_search latency, host buffers in and out, beside the oracle's
+        if extras:
+            n1, m1 = 10_000, 5
+            lv1 = draw_levels(n1, m1, 7)
+            o1 = oracle.OracleIndex(dim, m1, ef)
+            o1.add_batch(V[:n1], lv1)
+            g1 = Index("c1", dim, m1, ef, device=local_rank)
+            g1.import_graph(o1.export())
+            Q1 = Qall[:300]
+            same = True
+            for q in Q1[:40]:
+                a = g1.search_knn(q, k)
+                ids1, sims1 = o1.search(q, k)
+                same = same and [r.id for r in a] == ids1.tolist()
+            tq = time.perf_counter()
+            for q in Q1:
+                g1.search_knn(q, k)
+            t_g = (time.perf_counter() - tq) / len(Q1)
+            tq = time.perf_counter()
+            for q in Q1:
+                o1.search(q, k)
+            t_c = (time.perf_counter() - tq) / len(Q1)
+            c1 = dict(workload="C1: 10k x 128, M=5, ef=200, k=10, one query per hnsw_search call (host buffers)",
+                      gpu_us=round(1e6 * t_g, 1), cpu_oracle_us=round(1e6 * t_c, 1), identical=bool(same))
+            g1.close(); o1.close()
 
     known = {(1_000_000, 128, 16, 200, 10, 1024): "C2", (1_000_000, 768, 32, 400, 100, 4096): "C3",
              (10_000_000, 128, 16, 200, 10, 1024): "C4"}
@@ -359,14 +539,17 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %d nodes x dim %d, M=%d, ef=%d, k=%d, batch=%d queries/GPU, uniform[0,1) f32, replicated index"
                                % (cfg_name, N, dim, M, ef, k, B),
-                   "nodes": N, "dim": dim, "M": M, "ef": ef, "k": k, "batch": B, "build": args.build,
+                   "nodes": N, "dim": dim, "M": M, "ef": ef, "k": k, "batch": B, "graph": mode, "graph_desc": graph_desc,
+                   "steps_in_flight": S,
                    "parallelism": "replica x%d, query batch sharded%s" % (
                        world, " (ranks share one device, gloo: functional check only)" if one_device and world > 1 else "")},
         "gather_verified": gather_ok,
         "recall_at_%d" % k: None if recall is None else round(recall, 4),
         "build_seconds": None if t_build is None else round(t_build, 2),
         "host_buffers_qps": round(host_qps, 1),
+        "gpu_fast_build": fast_build,
         "clustered": clus,
+        "c1_single_query": c1,
         "setup_seconds": round(time.time() - t0, 1),
         "roofline": roofline,
         "cpu_baseline": cpu,

@@ -98,8 +98,10 @@ hnsw_status hnsw_delete(hnsw_index *h, uint32_t id, uint32_t *touched, uint32_t 
                         uint32_t *n_touched);
 
 /* Index::search_knn (core.rs:477-486 -> :865-892); ef = ef_construction
- * (core.rs:485).  Writes min(k, ef, reachable) results, nearest first; an empty
- * index returns HNSW_OK with *n_out = 0 (core.rs:481-483).                   */
+ * (core.rs:485).  *n_out = min(k, ef, reachable) results, nearest first; ids and
+ * sims must have room for k entries (entries past *n_out are padded like the
+ * batch form's).  An empty index returns HNSW_OK with *n_out = 0
+ * (core.rs:481-483).                                                          */
 hnsw_status hnsw_search(hnsw_index *h, const float *q, uint32_t dim, uint32_t k,
                         uint32_t *ids, float *sims, uint32_t *n_out);
 

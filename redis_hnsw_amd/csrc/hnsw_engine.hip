@@ -42,9 +42,10 @@ struct hnsw_index {
     bool spill_busy[4] = {false, false, false, false};
     uint32_t spill_rr = 0;
     float *d_Q = nullptr;
-    uint32_t *d_ids = nullptr, *d_nout = nullptr;
-    float *d_sims = nullptr;
-    size_t stage_q = 0, stage_r = 0, stage_b = 0;
+    uint32_t *d_res = nullptr;       // [ids B*k][sims B*k][n_out B] of the host-buffer entry points
+    size_t stage_q = 0, stage_r = 0;
+    uint32_t *h_pinned = nullptr;    // pinned mirror for batches <= kPinnedBatch
+    size_t pinned_words = 0;
     // insert scratch
     uint32_t *d_plan = nullptr;     // [plan_slots][kMaxLayers][1 + 64]
     uint32_t plan_slots = 0;
@@ -55,9 +56,11 @@ struct hnsw_index {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_sync = nullptr;
     bool ev_valid = false;
+    bool time_launches = false;     // tuning: bracket every search launch with events (hnsw_last_search_kernel_ms)
     int lds_buckets_override = -1;
     bool tag_table = true;          // 16-bit tag visited table when the id range allows it
     int tag_bb_override = -1;       // tests: force log2(buckets) of the tag table
+    int idbits_override = -1;       // tests: hash ids as an index of 2^idbits nodes would
     bool asymmetric = false;        // links may be one-directional (the fast build prunes that way; imports are checked)
     uint32_t lds_fill_x2 = 13;       // LDS visited table holds lnb * fill/2 ids (of 7 per bucket) before spilling
     int grid_override = -1;
@@ -329,7 +332,9 @@ VisCfg pick_vis(const hnsw_index *h, int R, int T, bool ins, uint32_t nwaves)
     while (((size_t)16 << (bb + 1)) <= c.bytes && bb + 1 <= 12) ++bb;
     if (h->tag_bb_override >= 2) bb = std::min<uint32_t>(bb, (uint32_t)h->tag_bb_override);
     if (bb < 2) return c;
-    const uint32_t idbits = std::max(ceil_log2(std::max(h->cap, 2u)), bb);
+    uint32_t idbits = std::max(ceil_log2(std::max(h->cap, 2u)), bb);
+    // tests: any idbits >= ceil_log2(cap) is a valid bijection domain (what a larger index would use)
+    if (h->idbits_override > (int)idbits && h->idbits_override <= 32) idbits = (uint32_t)h->idbits_override;
     if (idbits - bb > 13) return c;
     c.tagcfg = bb | (idbits << 8);
     c.lcap = (1u << bb) * 6u;                     // 6 of the 7 entries per bucket
@@ -338,6 +343,7 @@ VisCfg pick_vis(const hnsw_index *h, int R, int T, bool ins, uint32_t nwaves)
 }
 
 constexpr uint32_t kSpillRegions = 4;
+constexpr uint32_t kPinnedBatch = 64;
 
 // Pick the next spill region for a launch on `st`; the stream first waits for the launch that used
 // that region last.  Call spill_release() right after enqueueing the kernel.
@@ -422,20 +428,29 @@ hnsw_status launch_search_t(hnsw_index *h, const float *dQ, uint32_t B, uint32_t
     GraphView gv = view(h);
     gv.tagcfg = vc.tagcfg;
     auto kern = k_search<MODE, T, R>;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {   // the attribute sticks to the function: set it once per size class, not once per launch
+        static size_t lds_set[16] = {0};
+        size_t &have = lds_set[h->device & 15];
+        if (lds > have) {
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            have = lds;
+        }
+    }
     uint32_t grid = std::min(B, h->spill_slots);
     if (h->grid_override > 0) grid = std::min<uint32_t>(grid, (uint32_t)h->grid_override);
     uint32_t region, *spill;
     hnsw_status ss = spill_acquire(h, st, &region, &spill);
     if (ss != HNSW_OK) return ss;
-    HIP_TRY(h, hipEventRecord(h->ev0, st));
+    if (h->time_launches) HIP_TRY(h, hipEventRecord(h->ev0, st));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, st, gv, dQ, B, k, h->efc, lnb, vc.lcap, spill,
                        h->spill_gnb, d_ids, d_sims, d_nout, h->visited_bounded ? 1u : 0u);
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipEventRecord(h->ev1, st));
+    if (h->time_launches) {
+        HIP_TRY(h, hipEventRecord(h->ev1, st));
+        h->ev_valid = true;
+    }
     if ((ss = spill_release(h, st, region)) != HNSW_OK) return ss;
-    h->ev_valid = true;
     return HNSW_OK;
 }
 
@@ -464,9 +479,12 @@ hnsw_status launch_search(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k
     return launch_search_r<MODE_AVX, 0>(h, R, dQ, B, k, d_ids, d_sims, d_nout, st);
 }
 
+// Staging of the host-buffer entry points: queries in, one result block [ids B*k][sims B*k][n_out B] out
+// (a single copy back), and a pinned host mirror for small batches -- a HNSW.SEARCH command is one query,
+// where the pageable-memory staging the runtime would do costs more than the transfers themselves.
 hnsw_status ensure_stage(hnsw_index *h, uint32_t B, uint32_t k)
 {
-    size_t nq = (size_t)B * h->dim, nr = (size_t)B * k;
+    size_t nq = (size_t)B * h->dim, nr = 2 * (size_t)B * k + B;
     hnsw_status s;
     if (nq > h->stage_q) {
         dev_free(h, h->d_Q, h->stage_q);
@@ -474,16 +492,17 @@ hnsw_status ensure_stage(hnsw_index *h, uint32_t B, uint32_t k)
         h->stage_q = nq;
     }
     if (nr > h->stage_r) {
-        dev_free(h, h->d_ids, h->stage_r);
-        dev_free(h, h->d_sims, h->stage_r);
-        if ((s = dev_alloc(h, &h->d_ids, nr)) != HNSW_OK) return s;
-        if ((s = dev_alloc(h, &h->d_sims, nr)) != HNSW_OK) return s;
+        dev_free(h, h->d_res, h->stage_r);
+        if ((s = dev_alloc(h, &h->d_res, nr)) != HNSW_OK) return s;
         h->stage_r = nr;
     }
-    if (B > h->stage_b) {
-        dev_free(h, h->d_nout, h->stage_b);
-        if ((s = dev_alloc(h, &h->d_nout, B)) != HNSW_OK) return s;
-        h->stage_b = B;
+    const size_t pin_words = nq + nr;
+    if (B <= kPinnedBatch && pin_words > h->pinned_words) {
+        if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+        h->h_pinned = nullptr;
+        h->pinned_words = 0;
+        HIP_TRY(h, hipHostMalloc((void **)&h->h_pinned, pin_words * 4, hipHostMallocDefault));
+        h->pinned_words = pin_words;
     }
     return HNSW_OK;
 }
@@ -599,8 +618,9 @@ void hnsw_destroy(hnsw_index *h)
     }
     (void)hipFree(h->d_vec); (void)hipFree(h->d_adj0); (void)hipFree(h->d_adjU);
     (void)hipFree(h->d_upper_base); (void)hipFree(h->d_levels); (void)hipFree(h->d_hdr);
-    (void)hipFree(h->d_spill); (void)hipFree(h->d_spill_one); (void)hipFree(h->d_Q); (void)hipFree(h->d_ids); (void)hipFree(h->d_sims);
-    (void)hipFree(h->d_nout); (void)hipFree(h->d_plan); (void)hipFree(h->d_touched); (void)hipFree(h->d_work);
+    (void)hipFree(h->d_spill); (void)hipFree(h->d_spill_one); (void)hipFree(h->d_Q); (void)hipFree(h->d_res);
+    if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+    (void)hipFree(h->d_plan); (void)hipFree(h->d_touched); (void)hipFree(h->d_work);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_sync) (void)hipEventDestroy(h->ev_sync);
@@ -620,10 +640,12 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
     }
     if (!std::strcmp(key, "tag_table")) { h->tag_table = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "tag_bb")) { h->tag_bb_override = (int)value; return HNSW_OK; }
+    if (!std::strcmp(key, "idbits")) { h->idbits_override = (int)value; return HNSW_OK; }
     if (!std::strcmp(key, "lds_fill_x2")) { h->lds_fill_x2 = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 2), 13); return HNSW_OK; }
     if (!std::strcmp(key, "lds_buckets")) { h->lds_buckets_override = (int)value; return HNSW_OK; }
     if (!std::strcmp(key, "lds_hash_bits")) { h->lds_buckets_override = std::max<int>(2, (int)((1ll << value) / 8)); return HNSW_OK; }
     if (!std::strcmp(key, "grid")) { h->grid_override = (int)value; return HNSW_OK; }
+    if (!std::strcmp(key, "time_launches")) { h->time_launches = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "launch_concurrency")) { h->launch_concurrency = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 8); return HNSW_OK; }
     if (!std::strcmp(key, "visited_bounded")) { h->visited_bounded = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "waves_per_cu")) { h->max_waves_per_cu = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 8); return HNSW_OK; }
@@ -817,12 +839,27 @@ hnsw_status hnsw_search_batch(hnsw_index *h, const float *Q, uint32_t B, uint32_
     }
     hnsw_status s = ensure_stage(h, B, k);
     if (s != HNSW_OK) return s;
-    HIP_TRY(h, hipMemcpyAsync(h->d_Q, Q, (size_t)B * dim * 4, hipMemcpyHostToDevice, h->stream));
-    if ((s = launch_search(h, h->d_Q, B, k, h->d_ids, h->d_sims, h->d_nout, h->stream)) != HNSW_OK) return s;
-    HIP_TRY(h, hipMemcpyAsync(ids, h->d_ids, (size_t)B * k * 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(sims, h->d_sims, (size_t)B * k * 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(n_out, h->d_nout, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t nq = (size_t)B * dim, nk = (size_t)B * k;
+    uint32_t *d_ids = h->d_res, *d_nout = h->d_res + 2 * nk;
+    float *d_sims = reinterpret_cast<float *>(h->d_res + nk);
+    const bool pinned = B <= kPinnedBatch;
+    const void *src = Q;
+    if (pinned) { std::memcpy(h->h_pinned, Q, nq * 4); src = h->h_pinned; }
+    HIP_TRY(h, hipMemcpyAsync(h->d_Q, src, nq * 4, hipMemcpyHostToDevice, h->stream));
+    if ((s = launch_search(h, h->d_Q, B, k, d_ids, d_sims, d_nout, h->stream)) != HNSW_OK) return s;
+    if (pinned) {
+        uint32_t *back = h->h_pinned + nq;
+        HIP_TRY(h, hipMemcpyAsync(back, h->d_res, (2 * nk + B) * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        std::memcpy(ids, back, nk * 4);
+        std::memcpy(sims, back + nk, nk * 4);
+        std::memcpy(n_out, back + 2 * nk, (size_t)B * 4);
+    } else {
+        HIP_TRY(h, hipMemcpyAsync(ids, d_ids, nk * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(sims, d_sims, nk * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(n_out, d_nout, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
     for (uint32_t b = 0; b < B; ++b)
         if (n_out[b] == kEmpty) return fail(h, HNSW_ERR_CAPACITY, "visited-set spill table overflow");
     return HNSW_OK;
@@ -832,14 +869,9 @@ hnsw_status hnsw_search(hnsw_index *h, const float *q, uint32_t dim, uint32_t k,
                         uint32_t *n_out)
 {
     if (!h || !n_out) return HNSW_ERR_INVALID;
-    std::vector<uint32_t> tid(k ? k : 1);
-    std::vector<float> tsim(k ? k : 1);
-    uint32_t n = 0;
-    hnsw_status s = hnsw_search_batch(h, q, 1, dim, k, tid.data(), tsim.data(), &n);
-    if (s != HNSW_OK) return s;
-    for (uint32_t i = 0; i < n; ++i) { ids[i] = tid[i]; sims[i] = tsim[i]; }
-    *n_out = n;
-    return HNSW_OK;
+    // the caller's buffers hold k entries (include/hnsw_mi355x.h): the batch form writes straight into them
+    if (!ids || !sims) return HNSW_ERR_INVALID;
+    return hnsw_search_batch(h, q, 1, dim, k, ids, sims, n_out);
 }
 
 hnsw_status hnsw_import(hnsw_index *h, uint32_t n, const float *vectors, const uint32_t *levels,
@@ -1224,7 +1256,7 @@ hnsw_status hnsw_debug_phase_cycles(hnsw_index *h, uint64_t *out8)
 hnsw_status hnsw_last_search_kernel_ms(hnsw_index *h, float *ms)
 {
     if (!h || !ms) return HNSW_ERR_INVALID;
-    if (!h->ev_valid) return fail(h, HNSW_ERR_INVALID, "no search launched yet");
+    if (!h->ev_valid) return fail(h, HNSW_ERR_INVALID, "no timed search launch yet (hnsw_set_tuning(\"time_launches\", 1) first)");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipEventSynchronize(h->ev1));
     HIP_TRY(h, hipEventElapsedTime(ms, h->ev0, h->ev1));

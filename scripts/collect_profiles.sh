@@ -10,7 +10,7 @@ TMP=/tmp/prof_$TAG
 mkdir -p $OUT $TMP
 cd /tmp && export TMPDIR=/tmp
 cd $R
-ARGS="--steps 20 --warmup 3 --no-cpu-baseline --no-clustered $*"
+ARGS="--steps 40 --warmup 4 --no-cpu-baseline --no-extras $*"
 echo "# python bench.py $ARGS" > $OUT/kernel_stats.txt
 timeout 300 rocprofv3 --kernel-trace --stats -d $TMP/stats -o p -- python bench.py $ARGS > $TMP/stats.log 2>&1
 grep -E '^\{' $TMP/stats.log >> $OUT/kernel_stats.txt

@@ -177,6 +177,60 @@ def test_bounded_visited_table_is_exact(eng, oracle_mod, built, knob, val, cfg):
     gi.close()
 
 
+@pytest.mark.parametrize("idbits,bounded", [(24, 0), (24, 1), (22, 0), (27, 1)])
+def test_search_parity_with_the_id_range_of_a_10m_index(eng, oracle_mod, built, idbits, bounded):
+    """C4 (10 M nodes) hashes ids over 2^24: 13 tag bits at 2048 buckets, the edge of the 16-bit tag table
+    (27 bits no longer fit: the 32-bit-id table takes over).  The tag hash is a bijection of [0, 2^idbits) for
+    any idbits >= log2(capacity), so the same code path runs on a small graph."""
+    n, dim, m, ef, k, nq = 2000, 128, 16, 200, 10, 96
+    V, o, lv = built(n, dim, m, ef)
+    gi = eng.Index("foo", dim, m, ef)
+    gi.import_graph(o.export())
+    gi.set_tuning("idbits", idbits)
+    gi.set_tuning("visited_bounded", bounded)
+    Q = make_data(nq, dim, seed=6)
+    gi.reset_counters()
+    ids, sims, n_out = gi.search_batch(Q, k)
+    oids, osims, on, oct = o.search_batch(Q, k)
+    assert np.array_equal(n_out, on) and np.array_equal(ids, oids) and np.array_equal(_bits(sims), _bits(osims))
+    sc, _ = gi.counters()
+    assert (sc.n_ids, sc.n_expand) == (oct.n_ids, oct.n_expand)
+    if sc.n_spill == 0 or not bounded:
+        assert sc.n_dist == oct.n_dist
+    # and with the small table of the 8-waves-per-CU launches (2^24 ids: 14 tag bits would be needed at
+    # 1024 buckets, so those launches use the 32-bit table)
+    gi.set_tuning("tag_bb", 10)
+    ids2, sims2, _ = gi.search_batch(Q, k)
+    assert np.array_equal(ids2, oids) and np.array_equal(_bits(sims2), _bits(osims))
+    gi.close()
+
+
+def test_c1_single_query_calls(eng, oracle_mod):
+    """BASELINE config 1: 10k x 128, M=5, ef=200, k=10, one query per hnsw_search call (the only shape the
+    HNSW.SEARCH command can issue, src/lib.rs:462-496) on the reference-order graph."""
+    n, dim, m, ef, k = 10_000, 128, 5, 200, 10
+    V = make_data(n, dim, seed=1)
+    lv = oracle_mod.draw_levels(n, m, 7)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch(V, lv)
+    gi = eng.Index("c1", dim, m, ef)
+    gi.import_graph(o.export())
+    Q = make_data(200, dim, seed=2)
+    short = 0
+    for q in Q:
+        r = gi.search_knn(q, k)                      # hnsw_search: host buffers, one launch per call
+        oids, osims = o.search(q, k)
+        # min(k, ef, reachable) results (core.rs:878-890): with M=5 the reference's shrinks can isolate a node
+        # at layer 0 while it is still linked above, and a descent that lands on it returns that node alone
+        # (query 89 of this set does)
+        assert len(r) == len(oids)
+        short += len(oids) < k
+        assert [x.id for x in r] == oids.tolist()
+        assert np.array_equal(_bits(np.float32([x.sim for x in r])), _bits(osims))
+    assert short >= 1                                # the "reachable < k" case is covered
+    gi.close()
+
+
 def test_default_table_never_forgets_at_c2_scale_batch(eng, oracle_mod, built):
     """With the default table (sized for the batch) nothing is forgotten: all three counters are the oracle's."""
     n, dim, m, ef, k, nq = 2000, 128, 16, 200, 10, 128
@@ -678,3 +732,40 @@ def test_snapshot_round_trip_continues_identically(eng, oracle_mod):
     ok, why = graphs_equal(a.export_graph(), b.export_graph())
     assert ok, why
     a.close(); b.close()
+
+
+# ---- BASELINE.json config 4 at full size on one GPU ------------------------------------------
+def test_full_size_c4_10m_properties_and_sampled_parity(eng, oracle_mod):
+    """10M x 128, M=16, ef=200, k=10 (one replica of C4; fast GPU build): ids above 2^23, the 24-bit tag
+    hash, size-independent properties on a 1024-query batch, and bit-exact parity with the oracle searching
+    the same exported graph on a sample."""
+    from bench import draw_levels
+    N, dim, M, ef, k, B = 10_000_000, 128, 16, 200, 10, 1024
+    V = np.random.default_rng(1).random((N, dim), dtype=np.float32)
+    Q = np.random.default_rng(2).random((B, dim), dtype=np.float32)
+    gi = eng.Index("c4", dim, M, ef)
+    gi.add_batch(V, levels=draw_levels(N, M, 7), mode="fast")
+    assert gi.node_count == N
+    ids, sims, n_out = gi.search_batch(Q, k)
+    assert np.all(n_out == k) and np.all(ids < N)
+    assert ids.max() >= (1 << 23)                                          # the upper half of the id range is reachable
+    assert np.all(sims[:, :-1] >= sims[:, 1:]) and np.all(sims <= 0)
+    assert all(len(set(r.tolist())) == k for r in ids)
+    d = ((Q[:64, None, :].astype(np.float64) - V[ids[:64].astype(np.int64)].astype(np.float64)) ** 2).sum(-1)
+    assert np.allclose(-d, sims[:64], rtol=1e-5, atol=0)
+    ids2, sims2, _ = gi.search_batch(Q, k)                                 # idempotent
+    assert np.array_equal(ids, ids2) and np.array_equal(_bits(sims), _bits(sims2))
+    # the 8-waves-per-CU launch shape (4096 queries) agrees with the 1024-query one on the shared queries
+    Q4 = np.concatenate([Q, np.random.default_rng(3).random((3 * B, dim), dtype=np.float32)])
+    ids4, sims4, _ = gi.search_batch(Q4, k)
+    assert np.array_equal(ids4[:B], ids) and np.array_equal(_bits(sims4[:B]), _bits(sims))
+    g = gi.export_graph()
+    g["vectors"] = V
+    o = oracle_mod.OracleIndex.from_graph(dim, M, ef, g)
+    gi.reset_counters()
+    sids, ssims, _ = gi.search_batch(Q[:16], k)
+    oids, osims, on, oct = o.search_batch(Q[:16], k, threads=8)
+    assert np.array_equal(sids, oids) and np.array_equal(_bits(ssims), _bits(osims))
+    sc, _ = gi.counters()
+    assert (sc.n_dist, sc.n_ids, sc.n_expand) == (oct.n_dist, oct.n_ids, oct.n_expand)
+    gi.close()
