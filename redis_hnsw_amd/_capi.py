@@ -58,6 +58,31 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64; if
+    this library pulls in /opt/rocm's copies first and torch is imported later, torch's copy finds the device
+    already claimed ("No HIP GPUs are available").  Loading torch's copy first (when torch is installed; torch
+    itself is NOT imported) makes both resolve to the same runtime whatever the import order."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return                      # torch's runtime is already in the process
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        cand = os.path.join(libdir, name)
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load():
     """dlopen redis_hnsw_amd/lib/libhnsw_mi355x.so and bind every entry point."""
     global _lib
@@ -68,6 +93,7 @@ def load():
         raise RuntimeError(
             f"{path} is missing: build it with `python -m redis_hnsw_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         f = getattr(lib, name)  # AttributeError if the .so does not export it

@@ -73,3 +73,21 @@ def build_host_test(force=False):
            "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + "/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"]
     subprocess.check_call(cmd)
     return HOST_TEST_BIN
+
+
+SHIM_TEST_SRC = os.path.join(_HERE, "..", "tests", "cpp", "shim_sequence.c")
+SHIM_TEST_BIN = os.path.join(LIB_DIR, "shim_sequence")
+
+
+def build_shim_test(force=False):
+    """gcc build of tests/cpp/shim_sequence.c: the Rust shim's call sequence in plain C over
+    the C ABI, with a stand-in keyspace for the hnswnodet write-through."""
+    src = os.path.abspath(SHIM_TEST_SRC)
+    hdr = os.path.join(_HERE, "..", "include", "hnsw_mi355x.h")
+    if (not force and os.path.exists(SHIM_TEST_BIN)
+            and os.path.getmtime(SHIM_TEST_BIN) > max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(LIB_PATH))):
+        return SHIM_TEST_BIN
+    cmd = ["gcc", "-std=c11", "-O2", "-Wall", "-o", SHIM_TEST_BIN, src, "-L" + LIB_DIR, "-lhnsw_mi355x",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + "/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-lm"]
+    subprocess.check_call(cmd)
+    return SHIM_TEST_BIN

@@ -178,3 +178,61 @@ def test_snapshot_restored_engine_continues_like_the_oracle(eng, oracle_mod):
     oids, osims, on, _ = o.search_batch(Q, 5)
     assert np.array_equal(n_out, on) and np.array_equal(ids, oids) and np.array_equal(_bits(sims), _bits(osims))
     b.close()
+
+
+def test_rust_shim_call_sequence_in_c(eng):
+    """tests/cpp/shim_sequence.c: HNSW.NEW / NODE.ADD / NODE.DEL / SEARCH driven through the C ABI the way the
+    Rust shim of INTEGRATION.md does it, with a stand-in keyspace for the hnswnodet write-through."""
+    import subprocess
+    from redis_hnsw_amd import build
+    exe = build.build_shim_test()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "shim_sequence ok" in r.stdout
+
+
+def test_reference_rdb_layout_round_trip_through_the_engine(eng, oracle_mod):
+    """hnswindex + hnswnodet values (src/types.rs:243-284, 410-428) written from a live engine index (with
+    tombstones), read back through make_index -> hnsw_import: same graph by NAME, same answers, and the
+    restored index continues exactly like the oracle."""
+    from redis_hnsw_amd import rdb
+    n, dim, m, ef = 300, 16, 5, 24
+    V = make_data(n + 40, dim, seed=61)
+    lv = oracle_mod.draw_levels(n + 40, m, 8)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    a = eng.Index("hnsw.rdb", dim, m, ef)
+    key = lambda i: "hnsw.rdb.n%d" % i
+    for i in range(n):
+        o.add(V[i], int(lv[i]))
+        a.add_node(key(i), V[i], level=int(lv[i]))
+    gone = [4, 77, int(o.enterpoint), 200]
+    for i in gone:
+        o.delete(i)
+        a.delete_node(key(i))
+    index_value, node_values = rdb.dump_index(a)
+    assert len(node_values) == n - len(gone) and all(key(i) not in node_values for i in gone)
+    ir = rdb.load_index(index_value)
+    assert (ir.name, ir.node_count, ir.max_layer, ir.enterpoint) == ("hnsw.rdb", n - len(gone), o.max_layer, key(o.enterpoint))
+    b = rdb.restore_index(index_value, node_values)
+    assert b.node_count == n - len(gone) and b.enterpoint == key(o.enterpoint) and b.max_layer == o.max_layer
+    # same graph by name (ids are compacted over the tombstones)
+    live = [i for i in range(n) if i not in gone]
+    for new, old in enumerate(live):
+        for l in range(int(lv[old] if old else 0) + 1):
+            if l > o.max_layer:
+                break
+            assert [key(int(j)) for j in o.neighbors(old, l)] == [b._names[int(j)] for j in b.neighbors(new, l)], (old, l)
+    Q = make_data(30, dim, seed=2)
+    for q in Q:
+        ra, rb = a.search_knn(q, 5), b.search_knn(q, 5)
+        assert [(r.name, r.sim) for r in ra] == [(r.name, r.sim) for r in rb]
+    # both keep inserting: same names, same links
+    for i in range(n, n + 40):
+        a.add_node(key(i), V[i], level=int(lv[i]))
+        b.add_node(key(i), V[i], level=int(lv[i]))
+    ia, na = rdb.dump_index(a)
+    ib, nb = rdb.dump_index(b)
+    assert rdb.load_index(ia).enterpoint == rdb.load_index(ib).enterpoint
+    assert set(na) == set(nb)
+    assert all(rdb.load_node(na[k]) == rdb.load_node(nb[k]) for k in na)
+    a.close(); b.close()

@@ -1,0 +1,93 @@
+"""The reference's persistence layout (src/types.rs:176-428, src/lib.rs:252-315) restated in
+redis_hnsw_amd/rdb.py: codec round trips, and the committed fixtures (values of oracle-built graphs)."""
+import os
+
+import numpy as np
+import pytest
+
+from redis_hnsw_amd import rdb
+from tests.golden_util import GOLDEN_DIR, load_golden
+
+CASES = ["u360_dim32_m5_ef16_del", "line100_dim4_m5_ef16"]
+
+
+def _load_fixture(case):
+    z = np.load(os.path.join(GOLDEN_DIR, "rdb", case + ".npz"))
+    keys = [str(k) for k in z["node_keys"]]
+    vals, off = {}, 0
+    raw = z["node_values"].tobytes()
+    for k, ln in zip(keys, z["node_value_len"]):
+        vals[k] = raw[off:off + int(ln)]
+        off += int(ln)
+    return z["index_value"].tobytes(), vals
+
+
+def test_module_io_primitives_round_trip():
+    io = rdb.ModuleIO()
+    vals = [0, 1, 63, 64, 16383, 16384, 2**32 - 1, 2**32, 2**63]
+    for v in vals:
+        io.save_unsigned(v)
+    io.save_string("hnsw.idx.node.with.dots")
+    io.save_string("")
+    io.save_string("x" * 70000)
+    io.save_double(1.0 / np.log(5.0))
+    io.save_float(np.float32(0.1))
+    blob = io.finish()
+    rd = rdb.ModuleIO(blob)
+    assert [rd.load_unsigned() for _ in vals] == vals
+    assert rd.load_string() == "hnsw.idx.node.with.dots" and rd.load_string() == "" and rd.load_string() == "x" * 70000
+    assert rd.load_double() == 1.0 / np.log(5.0)
+    assert np.float32(rd.load_float()) == np.float32(0.1)
+    rd.expect_eof()
+    with pytest.raises(rdb.RdbFormatError):
+        rdb.ModuleIO(blob[:-3]).load_string()          # wrong opcode / truncated
+    with pytest.raises(rdb.RdbFormatError):
+        rdb.load_index(blob)                           # not an hnswindex value
+
+
+def test_empty_index_value():
+    ir = rdb.IndexRedis(name="hnsw.e", data_dim=4, m=5, m_max=5, m_max_0=10, ef_construction=200,
+                        level_mult=1.0 / np.log(5.0))
+    back = rdb.load_index(rdb.save_index(ir))
+    assert back == ir and back.enterpoint is None      # "null" <-> None (types.rs:233-236, 278-283)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_fixture_decodes_to_the_oracles_graph(case):
+    """hnswindex + hnswnodet values -> make_index -> the golden (oracle-built) graph, ids compacted over the
+    tombstones in key order; and re-encoding reproduces the committed bytes."""
+    index_value, node_values = _load_fixture(case)
+    c = load_golden(case)
+    ir = rdb.load_index(index_value)
+    assert (ir.name, ir.mfunc_kind, ir.data_dim, ir.m, ir.m_max, ir.m_max_0, ir.ef_construction) == \
+        ("hnsw.gold", "Euclidean", c["dim"], c["m"], c["m"], 2 * c["m"], c["ef"])
+    assert ir.level_mult == 1.0 / float(np.log(float(c["m"])))                 # core.rs:338
+    live = [i for i in range(c["n"]) if i not in set(int(x) for x in c["deleted"])]
+    assert ir.node_count == len(live) == len(ir.nodes) and ir.max_layer == c["graph"]["max_layer"]
+    assert sum(len(l) for l in ir.layers) == len(live)                         # every node in exactly one layer set
+    graph, names = rdb.redis_to_graph(ir, lambda nm: rdb.load_node(node_values[nm]))
+    new_id = {old: new for new, old in enumerate(live)}
+    assert names == ["hnsw.gold.node%d" % i for i in live]
+    assert graph["enterpoint"] == new_id[c["graph"]["enterpoint"]]
+    assert np.array_equal(graph["levels"], c["graph"]["levels"][live])
+    assert np.array_equal(graph["vectors"], c["V"][live])
+    for l in range(c["graph"]["max_layer"] + 1):
+        rp, cl = c["graph"]["row_ptr"][l], c["graph"]["col"][l]
+        for i in live:
+            want = [new_id[int(j)] for j in cl[int(rp[i]):int(rp[i + 1])]]
+            a, b = int(graph["row_ptr"][l][new_id[i]]), int(graph["row_ptr"][l][new_id[i] + 1])
+            assert graph["col"][l][a:b].tolist() == want, (l, i)
+    # encoder determinism: the same values again
+    ir2, nodes2 = rdb.graph_to_redis(ir.name, ir.data_dim, ir.m, ir.ef_construction, graph, names)
+    assert rdb.save_index(ir2) == index_value
+    assert all(rdb.save_node(nodes2[k]) == node_values[k] for k in names)
+
+
+def test_unknown_neighbour_is_the_references_error():
+    index_value, node_values = _load_fixture(CASES[1])
+    ir = rdb.load_index(index_value)
+    victim = ir.nodes[7]
+    broken = dict(node_values)
+    del broken[victim]
+    with pytest.raises(KeyError, match="does not exist"):                     # src/lib.rs:262
+        rdb.redis_to_graph(ir, lambda nm: rdb.load_node(broken[nm]) if nm in broken else None)
