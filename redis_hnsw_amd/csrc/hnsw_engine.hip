@@ -5,6 +5,7 @@
 #include "../../include/hnsw_mi355x.h"
 #include "hnsw_insert.hpp"
 #include "hnsw_kernels.hpp"
+#include "hnsw_search_lean.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -64,6 +65,7 @@ struct hnsw_index {
     bool asymmetric = false;        // links may be one-directional (the fast build prunes that way; imports are checked)
     uint32_t lds_fill_x2 = 13;       // LDS visited table holds lnb * fill/2 ids (of 7 per bucket) before spilling
     int grid_override = -1;
+    bool lean = true;                // dim-128 searches use the specialised kernel (hnsw_search_lean.hpp) when its preconditions hold
     bool visited_bounded = true;     // k_search: a full LDS visited table stops recording (exact results)
     uint32_t max_waves_per_cu = 8;
     uint32_t launch_concurrency = 1; // tuning: search launches the caller keeps in flight at once (sizes the LDS share)   // residency the LDS visited table is sized for (tuning: waves_per_cu)
@@ -467,11 +469,70 @@ hnsw_status launch_search_r(hnsw_index *h, int R, const float *dQ, uint32_t B, u
     return fail(h, HNSW_ERR_INVALID, "ef_construction > 1024 is not supported");
 }
 
+// The specialised kernel: no HBM spill table involved, so no region bookkeeping either.
+template <int T, int R, int BB>
+hnsw_status launch_lean_t(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t idbits, uint32_t *d_ids,
+                          float *d_sims, uint32_t *d_nout, hipStream_t st)
+{
+    const size_t lds = (size_t)R * 64 * 8 + ((size_t)16 << BB);
+    auto kern = k_search_lean<T, R, BB>;
+    {
+        static size_t lds_set[16] = {0};
+        size_t &have = lds_set[h->device & 15];
+        if (lds > have) {
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            have = lds;
+        }
+    }
+    uint32_t grid = std::min(B, 2048u);
+    if (h->grid_override > 0) grid = std::min<uint32_t>(grid, (uint32_t)h->grid_override);
+    if (h->time_launches) HIP_TRY(h, hipEventRecord(h->ev0, st));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, st, view(h), dQ, B, k, h->efc, (1u << BB) * 6u, idbits, d_ids, d_sims,
+                       d_nout);
+    HIP_TRY(h, hipGetLastError());
+    if (h->time_launches) {
+        HIP_TRY(h, hipEventRecord(h->ev1, st));
+        h->ev_valid = true;
+    }
+    // inserts wait for searches in flight through the spill-region events: keep that ordering
+    const uint32_t region = h->spill_rr++ % kSpillRegions;
+    return spill_release(h, st, region);
+}
+
+// returns HNSW_OK and sets *done when the specialised kernel was launched
+hnsw_status try_launch_lean(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t *d_ids, float *d_sims,
+                            uint32_t *d_nout, hipStream_t st, bool *done)
+{
+    *done = false;
+    const int R = pick_R(h->efc);
+    if (!h->lean || h->mode != MODE_AVX || h->T != 4 || !h->visited_bounded || !h->tag_table || h->tag_bb_override >= 0 ||
+        h->lds_buckets_override >= 0 || h->stride0 > 64 || h->strideU > 64 || (R != 1 && R != 4))
+        return HNSW_OK;
+    uint32_t per_cu = ((uint64_t)B * h->launch_concurrency + 255) / 256;
+    per_cu = std::min(std::max(per_cu, 1u), h->max_waves_per_cu);
+    uint32_t bb = per_cu >= 5 ? 10 : 11;
+    uint32_t idbits = std::max(ceil_log2(std::max(h->cap, 2u)), 11u);
+    if (h->idbits_override > (int)idbits && h->idbits_override <= 31) idbits = (uint32_t)h->idbits_override;
+    if (idbits - bb > 13) {
+        if (bb == 10 && idbits - 11 <= 13) bb = 11;      // a 10 M index: the 32 KB table at 4 waves per CU
+        else return HNSW_OK;
+    }
+    *done = true;
+#define LEAN_CASE(RR, BBB) if (R == RR && bb == BBB) return launch_lean_t<4, RR, BBB>(h, dQ, B, k, idbits, d_ids, d_sims, d_nout, st);
+    LEAN_CASE(1, 10) LEAN_CASE(1, 11) LEAN_CASE(4, 10) LEAN_CASE(4, 11)
+#undef LEAN_CASE
+    *done = false;
+    return HNSW_OK;
+}
+
 hnsw_status launch_search(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t *d_ids,
                           float *d_sims, uint32_t *d_nout, hipStream_t st)
 {
     hnsw_status s = ensure_spill(h);
     if (s != HNSW_OK) return s;
+    bool done = false;
+    if ((s = try_launch_lean(h, dQ, B, k, d_ids, d_sims, d_nout, st, &done)) != HNSW_OK || done) return s;
     const int R = pick_R(h->efc);
     if (h->mode == MODE_SCALAR) return launch_search_r<MODE_SCALAR, 0>(h, R, dQ, B, k, d_ids, d_sims, d_nout, st);
     if (h->T == 4) return launch_search_r<MODE_AVX, 4>(h, R, dQ, B, k, d_ids, d_sims, d_nout, st);
@@ -647,6 +708,7 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
     if (!std::strcmp(key, "grid")) { h->grid_override = (int)value; return HNSW_OK; }
     if (!std::strcmp(key, "time_launches")) { h->time_launches = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "launch_concurrency")) { h->launch_concurrency = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 8); return HNSW_OK; }
+    if (!std::strcmp(key, "lean")) { h->lean = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "visited_bounded")) { h->visited_bounded = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "waves_per_cu")) { h->max_waves_per_cu = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 8); return HNSW_OK; }
     if (!std::strcmp(key, "fast_seed")) { h->fast_seed = (uint32_t)std::max<int64_t>(value, 1); return HNSW_OK; }

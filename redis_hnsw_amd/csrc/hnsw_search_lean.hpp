@@ -1,0 +1,294 @@
+// hnsw_search_lean.hpp -- the search kernel's inner loop, specialised for the shapes every BASELINE
+// configuration with dim 128 uses (C1, C2, C4): AVX2 summation order with the query in registers (T = dim/32),
+// adjacency rows of at most 63 ids (one 256-byte wave load), the 16-bit tag table as the visited set with a
+// compile-time bucket count, in its BOUNDED form only (a full table stops recording; re-met members of W are
+// dropped by key equality -- see search_level_v2 and DESIGN.md 4.1).  Same algorithm, same results and the
+// same work counters as search_level_v2; what is gone is everything that made the general routine's
+// instruction stream long: the HBM spill path and its three table formats inside the loop, the second code
+// path for rows wider than 32, and the closures the compiler spilled scalar registers for.  A row is walked
+// in chunks of 32 ids; the rounds of 8 vectors a chunk does not need are skipped (uniform branches), which is
+// what the narrow rows of C1 (M=5) want.
+#pragma once
+#include "hnsw_device.hpp"
+
+namespace hnsw {
+
+template <int BB>
+struct TagSet {
+    uint32_t *tab;       // LDS, (1 << BB) buckets of 16 bytes: [u16 arrivals][u16 entry x 7]
+    uint32_t idbits;     // ids are < 2^idbits, idbits - BB <= 13
+    uint32_t count;      // ids recorded (wave-uniform)
+    uint32_t lcap;       // ... before the table stops recording
+    bool lossy;          // wave-uniform
+};
+
+template <int BB>
+__device__ __forceinline__ void tagset_clear(TagSet<BB> &v, int lane)
+{
+    uint4 *t4 = reinterpret_cast<uint4 *>(v.tab);
+    const uint4 e = make_uint4(0xFFFF0000u, kEmpty, kEmpty, kEmpty);
+#pragma unroll
+    for (uint32_t i = 0; i < (1u << BB) / 64; ++i) t4[i * 64 + lane] = e;
+    v.count = 0;
+    v.lossy = false;
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Test-and-set of one id per lane flagged `valid` (ids of one adjacency row: all distinct).  Returns "was not
+// recorded before"; records it unless the table has stopped recording.  An id lives in the first bucket from
+// its home bucket on that had room when it arrived, so a lookup may stop at the first bucket that is not full.
+template <int BB>
+__device__ __forceinline__ bool tagset_visit(TagSet<BB> &v, bool valid, uint32_t id)
+{
+    const uint32_t mask = (1u << v.idbits) - 1u;
+    const uint32_t x = (id * kTagMul) & mask;
+    const uint32_t h = x ^ (x >> ((v.idbits + 1) >> 1));
+    constexpr uint32_t bmask = (1u << BB) - 1u;
+    const uint32_t b0 = h & bmask, tag = h >> BB;
+    uint32_t state = valid ? 3u : 0u;            // 3 unresolved, 1 absent (fresh), 0 present / not asked
+#pragma unroll 1
+    for (uint32_t d = 0; d < 7; ++d) {
+        uint32_t *bp = v.tab + (((b0 + d) & bmask) << 2);
+        const uint4 wv = *reinterpret_cast<const uint4 *>(bp);
+        const uint32_t want = (tag << 3) | d;
+        const uint32_t ww = want | (want << 16);
+        const bool hit = ((haszero16(wv.y ^ ww) | haszero16(wv.z ^ ww) | haszero16(wv.w ^ ww)) != 0u) | ((wv.x >> 16) == want);
+        const bool room = (wv.x & 0xFFFFu) < kBucketIds;
+        if (state == 3u) {
+            if (hit) state = 0u;
+            else if (room) {
+                if (v.lossy) state = 1u;
+                else {
+                    const uint32_t old = atomicAdd(bp, 1u) & 0xFFFFu;      // arrivals: hands out distinct slots
+                    if (old < kBucketIds) {
+                        reinterpret_cast<unsigned short *>(bp)[1 + old] = (unsigned short)want;
+                        state = 1u;
+                    }                                                       // else: filled meanwhile, chain on
+                }
+            }
+        }
+        if (!__ballot(state == 3u)) break;
+    }
+    if (__ballot(state == 3u)) v.lossy = true;   // seven full buckets in a row: absent, and recording stops
+    return state != 0u;
+}
+
+// squared distance of one vector (id) for this lane's 8-lane group, AVX2 order (metrics.rs:48-77)
+template <int T>
+__device__ __forceinline__ void lean_load(const float4 *vec4, uint32_t row4, uint32_t id, int pp, float4 (&v)[T])
+{
+    const float4 *p = vec4 + (size_t)id * row4 + pp;
+#pragma unroll
+    for (int t = 0; t < T; ++t) v[t] = p[t * 8];
+}
+
+// search_level (core.rs:607-675) with W in registers; leaves w[] sorted (also copied to Wbuf) and returns |W|.
+template <int T, int R, int BB>
+__device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64_t *Wbuf, TagSet<BB> &vis,
+                                                      const QReg<T> &qr, uint32_t ep, uint32_t ef, uint32_t lc,
+                                                      WorkCtr &ctr, int lane, unsigned long long *lossy_ctr)
+{
+    const int grp = lane >> 3, pp = piece_of_lane(lane), sub = lane & 7;
+    const float4 *vec4 = reinterpret_cast<const float4 *>(g.vec);
+    const uint32_t row4 = g.dim >> 2;
+    const uint32_t stride = lc ? g.strideU : g.stride0;          // <= 64: a row is one wave load
+
+    tagset_clear<BB>(vis, lane);                                  // core.rs:614
+    (void)tagset_visit<BB>(vis, lane == 0, ep);                   // core.rs:617
+    vis.count = 1;
+    const uint32_t *row = row_ptr(g, ep, lc);
+    uint32_t word = (uint32_t)lane < stride ? row[lane] : 0u;     // requested before the distance is computed
+    uint64_t w[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) w[r] = ~0ull;
+    uint64_t ckey;
+    {
+        float4 v0[T];
+        lean_load<T>(vec4, row4, ep, pp, v0);
+        const float d = avx_reduce(avx_accumulate<T>(qr.q, v0)); // core.rs:621
+        ctr.n_dist += 1;
+        ckey = pack_key(d, ep);
+        if (lane == 0) w[0] = ckey | 1ull;                        // core.rs:627-628, popped right away (:631)
+    }
+    uint32_t nW = 1;
+    uint64_t worst = ef == 1 ? ckey : ~0ull;                      // W's ef-th key once it is full (core.rs:651)
+    uint64_t pkey = ~0ull;                                        // keys of the last chunk, merged one expansion later
+    bool ptake = false;
+    uint32_t pup[R], ppos = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) pup[r] = 0;
+
+    for (;;) {
+        ctr.n_expand += 1;
+        uint32_t cnt = __builtin_amdgcn_readfirstlane(word);
+        if (cnt > stride - 1) cnt = stride - 1;
+        ctr.n_ids += cnt;
+        bool have_next = false;
+        uint64_t nkey = ~0ull;
+        uint32_t word_next = 0;
+
+        uint32_t c0 = 0;
+        do {                                                      // chunks of 32 ids (core.rs:646 stored order)
+            const uint32_t nch = cnt - c0 < 32u ? cnt - c0 : 32u;
+            const bool last = c0 + 32u >= cnt;
+            uint64_t key = ~0ull;
+            bool take = false;
+            uint64_t rkey = ~0ull;                                // first unexpanded entry of W (last chunk only)
+            uint32_t word_spec = 0;                               // ... and its adjacency row, requested early
+            if (nch) {
+                // slot s = r*8 + grp of this chunk sits in lane c0 + 1 + s; empty slots re-read the first id
+                const uint32_t safe = (uint32_t)__builtin_amdgcn_readlane((int)word, (int)(c0 + 1));
+                uint32_t idr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t s = (uint32_t)(r * 8 + grp);
+                    const uint32_t got = bperm(word, (int)((c0 + 1 + s) & 63u));
+                    idr[r] = s < nch ? got : safe;
+                }
+                float4 v[4][T];
+                lean_load<T>(vec4, row4, idr[0], pp, v[0]);
+                if (nch > 8) lean_load<T>(vec4, row4, idr[1], pp, v[1]);
+                if (nch > 16) lean_load<T>(vec4, row4, idr[2], pp, v[2]);
+                if (nch > 24) lean_load<T>(vec4, row4, idr[3], pp, v[3]);
+                // ---- under those loads: visited filter (core.rs:648-649) and the deferred merge ----
+                if (!vis.lossy && vis.count + 32u > vis.lcap) {
+                    vis.lossy = true;
+                    if (lane == 0) atomicAdd(lossy_ctr, 1ull);
+                }
+                const uint32_t li = (uint32_t)lane - (c0 + 1);
+                const bool was_lossy = vis.lossy;
+                const uint64_t fm = __ballot(tagset_visit<BB>(vis, li < nch, word));
+                if (vis.lossy && !was_lossy && lane == 0) atomicAdd(lossy_ctr, 1ull);
+                const uint32_t nf = (uint32_t)__popcll(fm);
+                vis.count += nf;
+                ctr.n_dist += nf;                                 // the reference evaluates the fresh ones (core.rs:652)
+                if (__ballot(ptake)) {
+                    nW = merge_apply<R>(w, Wbuf, nW, ef, pkey, ptake, pup, ppos, lane, &worst);
+                    ptake = false;
+                }
+                if (last) {
+                    // W is complete: unless one of this chunk's keys beats it, its first unexpanded entry is the
+                    // next candidate.  Requesting that row now, behind the vector loads, takes one of the two
+                    // dependent memory round trips of an expansion off the chain whenever the guess holds (a
+                    // wrong guess costs one 256-byte row).
+                    int r2, l2;
+                    if (first_unexpanded<R>(w, rkey, r2, l2)) {
+                        const uint32_t *rs = row_ptr(g, key_id(rkey), lc);
+                        word_spec = (uint32_t)lane < stride ? rs[lane] : 0u;
+                    } else rkey = ~0ull;
+                }
+                // ---- distances ----
+                float dsel = 0.f;
+                {
+                    const float d0 = avx_reduce(avx_accumulate<T>(qr.q, v[0]));
+                    dsel = d0;
+                    if (nch > 8) { const float d1 = avx_reduce(avx_accumulate<T>(qr.q, v[1])); dsel = sub == 1 ? d1 : dsel; }
+                    if (nch > 16) { const float d2 = avx_reduce(avx_accumulate<T>(qr.q, v[2])); dsel = sub == 2 ? d2 : dsel; }
+                    if (nch > 24) { const float d3 = avx_reduce(avx_accumulate<T>(qr.q, v[3])); dsel = sub == 3 ? d3 : dsel; }
+                }
+                const uint32_t myslot = (uint32_t)(sub * 8 + grp);
+                const uint32_t idsel = sub == 0 ? idr[0] : sub == 1 ? idr[1] : sub == 2 ? idr[2] : idr[3];
+                const bool mine = sub < 4 && myslot < nch && ((fm >> ((c0 + 1 + myslot) & 63u)) & 1ull);
+                key = pack_key(dsel, idsel);
+                take = mine && key < worst;                       // core.rs:657
+                if (vis.lossy) take = drop_members<R>(w, key, take, lane);
+            } else {
+                if (__ballot(ptake)) {
+                    nW = merge_apply<R>(w, Wbuf, nW, ef, pkey, ptake, pup, ppos, lane, &worst);
+                    ptake = false;
+                }
+                int r2, l2;
+                if (!first_unexpanded<R>(w, rkey, r2, l2)) rkey = ~0ull;
+            }
+            if (!last) {
+                nW = merge_regs<R>(w, Wbuf, nW, ef, key, take, lane, &worst);   // core.rs:659-664
+            } else {
+                // The next candidate is known before these keys are merged: the nearest accepted new key if
+                // it beats the first unexpanded entry of W, else that entry.  Its row is requested now; the
+                // ranks of the pending keys are computed under that latency, the scatter one expansion later.
+                nkey = rkey;
+                uint64_t bm = __ballot(take && key < rkey);
+                while (bm) {
+                    const int j = __ffsll((unsigned long long)bm) - 1;
+                    bm &= bm - 1;
+                    const uint64_t kj = readlane64(key, j);
+                    nkey = kj < nkey ? kj : nkey;
+                }
+                have_next = nkey != ~0ull;
+                if (have_next) {
+                    if (nkey == rkey && nch) word_next = word_spec;          // the early request was the right one
+                    else {
+                        row = row_ptr(g, key_id(nkey), lc);
+                        word_next = (uint32_t)lane < stride ? row[lane] : 0u;
+                    }
+                }
+                pkey = key;
+                ptake = take;
+            }
+            c0 += 32u;
+        } while (c0 < cnt);
+
+        if (!have_next) break;                                    // core.rs:630,635
+        // mark the chosen entry expanded (core.rs:631 pop)
+#pragma unroll
+        for (int r = 0; r < R; ++r) w[r] |= (w[r] == nkey) ? 1ull : 0ull;
+        if (ptake && pkey == nkey) pkey |= 1ull;
+        if (__ballot(ptake)) merge_rank<R>(w, pkey, ptake, pup, ppos, lane);
+        ckey = nkey;
+        word = word_next;
+    }
+    if (__ballot(ptake)) nW = merge_regs<R>(w, Wbuf, nW, ef, pkey, ptake, lane, &worst);
+#pragma unroll
+    for (int r = 0; r < R; ++r) Wbuf[r * 64 + lane] = w[r];
+    __builtin_amdgcn_wave_barrier();
+    (void)ckey;
+    return nW;
+}
+
+// HNSW.SEARCH (core.rs:477-486 -> :865-892): one wave per query, grid-stride over the batch.
+template <int T, int R, int BB>
+__global__ __launch_bounds__(64) void k_search_lean(GraphView g, const float *__restrict__ Q, uint32_t B, uint32_t k,
+                                                    uint32_t ef, uint32_t lcap, uint32_t idbits,
+                                                    uint32_t *__restrict__ out_ids, float *__restrict__ out_sims,
+                                                    uint32_t *__restrict__ out_n)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    uint64_t *Wbuf = reinterpret_cast<uint64_t *>(smem);                       // [R*64]
+    TagSet<BB> vis;
+    vis.tab = reinterpret_cast<uint32_t *>(smem + (size_t)R * 64 * 8);
+    vis.idbits = idbits;
+    vis.lcap = lcap;
+    vis.count = 0;
+    vis.lossy = false;
+    WorkCtr ctr = {};
+    const int32_t ep0 = g.hdr->enterpoint;        // core.rs:866
+    const uint32_t lmax = g.hdr->max_layer;       // core.rs:867
+    for (uint32_t qi = blockIdx.x; qi < B; qi += gridDim.x) {
+        QReg<T> qr;
+        load_query<MODE_AVX, T>(Q + (size_t)qi * g.dim, g.dim, qr, nullptr, lane);
+        uint32_t ep = (uint32_t)ep0;
+        for (uint32_t lc = lmax; lc >= 1; --lc) {  // core.rs:870-874
+            search_level_lean<T, 1, BB>(g, Wbuf, vis, qr, ep, 1, lc, ctr, lane, &g.hdr->ctr_search[3]);
+            ep = key_id(Wbuf[0]);                  // core.rs:872
+            __builtin_amdgcn_wave_barrier();
+        }
+        const uint32_t nW = search_level_lean<T, R, BB>(g, Wbuf, vis, qr, ep, ef, 0, ctr, lane, &g.hdr->ctr_search[3]); // core.rs:876
+        // core.rs:878-890: nearest first, min(k, |W|) results; sim = -dist (metrics.rs:75)
+        const uint32_t nres = nW < k ? nW : k;
+        for (uint32_t i = lane; i < k; i += 64) {
+            const uint64_t key = i < nres ? Wbuf[i] : 0;
+            out_ids[(size_t)qi * k + i] = i < nres ? key_id(key) : kEmpty;
+            out_sims[(size_t)qi * k + i] = i < nres ? -key_dist(key) : -__builtin_inff();
+        }
+        if (lane == 0) out_n[qi] = nres;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) {
+        atomicAdd(&g.hdr->ctr_search[0], (unsigned long long)ctr.n_dist);
+        atomicAdd(&g.hdr->ctr_search[1], (unsigned long long)ctr.n_ids);
+        atomicAdd(&g.hdr->ctr_search[2], (unsigned long long)ctr.n_expand);
+    }
+}
+
+} // namespace hnsw

@@ -20,11 +20,18 @@ def stats(db):
 
 def pmc(db, sub):
     cur = sqlite3.connect(db).cursor()
-    q = ("select counter_name, count(*), avg(value), min(value), max(value), avg(duration), avg(vgpr_count), "
-         "avg(lds_block_size), avg(grid_size) from counters_collection where kernel_name like ? group by counter_name")
-    print("# rocprofv3 --pmc, dispatches of kernels matching %r" % sub)
+    q = ("select kernel_name, lds_block_size, grid_size, counter_name, count(*), avg(value), min(value), max(value), avg(duration), "
+         "avg(vgpr_count) from counters_collection where kernel_name like ? "
+         "group by kernel_name, lds_block_size, grid_size, counter_name order by kernel_name, lds_block_size, grid_size, counter_name")
+    print("# rocprofv3 --pmc, dispatches of kernels matching %r (grouped by kernel, LDS bytes, grid)" % sub)
+    last = None
     for r in cur.execute(q, ("%" + sub + "%",)):
-        print("counter=%s dispatches=%d avg=%.3f min=%.3f max=%.3f avg_dispatch_ns=%.0f vgpr=%d lds=%d grid=%d" % r)
+        name = r[0].split("(")[0].replace("void ", "")
+        head = (name, r[1], r[2])
+        if head != last:
+            print("kernel=%s lds=%d grid=%d vgpr=%d" % (name[:60], r[1], r[2], r[9]))
+            last = head
+        print("  counter=%s dispatches=%d avg=%.3f min=%.3f max=%.3f avg_dispatch_ns=%.0f" % (r[3], r[4], r[5], r[6], r[7], r[8]))
 
 
 if __name__ == "__main__":
