@@ -322,11 +322,13 @@ def main():
     # algorithmic bytes are the reference's: count them in a pass where the table holds everything.
     index.set_tuning("launch_concurrency", 1)
     index.set_tuning("waves_per_cu", 4)
+    index.set_tuning("visited_bounded", 0)           # the exact set: LDS table, HBM table beyond it
     index.reset_counters()
-    nb_exact = min(n_qbatches, args.steps)
+    nb_exact = min(n_qbatches, args.steps, max(1, 8192 // B))
     for b in range(nb_exact):
         search_now(myQ[b * B:(b + 1) * B], B)
     sx, _ = index.counters()
+    index.set_tuning("visited_bounded", 1)
     index.set_tuning("waves_per_cu", 8)
     index.set_tuning("launch_concurrency", S)
     n_dist_q, n_ids_q, n_exp_q = sx.n_dist / (nb_exact * B), sx.n_ids / (nb_exact * B), sx.n_expand / (nb_exact * B)

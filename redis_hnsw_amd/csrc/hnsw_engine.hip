@@ -301,7 +301,9 @@ uint32_t pick_lnb(const hnsw_index *h, int R, int T, bool ins, uint32_t nwaves)
     // (163840 / n - 512); 5..8 per CU follow the same rule, rounded down to 256 B
     const size_t tiers[8] = {160 * 1024 - 2048, 80896, 53760, 40448, 32256, 26624, 22784, 19968};
     // the insert kernels keep the exact HBM spill path: give them the larger table
-    const uint32_t max_per_cu = ins ? std::min(h->max_waves_per_cu, 4u) : h->max_waves_per_cu;
+    // ... and so does the dim-768 search: its kernel holds the query and 24 loads in registers (> 256 VGPRs:
+    // one wave per SIMD whatever the LDS share), so a smaller table would only forget more
+    const uint32_t max_per_cu = (ins || T == 24) ? std::min(h->max_waves_per_cu, 4u) : h->max_waves_per_cu;
     if (!ins) nwaves *= h->launch_concurrency;   // searches the caller overlaps on several streams share the CUs
     uint32_t per_cu = (nwaves + 255) / 256;
     per_cu = std::min(std::max(per_cu, 1u), max_per_cu);
@@ -709,6 +711,10 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
     if (!std::strcmp(key, "time_launches")) { h->time_launches = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "launch_concurrency")) { h->launch_concurrency = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 8); return HNSW_OK; }
     if (!std::strcmp(key, "lean")) { h->lean = value != 0; return HNSW_OK; }
+    if (!std::strcmp(key, "query_in_lds")) {     // dims 128 / 768 normally keep the query in registers (T = dim/32)
+        if (h->mode == MODE_AVX) h->T = value ? 0 : ((h->dim == 128 || h->dim == 768) ? (int)(h->dim / 32) : 0);
+        return HNSW_OK;
+    }
     if (!std::strcmp(key, "visited_bounded")) { h->visited_bounded = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "waves_per_cu")) { h->max_waves_per_cu = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 8); return HNSW_OK; }
     if (!std::strcmp(key, "fast_seed")) { h->fast_seed = (uint32_t)std::max<int64_t>(value, 1); return HNSW_OK; }

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Collect the rocprofv3 evidence for bench.py on the GPU box and leave only small text summaries
+# Collect the rocprofv3 evidence for one bench.py workload on the GPU box and leave only small text summaries
 # under gpurun_out/profiles_$TAG/ (the rocpd databases are too large to copy back).
-# Usage: scripts/collect_profiles.sh TAG [bench args...]
+# Usage: scripts/collect_profiles.sh TAG [bench args...]        e.g.  r2_c2   |   r2_c3 --nodes 1000000 --dim 768 ...
 set -u
-TAG=${1:-r1}; shift || true
+TAG=${1:-r2}; shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 TMP=/tmp/prof_$TAG
@@ -11,26 +11,32 @@ mkdir -p $OUT $TMP
 cd /tmp && export TMPDIR=/tmp
 cd $R
 ARGS="--steps 40 --warmup 4 --no-cpu-baseline --no-extras $*"
-echo "# python bench.py $ARGS" > $OUT/kernel_stats.txt
-timeout 300 rocprofv3 --kernel-trace --stats -d $TMP/stats -o p -- python bench.py $ARGS > $TMP/stats.log 2>&1
+COMMIT=$(cat $R/.commit_for_profiles 2>/dev/null || echo unknown)
+echo "# commit $COMMIT" > $OUT/kernel_stats.txt
+echo "# rocprofv3 --kernel-trace --stats -- python bench.py $ARGS" >> $OUT/kernel_stats.txt
+timeout 900 rocprofv3 --kernel-trace --stats -d $TMP/stats -o p -- python bench.py $ARGS > $TMP/stats.log 2>&1
 grep -E '^\{' $TMP/stats.log >> $OUT/kernel_stats.txt
 python scripts/summarize_rocprof.py stats $TMP/stats/p_results.db >> $OUT/kernel_stats.txt
+python scripts/summarize_rocprof.py dispatches $TMP/stats/p_results.db k_search >> $OUT/kernel_stats.txt
 rm -rf $TMP/stats
-echo "# python bench.py $ARGS   (one counter per pass)" > $OUT/pmc_hbm.txt
+echo "# commit $COMMIT" > $OUT/pmc_hbm.txt
+echo "# rocprofv3 --pmc <counter> -- python bench.py $ARGS   (one counter per pass; kernels are serialised under --pmc)" >> $OUT/pmc_hbm.txt
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $C -d $TMP/$C -o p -- python bench.py $ARGS > $TMP/$C.log 2>&1
+  timeout 900 rocprofv3 --pmc $C -d $TMP/$C -o p -- python bench.py $ARGS > $TMP/$C.log 2>&1
   python scripts/summarize_rocprof.py pmc $TMP/$C/p_results.db k_search >> $OUT/pmc_hbm.txt
-  rm -rf $TMP/$C
 done
+python scripts/summarize_rocprof.py traffic $TMP/FETCH_SIZE/p_results.db $TMP/WRITE_SIZE/p_results.db k_search "$COMMIT" "$ARGS" > $OUT/traffic_entry.json
+rm -rf $TMP/FETCH_SIZE $TMP/WRITE_SIZE
 echo "# calibration: scripts/calib_fetch.py streams 2 x 2e6 x 512 B = 2.048e9 B through the engine's row access pattern" >> $OUT/pmc_hbm.txt
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $TMP/calib -o p -- python scripts/calib_fetch.py > $TMP/calib.log 2>&1
 python scripts/summarize_rocprof.py pmc $TMP/calib/p_results.db k_metric >> $OUT/pmc_hbm.txt
 rm -rf $TMP/calib
-echo "# python bench.py $ARGS   (SQ counters, 8 per pass)" > $OUT/pmc_sq.txt
-timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU -d $TMP/sq1 -o p -- python bench.py $ARGS > $TMP/sq1.log 2>&1
+echo "# commit $COMMIT" > $OUT/pmc_sq.txt
+echo "# rocprofv3 --pmc (8 SQ counters per pass) -- python bench.py $ARGS" >> $OUT/pmc_sq.txt
+timeout 900 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU -d $TMP/sq1 -o p -- python bench.py $ARGS > $TMP/sq1.log 2>&1
 python scripts/summarize_rocprof.py pmc $TMP/sq1/p_results.db k_search >> $OUT/pmc_sq.txt; rm -rf $TMP/sq1
-timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_BRANCH -d $TMP/sq2 -o p -- python bench.py $ARGS > $TMP/sq2.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_BRANCH -d $TMP/sq2 -o p -- python bench.py $ARGS > $TMP/sq2.log 2>&1
 python scripts/summarize_rocprof.py pmc $TMP/sq2/p_results.db k_search >> $OUT/pmc_sq.txt; rm -rf $TMP/sq2
-cat $OUT/kernel_stats.txt | head -12 | cut -c1-200
+head -30 $OUT/kernel_stats.txt | cut -c1-220
 cat $OUT/pmc_hbm.txt | cut -c1-160
-cat $OUT/pmc_sq.txt | cut -c1-120
+cat $OUT/traffic_entry.json

@@ -66,7 +66,7 @@ def main():
         B = int(kv.pop("B", 1024))
         nstreams = int(kv.pop("streams", 1))
         # defaults first, then the variant's knobs
-        for key, val in dict(waves_per_cu=8, tag_bb=-1, tag_table=1, grid=-1, visited_bounded=1, launch_concurrency=1, lean=1).items():
+        for key, val in dict(waves_per_cu=8, tag_bb=-1, tag_table=1, grid=-1, visited_bounded=1, launch_concurrency=1, lean=1, query_in_lds=0).items():
             gi.set_tuning(key, val)
         for key, val in kv.items():
             gi.set_tuning(key, int(val))

@@ -34,8 +34,55 @@ def pmc(db, sub):
         print("  counter=%s dispatches=%d avg=%.3f min=%.3f max=%.3f avg_dispatch_ns=%.0f" % (r[3], r[4], r[5], r[6], r[7], r[8]))
 
 
+def dispatches(db, sub):
+    """per (kernel, LDS bytes, grid) group of the kernel trace: launches and average duration -- the timed
+    launches of bench.py are the largest group (the warm-up, recall and counter passes use other shapes)"""
+    con = sqlite3.connect(db)
+    cur = con.cursor()
+    names = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+    view = "kernels" if "kernels" in names else None
+    if view is None:
+        print("# (no kernels view in this rocpd database: %s)" % ", ".join(n for n in names if "kernel" in n.lower()))
+        return
+    cols = [r[1] for r in cur.execute("pragma table_info(%s)" % view)]
+    lds = "lds_size" if "lds_size" in cols else ("lds_block_size" if "lds_block_size" in cols else "0")
+    grid = "grid_x" if "grid_x" in cols else ("grid_size" if "grid_size" in cols else "0")
+    dur = "duration" if "duration" in cols else "(end - start)"
+    q = ("select name, %s, %s, count(*), avg(%s), min(%s), max(%s) from %s where name like ? group by name, %s, %s "
+         "order by count(*) desc" % (lds, grid, dur, dur, dur, view, lds, grid))
+    print("# kernel-trace dispatches of kernels matching %r, grouped by (kernel, LDS bytes, grid); durations in ns" % sub)
+    for r in cur.execute(q, ("%" + sub + "%",)):
+        print("kernel=%s lds=%s grid=%s launches=%d avg_ns=%.0f min_ns=%.0f max_ns=%.0f" % (
+            r[0].split("(")[0].replace("void ", "")[:60], r[1], r[2], r[3], r[4], r[5], r[6]))
+
+
+def traffic(fetch_db, write_db, sub, commit, args):
+    """JSON entry for profiles/traffic.json: HBM bytes per launch of the most frequent k_search launch shape
+    (FETCH_SIZE is KiB and reports half of a wide coalesced read on gfx950: x2, see MI355X_MICROARCH.md)"""
+    import json
+
+    def top(db, counter):
+        cur = sqlite3.connect(db).cursor()
+        q = ("select kernel_name, lds_block_size, grid_size, count(*), avg(value) from counters_collection "
+             "where kernel_name like ? and counter_name = ? group by kernel_name, lds_block_size, grid_size order by count(*) desc")
+        rows = list(cur.execute(q, ("%" + sub + "%", counter)))
+        return rows[0] if rows else None
+    f, w = top(fetch_db, "FETCH_SIZE"), top(write_db, "WRITE_SIZE")
+    out = dict(commit=commit, bench_args=args, kernel=f[0].split("(")[0].replace("void ", "") if f else None,
+               lds_bytes=f[1] if f else None, launches_sampled=f[3] if f else 0,
+               fetch_size_kib_per_launch=f[4] if f else None, write_size_kib_per_launch=w[4] if w else None,
+               fetch_correction=2.0)
+    if f and w:
+        out["k_search_hbm_bytes_per_launch"] = int(f[4] * 1024 * 2.0 + w[4] * 1024)
+    print(json.dumps(out, indent=1))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "dispatches":
+        dispatches(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "traffic":
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6])
     else:
         pmc(sys.argv[2], sys.argv[3])
