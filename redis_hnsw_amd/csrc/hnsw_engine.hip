@@ -472,12 +472,12 @@ hnsw_status launch_search_r(hnsw_index *h, int R, const float *dQ, uint32_t B, u
 }
 
 // The specialised kernel: no HBM spill table involved, so no region bookkeeping either.
-template <int T, int R, int BB>
+template <int T, int R, int BB, int DB>
 hnsw_status launch_lean_t(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t idbits, uint32_t *d_ids,
                           float *d_sims, uint32_t *d_nout, hipStream_t st)
 {
     const size_t lds = (size_t)R * 64 * 8 + ((size_t)16 << BB);
-    auto kern = k_search_lean<T, R, BB>;
+    auto kern = k_search_lean<T, R, BB, DB>;
     {
         static size_t lds_set[16] = {0};
         size_t &have = lds_set[h->device & 15];
@@ -516,13 +516,18 @@ hnsw_status try_launch_lean(hnsw_index *h, const float *dQ, uint32_t B, uint32_t
     uint32_t bb = per_cu >= 5 ? 10 : 11;
     uint32_t idbits = std::max(ceil_log2(std::max(h->cap, 2u)), 11u);
     if (h->idbits_override > (int)idbits && h->idbits_override <= 31) idbits = (uint32_t)h->idbits_override;
+    // 16-bit entries: tag (idbits - bb bits) + displacement.  3 displacement bits normally; 2^24 ids at 1024
+    // buckets need 14 tag bits, which leaves 2 (chains of at most 3 buckets: more ids go unrecorded, see
+    // tagset_visit -- results are unaffected)
+    uint32_t db = 3;
     if (idbits - bb > 13) {
-        if (bb == 10 && idbits - 11 <= 13) bb = 11;      // a 10 M index: the 32 KB table at 4 waves per CU
+        if (idbits - bb == 14) db = 2;
         else return HNSW_OK;
     }
     *done = true;
-#define LEAN_CASE(RR, BBB) if (R == RR && bb == BBB) return launch_lean_t<4, RR, BBB>(h, dQ, B, k, idbits, d_ids, d_sims, d_nout, st);
-    LEAN_CASE(1, 10) LEAN_CASE(1, 11) LEAN_CASE(4, 10) LEAN_CASE(4, 11)
+#define LEAN_CASE(RR, BBB, DDB) if (R == RR && bb == BBB && db == DDB) return launch_lean_t<4, RR, BBB, DDB>(h, dQ, B, k, idbits, d_ids, d_sims, d_nout, st);
+    LEAN_CASE(1, 10, 3) LEAN_CASE(1, 11, 3) LEAN_CASE(4, 10, 3) LEAN_CASE(4, 11, 3)
+    LEAN_CASE(1, 10, 2) LEAN_CASE(1, 11, 2) LEAN_CASE(4, 10, 2) LEAN_CASE(4, 11, 2)
 #undef LEAN_CASE
     *done = false;
     return HNSW_OK;

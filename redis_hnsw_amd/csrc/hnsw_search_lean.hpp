@@ -13,17 +13,17 @@
 
 namespace hnsw {
 
-template <int BB>
+template <int BB, int DB = 3>
 struct TagSet {
     uint32_t *tab;       // LDS, (1 << BB) buckets of 16 bytes: [u16 arrivals][u16 entry x 7]
-    uint32_t idbits;     // ids are < 2^idbits, idbits - BB <= 13
+    uint32_t idbits;     // ids are < 2^idbits, idbits - BB <= 16 - DB (DB displacement bits per entry: 3, or 2 for 2^24 ids at 1024 buckets)
     uint32_t count;      // ids recorded (wave-uniform)
     uint32_t lcap;       // ... before the table stops recording
     bool lossy;          // wave-uniform
 };
 
-template <int BB>
-__device__ __forceinline__ void tagset_clear(TagSet<BB> &v, int lane)
+template <int BB, int DB>
+__device__ __forceinline__ void tagset_clear(TagSet<BB, DB> &v, int lane)
 {
     uint4 *t4 = reinterpret_cast<uint4 *>(v.tab);
     const uint4 e = make_uint4(0xFFFF0000u, kEmpty, kEmpty, kEmpty);
@@ -37,8 +37,8 @@ __device__ __forceinline__ void tagset_clear(TagSet<BB> &v, int lane)
 // Test-and-set of one id per lane flagged `valid` (ids of one adjacency row: all distinct).  Returns "was not
 // recorded before"; records it unless the table has stopped recording.  An id lives in the first bucket from
 // its home bucket on that had room when it arrived, so a lookup may stop at the first bucket that is not full.
-template <int BB>
-__device__ __forceinline__ bool tagset_visit(TagSet<BB> &v, bool valid, uint32_t id)
+template <int BB, int DB>
+__device__ __forceinline__ bool tagset_visit(TagSet<BB, DB> &v, bool valid, uint32_t id)
 {
     const uint32_t mask = (1u << v.idbits) - 1u;
     const uint32_t x = (id * kTagMul) & mask;
@@ -46,11 +46,14 @@ __device__ __forceinline__ bool tagset_visit(TagSet<BB> &v, bool valid, uint32_t
     constexpr uint32_t bmask = (1u << BB) - 1u;
     const uint32_t b0 = h & bmask, tag = h >> BB;
     uint32_t state = valid ? 3u : 0u;            // 3 unresolved, 1 absent (fresh), 0 present / not asked
+    // displacements 0 .. kMaxD-1; the all-ones entry is the free-slot marker, so the largest displacement
+    // value of a DB-bit field is never used
+    constexpr uint32_t kMaxD = (1u << DB) - 1u;
 #pragma unroll 1
-    for (uint32_t d = 0; d < 7; ++d) {
+    for (uint32_t d = 0; d < kMaxD; ++d) {
         uint32_t *bp = v.tab + (((b0 + d) & bmask) << 2);
         const uint4 wv = *reinterpret_cast<const uint4 *>(bp);
-        const uint32_t want = (tag << 3) | d;
+        const uint32_t want = (tag << DB) | d;
         const uint32_t ww = want | (want << 16);
         const bool hit = ((haszero16(wv.y ^ ww) | haszero16(wv.z ^ ww) | haszero16(wv.w ^ ww)) != 0u) | ((wv.x >> 16) == want);
         const bool room = (wv.x & 0xFFFFu) < kBucketIds;
@@ -69,7 +72,7 @@ __device__ __forceinline__ bool tagset_visit(TagSet<BB> &v, bool valid, uint32_t
         }
         if (!__ballot(state == 3u)) break;
     }
-    if (__ballot(state == 3u)) v.lossy = true;   // seven full buckets in a row: absent, and recording stops
+    if (__ballot(state == 3u)) v.lossy = true;   // kMaxD full buckets in a row: absent, and recording stops
     return state != 0u;
 }
 
@@ -83,8 +86,8 @@ __device__ __forceinline__ void lean_load(const float4 *vec4, uint32_t row4, uin
 }
 
 // search_level (core.rs:607-675) with W in registers; leaves w[] sorted (also copied to Wbuf) and returns |W|.
-template <int T, int R, int BB>
-__device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64_t *Wbuf, TagSet<BB> &vis,
+template <int T, int R, int BB, int DB>
+__device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64_t *Wbuf, TagSet<BB, DB> &vis,
                                                       const QReg<T> &qr, uint32_t ep, uint32_t ef, uint32_t lc,
                                                       WorkCtr &ctr, int lane, unsigned long long *lossy_ctr)
 {
@@ -93,8 +96,8 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
     const uint32_t row4 = g.dim >> 2;
     const uint32_t stride = lc ? g.strideU : g.stride0;          // <= 64: a row is one wave load
 
-    tagset_clear<BB>(vis, lane);                                  // core.rs:614
-    (void)tagset_visit<BB>(vis, lane == 0, ep);                   // core.rs:617
+    tagset_clear<BB, DB>(vis, lane);                                  // core.rs:614
+    (void)tagset_visit<BB, DB>(vis, lane == 0, ep);                   // core.rs:617
     vis.count = 1;
     const uint32_t *row = row_ptr(g, ep, lc);
     uint32_t word = (uint32_t)lane < stride ? row[lane] : 0u;     // requested before the distance is computed
@@ -157,7 +160,7 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
                 }
                 const uint32_t li = (uint32_t)lane - (c0 + 1);
                 const bool was_lossy = vis.lossy;
-                const uint64_t fm = __ballot(tagset_visit<BB>(vis, li < nch, word));
+                const uint64_t fm = __ballot(tagset_visit<BB, DB>(vis, li < nch, word));
                 if (vis.lossy && !was_lossy && lane == 0) atomicAdd(lossy_ctr, 1ull);
                 const uint32_t nf = (uint32_t)__popcll(fm);
                 vis.count += nf;
@@ -246,7 +249,7 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
 }
 
 // HNSW.SEARCH (core.rs:477-486 -> :865-892): one wave per query, grid-stride over the batch.
-template <int T, int R, int BB>
+template <int T, int R, int BB, int DB>
 __global__ __launch_bounds__(64) void k_search_lean(GraphView g, const float *__restrict__ Q, uint32_t B, uint32_t k,
                                                     uint32_t ef, uint32_t lcap, uint32_t idbits,
                                                     uint32_t *__restrict__ out_ids, float *__restrict__ out_sims,
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(64) void k_search_lean(GraphView g, const float *__
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
     uint64_t *Wbuf = reinterpret_cast<uint64_t *>(smem);                       // [R*64]
-    TagSet<BB> vis;
+    TagSet<BB, DB> vis;
     vis.tab = reinterpret_cast<uint32_t *>(smem + (size_t)R * 64 * 8);
     vis.idbits = idbits;
     vis.lcap = lcap;
@@ -269,11 +272,11 @@ __global__ __launch_bounds__(64) void k_search_lean(GraphView g, const float *__
         load_query<MODE_AVX, T>(Q + (size_t)qi * g.dim, g.dim, qr, nullptr, lane);
         uint32_t ep = (uint32_t)ep0;
         for (uint32_t lc = lmax; lc >= 1; --lc) {  // core.rs:870-874
-            search_level_lean<T, 1, BB>(g, Wbuf, vis, qr, ep, 1, lc, ctr, lane, &g.hdr->ctr_search[3]);
+            search_level_lean<T, 1, BB, DB>(g, Wbuf, vis, qr, ep, 1, lc, ctr, lane, &g.hdr->ctr_search[3]);
             ep = key_id(Wbuf[0]);                  // core.rs:872
             __builtin_amdgcn_wave_barrier();
         }
-        const uint32_t nW = search_level_lean<T, R, BB>(g, Wbuf, vis, qr, ep, ef, 0, ctr, lane, &g.hdr->ctr_search[3]); // core.rs:876
+        const uint32_t nW = search_level_lean<T, R, BB, DB>(g, Wbuf, vis, qr, ep, ef, 0, ctr, lane, &g.hdr->ctr_search[3]); // core.rs:876
         // core.rs:878-890: nearest first, min(k, |W|) results; sim = -dist (metrics.rs:75)
         const uint32_t nres = nW < k ? nW : k;
         for (uint32_t i = lane; i < k; i += 64) {

@@ -202,6 +202,14 @@ def test_search_parity_with_the_id_range_of_a_10m_index(eng, oracle_mod, built, 
     gi.set_tuning("tag_bb", 10)
     ids2, sims2, _ = gi.search_batch(Q, k)
     assert np.array_equal(ids2, oids) and np.array_equal(_bits(sims2), _bits(osims))
+    # the launch shape of eight waves per CU (here: 96 queries announced as one of 16 concurrent launches):
+    # the specialised kernel's 1024-bucket table, whose entries keep 2 displacement bits at 2^24 ids
+    gi.set_tuning("tag_bb", -1)
+    gi.set_tuning("visited_bounded", 1)
+    gi.set_tuning("launch_concurrency", 8)
+    Qw = np.concatenate([Q, Q, Q])[:272]                       # 272 x 8 > 2048 waves: 8 per CU
+    ids3, sims3, _ = gi.search_batch(Qw, k)
+    assert np.array_equal(ids3[:nq], oids) and np.array_equal(_bits(sims3[:nq]), _bits(osims))
     gi.close()
 
 
