@@ -65,6 +65,7 @@ struct hnsw_index {
     bool asymmetric = false;        // links may be one-directional (the fast build prunes that way; imports are checked)
     uint32_t lds_fill_x2 = 13;       // LDS visited table holds lnb * fill/2 ids (of 7 per bucket) before spilling
     int grid_override = -1;
+    bool bf16 = false;               // vectors are stored as bf16 (compress_bf16): read-only, dim 128, specialised kernel only
     bool lean = true;                // dim-128 searches use the specialised kernel (hnsw_search_lean.hpp) when its preconditions hold
     bool visited_bounded = true;     // k_search: a full LDS visited table stops recording (exact results)
     uint32_t max_waves_per_cu = 8;
@@ -472,12 +473,12 @@ hnsw_status launch_search_r(hnsw_index *h, int R, const float *dQ, uint32_t B, u
 }
 
 // The specialised kernel: no HBM spill table involved, so no region bookkeeping either.
-template <int T, int R, int BB, int DB>
+template <class VEC, int R, int BB, int DB>
 hnsw_status launch_lean_t(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t idbits, uint32_t *d_ids,
                           float *d_sims, uint32_t *d_nout, hipStream_t st)
 {
     const size_t lds = (size_t)R * 64 * 8 + ((size_t)16 << BB);
-    auto kern = k_search_lean<T, R, BB, DB>;
+    auto kern = k_search_lean<VEC, R, BB, DB>;
     {
         static size_t lds_set[16] = {0};
         size_t &have = lds_set[h->device & 15];
@@ -508,7 +509,7 @@ hnsw_status try_launch_lean(hnsw_index *h, const float *dQ, uint32_t B, uint32_t
 {
     *done = false;
     const int R = pick_R(h->efc);
-    if (!h->lean || h->mode != MODE_AVX || h->T != 4 || !h->visited_bounded || !h->tag_table || h->tag_bb_override >= 0 ||
+    if (!h->lean || h->mode != MODE_AVX || h->dim != 128 || !h->visited_bounded || !h->tag_table || h->tag_bb_override >= 0 ||
         h->lds_buckets_override >= 0 || h->stride0 > 64 || h->strideU > 64 || (R != 1 && R != 4))
         return HNSW_OK;
     uint32_t per_cu = ((uint64_t)B * h->launch_concurrency + 255) / 256;
@@ -525,7 +526,10 @@ hnsw_status try_launch_lean(hnsw_index *h, const float *dQ, uint32_t B, uint32_t
         else return HNSW_OK;
     }
     *done = true;
-#define LEAN_CASE(RR, BBB, DDB) if (R == RR && bb == BBB && db == DDB) return launch_lean_t<4, RR, BBB, DDB>(h, dQ, B, k, idbits, d_ids, d_sims, d_nout, st);
+#define LEAN_CASE(RR, BBB, DDB)                                                                                  \
+    if (R == RR && bb == BBB && db == DDB)                                                                      \
+        return h->bf16 ? launch_lean_t<VecBF16<4>, RR, BBB, DDB>(h, dQ, B, k, idbits, d_ids, d_sims, d_nout, st) \
+                       : launch_lean_t<VecF32<4>, RR, BBB, DDB>(h, dQ, B, k, idbits, d_ids, d_sims, d_nout, st);
     LEAN_CASE(1, 10, 3) LEAN_CASE(1, 11, 3) LEAN_CASE(4, 10, 3) LEAN_CASE(4, 11, 3)
     LEAN_CASE(1, 10, 2) LEAN_CASE(1, 11, 2) LEAN_CASE(4, 10, 2) LEAN_CASE(4, 11, 2)
 #undef LEAN_CASE
@@ -540,6 +544,7 @@ hnsw_status launch_search(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k
     if (s != HNSW_OK) return s;
     bool done = false;
     if ((s = try_launch_lean(h, dQ, B, k, d_ids, d_sims, d_nout, st, &done)) != HNSW_OK || done) return s;
+    if (h->bf16) return fail(h, HNSW_ERR_INVALID, "bf16 storage is served by the specialised kernel only (dim 128, rows <= 63 ids, ef <= 256, default tuning)");
     const int R = pick_R(h->efc);
     if (h->mode == MODE_SCALAR) return launch_search_r<MODE_SCALAR, 0>(h, R, dQ, B, k, d_ids, d_sims, d_nout, st);
     if (h->T == 4) return launch_search_r<MODE_AVX, 4>(h, R, dQ, B, k, d_ids, d_sims, d_nout, st);
@@ -715,6 +720,27 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
     if (!std::strcmp(key, "grid")) { h->grid_override = (int)value; return HNSW_OK; }
     if (!std::strcmp(key, "time_launches")) { h->time_launches = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "launch_concurrency")) { h->launch_concurrency = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 8); return HNSW_OK; }
+    if (!std::strcmp(key, "compress_bf16")) {
+        // One way: the f32 vector matrix becomes a bf16 one (round to nearest even) and the index read-only.
+        // A separate, clearly-labelled serving mode: half the bytes of the gather; the
+        // arithmetic stays the reference's f32 kernel on the stored values, so results are those of the
+        // reference run on the bf16-rounded vectors (not on the original f32 ones).
+        if (!value || h->bf16) return HNSW_OK;
+        if (h->mode != MODE_AVX || h->dim != 128) return fail(h, HNSW_ERR_INVALID, "compress_bf16 supports dim 128");
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, hipDeviceSynchronize());
+        unsigned short *d16 = nullptr;
+        const size_t nel = (size_t)h->cap * h->dim;
+        HIP_TRY(h, hipMalloc((void **)&d16, std::max<size_t>(nel, 1) * 2));
+        hipLaunchKernelGGL(k_f32_to_bf16, dim3(4096), dim3(256), 0, h->stream, h->d_vec, d16, (size_t)h->n * h->dim);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        (void)hipFree(h->d_vec);
+        h->hbm_bytes -= std::min<uint64_t>(h->hbm_bytes, nel * 2);
+        h->d_vec = reinterpret_cast<float *>(d16);
+        h->bf16 = true;
+        return HNSW_OK;
+    }
     if (!std::strcmp(key, "lean")) { h->lean = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "query_in_lds")) {     // dims 128 / 768 normally keep the query in registers (T = dim/32)
         if (h->mode == MODE_AVX) h->T = value ? 0 : ((h->dim == 128 || h->dim == 768) ? (int)(h->dim / 32) : 0);
@@ -732,6 +758,7 @@ hnsw_status hnsw_add(hnsw_index *h, const float *v, uint32_t dim, int32_t level,
                      uint32_t *touched, uint32_t touched_cap, uint32_t *n_touched)
 {
     if (!h || !v) return HNSW_ERR_INVALID;
+    if (h->bf16) return fail(h, HNSW_ERR_INVALID, "the index is read-only in bf16 storage mode");
     if (dim != h->dim) {                         // core.rs:389-391
         char buf[96];
         snprintf(buf, sizeof buf, "data dimension: %u does not match Index", dim);
@@ -761,6 +788,7 @@ hnsw_status hnsw_add_batch(hnsw_index *h, const float *V, uint32_t n, uint32_t d
                            uint32_t mode)
 {
     if (!h || (!V && n)) return HNSW_ERR_INVALID;
+    if (h->bf16) return fail(h, HNSW_ERR_INVALID, "the index is read-only in bf16 storage mode");
     if (dim != h->dim) {
         char buf[96];
         snprintf(buf, sizeof buf, "data dimension: %u does not match Index", dim);
@@ -838,6 +866,7 @@ hnsw_status hnsw_delete(hnsw_index *h, uint32_t id, uint32_t *touched, uint32_t 
 {
     if (!h) return HNSW_ERR_INVALID;
     if (n_touched) *n_touched = 0;
+    if (h->bf16) return fail(h, HNSW_ERR_INVALID, "the index is read-only in bf16 storage mode");
     if (id >= h->n || h->h_dead[id]) {                          // core.rs:419-422
         char buf[64];
         snprintf(buf, sizeof buf, "Node: %u does not exist", id);
@@ -952,6 +981,7 @@ hnsw_status hnsw_import(hnsw_index *h, uint32_t n, const float *vectors, const u
                         const uint32_t *const *col)
 {
     if (!h) return HNSW_ERR_INVALID;
+    if (h->bf16) return fail(h, HNSW_ERR_INVALID, "the index is read-only in bf16 storage mode");
     if (h->n != 0) return fail(h, HNSW_ERR_INVALID, "hnsw_import needs an empty index");
     if (n == 0) return HNSW_OK;
     if (enterpoint < 0 || enterpoint >= (int64_t)n || n_layers == 0 || n_layers > kMaxLayers)
@@ -1076,6 +1106,17 @@ hnsw_status hnsw_get_vector(hnsw_index *h, uint32_t id, float *out)
     if (!h || !out) return HNSW_ERR_INVALID;
     if (id >= h->n) return fail(h, HNSW_ERR_NOT_FOUND, "node id out of range");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->bf16) {                                   // the stored (rounded) value, widened
+        std::vector<uint16_t> tmp(h->dim);
+        const uint16_t *src = reinterpret_cast<const uint16_t *>(h->d_vec) + (size_t)id * h->dim;
+        HIP_TRY(h, hipMemcpyAsync(tmp.data(), src, (size_t)h->dim * 2, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        for (uint32_t i = 0; i < h->dim; ++i) {
+            const uint32_t u = (uint32_t)tmp[i] << 16;
+            std::memcpy(&out[i], &u, 4);
+        }
+        return HNSW_OK;
+    }
     HIP_TRY(h, hipMemcpyAsync(out, h->d_vec + (size_t)id * h->dim, (size_t)h->dim * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return HNSW_OK;
@@ -1193,6 +1234,7 @@ hnsw_status hnsw_serialize_size(hnsw_index *h, uint64_t *bytes)
 hnsw_status hnsw_serialize(hnsw_index *h, void *buf, uint64_t cap, uint64_t *written)
 {
     if (!h || !buf || !written) return HNSW_ERR_INVALID;
+    if (h->bf16) return fail(h, HNSW_ERR_INVALID, "snapshots are taken from the f32 index (bf16 storage is a derived serving copy)");
     uint64_t need = 0;
     hnsw_status s = hnsw_serialize_size(h, &need);
     if (s != HNSW_OK) return s;

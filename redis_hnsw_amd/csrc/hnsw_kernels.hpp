@@ -242,6 +242,16 @@ __global__ void k_count_asymmetric(const uint32_t *__restrict__ adj, uint32_t st
     if (bad && lane == 0) atomicAdd(out, (unsigned long long)bad);
 }
 
+// f32 -> bf16, round to nearest even (finite inputs: the host entry points refuse anything else)
+__global__ void k_f32_to_bf16(const float *__restrict__ src, unsigned short *__restrict__ dst, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t u = __float_as_uint(src[i]);
+        dst[i] = (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+    }
+}
+
 // -inf fill (similarities of an empty result)
 __global__ void k_fill_f32(float *p, size_t n, float v)
 {

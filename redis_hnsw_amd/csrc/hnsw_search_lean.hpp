@@ -76,24 +76,96 @@ __device__ __forceinline__ bool tagset_visit(TagSet<BB, DB> &v, bool valid, uint
     return state != 0u;
 }
 
-// squared distance of one vector (id) for this lane's 8-lane group, AVX2 order (metrics.rs:48-77)
+// ---- vector formats ------------------------------------------------------------------------------------
+// f32 rows (the reference's data): 8 lanes per vector, each the 16-byte piece piece_of_lane() of every
+// 128-byte block; 8 vectors per round, 4 rounds per chunk of 32 ids.  AVX2 order of metrics.rs:48-77.
 template <int T>
-__device__ __forceinline__ void lean_load(const float4 *vec4, uint32_t row4, uint32_t id, int pp, float4 (&v)[T])
-{
-    const float4 *p = vec4 + (size_t)id * row4 + pp;
+struct VecF32 {
+    static constexpr int LPV = 8, SPR = 8, NR = 4;
+    struct Q { float4 q[T]; };
+    struct V { float4 v[T]; };
+    static __device__ __forceinline__ void load_q(const float *src, Q &q, int lane)
+    {
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        const int pp = piece_of_lane(lane);
 #pragma unroll
-    for (int t = 0; t < T; ++t) v[t] = p[t * 8];
-}
+        for (int t = 0; t < T; ++t) q.q[t] = s4[t * 8 + pp];
+    }
+    static __device__ __forceinline__ void load_v(const GraphView &g, uint32_t id, int lane, V &v)
+    {
+        const float4 *p = reinterpret_cast<const float4 *>(g.vec) + (size_t)id * (g.dim >> 2) + piece_of_lane(lane);
+#pragma unroll
+        for (int t = 0; t < T; ++t) v.v[t] = p[t * 8];
+    }
+    static __device__ __forceinline__ float dist(const Q &q, const V &v) { return avx_reduce(avx_accumulate<T>(q.q, v.v)); }
+};
+
+// bf16 rows (the compressed, read-only serving copy: hnsw_set_tuning "compress_bf16"): half the bytes per
+// vector.  The arithmetic is the reference's f32 AVX2 kernel applied to the stored values widened back to
+// f32 -- same 4 x 8 accumulators, same FMA order in t, same reduction tree -- so results are bit-identical
+// to the reference run on the bf16-rounded vectors.  A 16-byte load is 8 consecutive elements = the 8 AVX
+// lanes of ONE accumulator of one 32-element block, so a vector takes 4 lanes (lane a = accumulator a),
+// 16 vectors per round, 2 rounds per chunk.
+template <int T>
+struct VecBF16 {
+    static constexpr int LPV = 4, SPR = 16, NR = 2;
+    struct Q { f32x2 q[T][4]; };          // q[t][k] = elements 32t + 8a + 2k, +1
+    struct V { uint4 x[T]; };
+    static __device__ __forceinline__ void load_q(const float *src, Q &q, int lane)
+    {
+        const int a = lane & 3;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const float4 lo = *reinterpret_cast<const float4 *>(src + 32 * t + 8 * a);
+            const float4 hi = *reinterpret_cast<const float4 *>(src + 32 * t + 8 * a + 4);
+            q.q[t][0] = f32x2{lo.x, lo.y}; q.q[t][1] = f32x2{lo.z, lo.w};
+            q.q[t][2] = f32x2{hi.x, hi.y}; q.q[t][3] = f32x2{hi.z, hi.w};
+        }
+    }
+    static __device__ __forceinline__ void load_v(const GraphView &g, uint32_t id, int lane, V &v)
+    {
+        // row = dim bf16 = dim/8 pieces of 16 bytes; block t is pieces 4t .. 4t+3
+        const uint4 *p = reinterpret_cast<const uint4 *>(g.vec) + (size_t)id * (g.dim >> 3) + (lane & 3);
+#pragma unroll
+        for (int t = 0; t < T; ++t) v.x[t] = p[t * 4];
+    }
+    static __device__ __forceinline__ f32x2 widen(uint32_t w)      // two bf16 -> two f32 (exact)
+    {
+        return f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xFFFF0000u)};
+    }
+    static __device__ __forceinline__ float dist(const Q &q, const V &v)
+    {
+        f32x2 acc[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};   // AVX lanes j = 2k, 2k+1
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const uint32_t w[4] = {v.x[t].x, v.x[t].y, v.x[t].z, v.x[t].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x2 d = q.q[t][k] - widen(w[k]);
+                acc[k] = __builtin_elementwise_fma(d, d, acc[k]);                            // metrics.rs:57,60,64,68
+            }
+        }
+        // (e1+e2)+(e3+e4) per AVX lane (metrics.rs:71-74): the accumulators are the 4 lanes of a quad
+        float e[8] = {acc[0].x, acc[0].y, acc[1].x, acc[1].y, acc[2].x, acc[2].y, acc[3].x, acc[3].y};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            e[j] = __fadd_rn(e[j], dpp_mov<DPP_QUAD_XOR1>(e[j]));
+            e[j] = __fadd_rn(e[j], dpp_mov<DPP_QUAD_XOR2>(e[j]));
+        }
+        // low128 + high128 (metrics.rs:37-39), then (s0+s1)+(s2+s3) (:27-31)
+        const float s0 = __fadd_rn(e[0], e[4]), s1 = __fadd_rn(e[1], e[5]), s2 = __fadd_rn(e[2], e[6]), s3 = __fadd_rn(e[3], e[7]);
+        return __fadd_rn(__fadd_rn(s0, s1), __fadd_rn(s2, s3));
+    }
+};
 
 // search_level (core.rs:607-675) with W in registers; leaves w[] sorted (also copied to Wbuf) and returns |W|.
-template <int T, int R, int BB, int DB>
+template <class VEC, int R, int BB, int DB>
 __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64_t *Wbuf, TagSet<BB, DB> &vis,
-                                                      const QReg<T> &qr, uint32_t ep, uint32_t ef, uint32_t lc,
+                                                      const typename VEC::Q &qr, uint32_t ep, uint32_t ef, uint32_t lc,
                                                       WorkCtr &ctr, int lane, unsigned long long *lossy_ctr)
 {
-    const int grp = lane >> 3, pp = piece_of_lane(lane), sub = lane & 7;
-    const float4 *vec4 = reinterpret_cast<const float4 *>(g.vec);
-    const uint32_t row4 = g.dim >> 2;
+    constexpr int LPV = VEC::LPV, SPR = VEC::SPR, NR = VEC::NR;   // lanes per vector, vectors per round, rounds per chunk
+    const int grp = lane / LPV, sub = lane % LPV;
     const uint32_t stride = lc ? g.strideU : g.stride0;          // <= 64: a row is one wave load
 
     tagset_clear<BB, DB>(vis, lane);                                  // core.rs:614
@@ -106,9 +178,9 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
     for (int r = 0; r < R; ++r) w[r] = ~0ull;
     uint64_t ckey;
     {
-        float4 v0[T];
-        lean_load<T>(vec4, row4, ep, pp, v0);
-        const float d = avx_reduce(avx_accumulate<T>(qr.q, v0)); // core.rs:621
+        typename VEC::V v0;
+        VEC::load_v(g, ep, lane, v0);
+        const float d = VEC::dist(qr, v0);                        // core.rs:621
         ctr.n_dist += 1;
         ckey = pack_key(d, ep);
         if (lane == 0) w[0] = ckey | 1ull;                        // core.rs:627-628, popped right away (:631)
@@ -139,20 +211,19 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
             uint64_t rkey = ~0ull;                                // first unexpanded entry of W (last chunk only)
             uint32_t word_spec = 0;                               // ... and its adjacency row, requested early
             if (nch) {
-                // slot s = r*8 + grp of this chunk sits in lane c0 + 1 + s; empty slots re-read the first id
+                // slot s = r*SPR + grp of this chunk sits in lane c0 + 1 + s; empty slots re-read the first id
                 const uint32_t safe = (uint32_t)__builtin_amdgcn_readlane((int)word, (int)(c0 + 1));
-                uint32_t idr[4];
+                uint32_t idr[NR];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const uint32_t s = (uint32_t)(r * 8 + grp);
+                for (int r = 0; r < NR; ++r) {
+                    const uint32_t s = (uint32_t)(r * SPR + grp);
                     const uint32_t got = bperm(word, (int)((c0 + 1 + s) & 63u));
                     idr[r] = s < nch ? got : safe;
                 }
-                float4 v[4][T];
-                lean_load<T>(vec4, row4, idr[0], pp, v[0]);
-                if (nch > 8) lean_load<T>(vec4, row4, idr[1], pp, v[1]);
-                if (nch > 16) lean_load<T>(vec4, row4, idr[2], pp, v[2]);
-                if (nch > 24) lean_load<T>(vec4, row4, idr[3], pp, v[3]);
+                typename VEC::V v[NR];
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+                    if (r == 0 || nch > (uint32_t)(r * SPR)) VEC::load_v(g, idr[r], lane, v[r]);   // uniform: skipped rounds cost nothing
                 // ---- under those loads: visited filter (core.rs:648-649) and the deferred merge ----
                 if (!vis.lossy && vis.count + 32u > vis.lcap) {
                     vis.lossy = true;
@@ -182,16 +253,16 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
                 }
                 // ---- distances ----
                 float dsel = 0.f;
-                {
-                    const float d0 = avx_reduce(avx_accumulate<T>(qr.q, v[0]));
-                    dsel = d0;
-                    if (nch > 8) { const float d1 = avx_reduce(avx_accumulate<T>(qr.q, v[1])); dsel = sub == 1 ? d1 : dsel; }
-                    if (nch > 16) { const float d2 = avx_reduce(avx_accumulate<T>(qr.q, v[2])); dsel = sub == 2 ? d2 : dsel; }
-                    if (nch > 24) { const float d3 = avx_reduce(avx_accumulate<T>(qr.q, v[3])); dsel = sub == 3 ? d3 : dsel; }
-                }
-                const uint32_t myslot = (uint32_t)(sub * 8 + grp);
-                const uint32_t idsel = sub == 0 ? idr[0] : sub == 1 ? idr[1] : sub == 2 ? idr[2] : idr[3];
-                const bool mine = sub < 4 && myslot < nch && ((fm >> ((c0 + 1 + myslot) & 63u)) & 1ull);
+                uint32_t idsel = idr[0];
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+                    if (r == 0 || nch > (uint32_t)(r * SPR)) {
+                        const float dr = VEC::dist(qr, v[r]);                                        // core.rs:652
+                        dsel = (r == 0 || sub == r) ? dr : dsel;
+                        idsel = (r == 0 || sub == r) ? idr[r] : idsel;
+                    }
+                const uint32_t myslot = (uint32_t)(sub * SPR + grp);
+                const bool mine = sub < NR && myslot < nch && ((fm >> ((c0 + 1 + myslot) & 63u)) & 1ull);
                 key = pack_key(dsel, idsel);
                 take = mine && key < worst;                       // core.rs:657
                 if (vis.lossy) take = drop_members<R>(w, key, take, lane);
@@ -249,7 +320,7 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
 }
 
 // HNSW.SEARCH (core.rs:477-486 -> :865-892): one wave per query, grid-stride over the batch.
-template <int T, int R, int BB, int DB>
+template <class VEC, int R, int BB, int DB>
 __global__ __launch_bounds__(64) void k_search_lean(GraphView g, const float *__restrict__ Q, uint32_t B, uint32_t k,
                                                     uint32_t ef, uint32_t lcap, uint32_t idbits,
                                                     uint32_t *__restrict__ out_ids, float *__restrict__ out_sims,
@@ -268,15 +339,15 @@ __global__ __launch_bounds__(64) void k_search_lean(GraphView g, const float *__
     const int32_t ep0 = g.hdr->enterpoint;        // core.rs:866
     const uint32_t lmax = g.hdr->max_layer;       // core.rs:867
     for (uint32_t qi = blockIdx.x; qi < B; qi += gridDim.x) {
-        QReg<T> qr;
-        load_query<MODE_AVX, T>(Q + (size_t)qi * g.dim, g.dim, qr, nullptr, lane);
+        typename VEC::Q qr;
+        VEC::load_q(Q + (size_t)qi * g.dim, qr, lane);
         uint32_t ep = (uint32_t)ep0;
         for (uint32_t lc = lmax; lc >= 1; --lc) {  // core.rs:870-874
-            search_level_lean<T, 1, BB, DB>(g, Wbuf, vis, qr, ep, 1, lc, ctr, lane, &g.hdr->ctr_search[3]);
+            search_level_lean<VEC, 1, BB, DB>(g, Wbuf, vis, qr, ep, 1, lc, ctr, lane, &g.hdr->ctr_search[3]);
             ep = key_id(Wbuf[0]);                  // core.rs:872
             __builtin_amdgcn_wave_barrier();
         }
-        const uint32_t nW = search_level_lean<T, R, BB, DB>(g, Wbuf, vis, qr, ep, ef, 0, ctr, lane, &g.hdr->ctr_search[3]); // core.rs:876
+        const uint32_t nW = search_level_lean<VEC, R, BB, DB>(g, Wbuf, vis, qr, ep, ef, 0, ctr, lane, &g.hdr->ctr_search[3]); // core.rs:876
         // core.rs:878-890: nearest first, min(k, |W|) results; sim = -dist (metrics.rs:75)
         const uint32_t nres = nW < k ? nW : k;
         for (uint32_t i = lane; i < k; i += 64) {

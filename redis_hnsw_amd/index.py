@@ -274,6 +274,12 @@ class Index:
         self._ids = {nm: j for j, nm in enumerate(self._names) if nm is not None}
         return self
 
+    def _vector(self, i):
+        """the stored vector of node id i (hnsw_get_vector)"""
+        out = np.zeros(self.data_dim, dtype=np.float32)
+        self._check(self._lib.hnsw_get_vector(self._h, int(i), _fp(out)))
+        return out
+
     def neighbors(self, i, layer):
         inf = self.info()
         cap = int(max(inf.stride0, inf.stride_upper))

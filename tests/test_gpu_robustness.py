@@ -236,3 +236,63 @@ def test_reference_rdb_layout_round_trip_through_the_engine(eng, oracle_mod):
     assert set(na) == set(nb)
     assert all(rdb.load_node(na[k]) == rdb.load_node(nb[k]) for k in na)
     a.close(); b.close()
+
+
+def _bf16_round(V):
+    """f32 -> bf16 (round to nearest even) -> f32: the values the compressed index stores"""
+    u = np.ascontiguousarray(V, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32).reshape(V.shape)
+
+
+def test_bf16_storage_mode_is_the_reference_on_rounded_vectors(eng, oracle_mod):
+    """SURVEY 8 f-4, first step: a read-only serving copy with bf16 vectors (half the gather bytes).  The
+    arithmetic stays the reference's f32 AVX2 kernel on the stored values, so the mode is checked EXACTLY:
+    ids and similarity bits equal the oracle's on the same graph with bf16-rounded vectors.  Against the f32
+    index the similarities move by at most 2^-7 relative (each component carries <= 2^-9 relative rounding
+    error; squared differences of values in [0,1) amplify it), and the top-10 sets overlap almost entirely."""
+    n, dim, m, ef, k, nq = 3000, 128, 16, 200, 10, 96
+    V = make_data(n, dim, seed=1)
+    lv = oracle_mod.draw_levels(n, m, 7)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch(V, lv)
+    g = o.export()
+    gi = eng.Index("b", dim, m, ef)
+    gi.import_graph(g)
+    Q = make_data(nq, dim, seed=2)
+    ids32, sims32, _ = gi.search_batch(Q, k)
+    bytes32 = gi.info().hbm_bytes
+    gi.set_tuning("compress_bf16", 1)
+    assert gi.info().hbm_bytes <= bytes32 - n * dim * 2            # the vector matrix halved
+    g16 = dict(g)
+    g16["vectors"] = _bf16_round(V)
+    o16 = oracle_mod.OracleIndex.from_graph(dim, m, ef, g16)
+    oids, osims, on, oct = o16.search_batch(Q, k)
+    gi.reset_counters()
+    ids, sims, n_out = gi.search_batch(Q, k)
+    assert np.array_equal(n_out, on) and np.array_equal(ids, oids) and np.array_equal(_bits(sims), _bits(osims))
+    sc, _ = gi.counters()
+    assert (sc.n_dist, sc.n_ids, sc.n_expand) == (oct.n_dist, oct.n_ids, oct.n_expand)
+    # the 8-waves-per-CU launch shape and the single-query entry point
+    gi.set_tuning("launch_concurrency", 8)
+    Qw = np.concatenate([Q, Q, Q])[:272]
+    idsw, simsw, _ = gi.search_batch(Qw, k)
+    assert np.array_equal(idsw[:nq], oids) and np.array_equal(_bits(simsw[:nq]), _bits(osims))
+    r = gi.search_knn(Q[0], k)
+    assert [x.id for x in r] == oids[0].tolist()
+    # stored value of a vector = its bf16 rounding
+    assert np.array_equal(_bits(gi._vector(5)), _bits(_bf16_round(V[5:6])[0]))
+    # tolerance against the f32 index, stated: similarities within 2^-7 relative on shared ids, overlap >= 0.97
+    overlap = np.mean([len(set(a.tolist()) & set(b.tolist())) / k for a, b in zip(ids, ids32)])
+    assert overlap >= 0.97
+    for a, sa, b, sb in zip(ids, sims, ids32, sims32):
+        common = {int(x): float(s) for x, s in zip(b, sb)}
+        for x, s in zip(a, sa):
+            if int(x) in common:
+                assert abs(float(s) - common[int(x)]) <= 2.0 ** -7 * abs(common[int(x)])
+    # read-only
+    with pytest.raises(eng.HNSWError):
+        gi.add_node("late", V[0])
+    with pytest.raises(eng.HNSWError):
+        gi.delete_node("node3")
+    gi.close()
