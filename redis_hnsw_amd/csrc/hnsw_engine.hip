@@ -300,7 +300,8 @@ uint32_t pick_lnb(const hnsw_index *h, int R, int T, bool ins, uint32_t nwaves)
     if (h->lds_buckets_override >= 2) return (uint32_t)h->lds_buckets_override;
     // measured on MI355X: 40448 B per 64-thread block still gives 4 blocks per CU, 40960 B does not
     // (163840 / n - 512); 5..8 per CU follow the same rule, rounded down to 256 B
-    const size_t tiers[8] = {160 * 1024 - 2048, 80896, 53760, 40448, 32256, 26624, 22784, 19968};
+    const size_t tiers[16] = {160 * 1024 - 2048, 80896, 53760, 40448, 32256, 26624, 22784, 19968,
+                              17664, 15872, 14336, 13056, 12032, 11008, 10240, 9728};
     // the insert kernels keep the exact HBM spill path: give them the larger table
     // ... and so does the dim-768 search: its kernel holds the query and 24 loads in registers (> 256 VGPRs:
     // one wave per SIMD whatever the LDS share), so a smaller table would only forget more
@@ -474,8 +475,8 @@ hnsw_status launch_search_r(hnsw_index *h, int R, const float *dQ, uint32_t B, u
 
 // The specialised kernel: no HBM spill table involved, so no region bookkeeping either.
 template <class VEC, int R, int BB, int DB>
-hnsw_status launch_lean_t(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t idbits, uint32_t *d_ids,
-                          float *d_sims, uint32_t *d_nout, hipStream_t st)
+hnsw_status launch_lean_t(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t idbits, uint32_t per_cu,
+                          uint32_t *d_ids, float *d_sims, uint32_t *d_nout, hipStream_t st)
 {
     const size_t lds = (size_t)R * 64 * 8 + ((size_t)16 << BB);
     auto kern = k_search_lean<VEC, R, BB, DB>;
@@ -488,7 +489,8 @@ hnsw_status launch_lean_t(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k
             have = lds;
         }
     }
-    uint32_t grid = std::min(B, 2048u);
+    // as many blocks as the CUs hold at this table size; a larger batch is walked grid-stride
+    uint32_t grid = std::min(B, 256u * std::max(per_cu, 8u));
     if (h->grid_override > 0) grid = std::min<uint32_t>(grid, (uint32_t)h->grid_override);
     if (h->time_launches) HIP_TRY(h, hipEventRecord(h->ev0, st));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, st, view(h), dQ, B, k, h->efc, (1u << BB) * 6u, idbits, d_ids, d_sims,
@@ -514,7 +516,8 @@ hnsw_status try_launch_lean(hnsw_index *h, const float *dQ, uint32_t B, uint32_t
         return HNSW_OK;
     uint32_t per_cu = ((uint64_t)B * h->launch_concurrency + 255) / 256;
     per_cu = std::min(std::max(per_cu, 1u), h->max_waves_per_cu);
-    uint32_t bb = per_cu >= 5 ? 10 : 11;
+    // 32 KB table at <= 4 waves per CU, 16 KB at <= 8, 8 KB beyond (tuning waves_per_cu > 8)
+    uint32_t bb = per_cu >= 9 ? 9 : (per_cu >= 5 ? 10 : 11);
     uint32_t idbits = std::max(ceil_log2(std::max(h->cap, 2u)), 11u);
     if (h->idbits_override > (int)idbits && h->idbits_override <= 31) idbits = (uint32_t)h->idbits_override;
     // 16-bit entries: tag (idbits - bb bits) + displacement.  3 displacement bits normally; 2^24 ids at 1024
@@ -528,10 +531,11 @@ hnsw_status try_launch_lean(hnsw_index *h, const float *dQ, uint32_t B, uint32_t
     *done = true;
 #define LEAN_CASE(RR, BBB, DDB)                                                                                  \
     if (R == RR && bb == BBB && db == DDB)                                                                      \
-        return h->bf16 ? launch_lean_t<VecBF16<4>, RR, BBB, DDB>(h, dQ, B, k, idbits, d_ids, d_sims, d_nout, st) \
-                       : launch_lean_t<VecF32<4>, RR, BBB, DDB>(h, dQ, B, k, idbits, d_ids, d_sims, d_nout, st);
+        return h->bf16 ? launch_lean_t<VecBF16<4>, RR, BBB, DDB>(h, dQ, B, k, idbits, per_cu, d_ids, d_sims, d_nout, st) \
+                       : launch_lean_t<VecF32<4>, RR, BBB, DDB>(h, dQ, B, k, idbits, per_cu, d_ids, d_sims, d_nout, st);
     LEAN_CASE(1, 10, 3) LEAN_CASE(1, 11, 3) LEAN_CASE(4, 10, 3) LEAN_CASE(4, 11, 3)
     LEAN_CASE(1, 10, 2) LEAN_CASE(1, 11, 2) LEAN_CASE(4, 10, 2) LEAN_CASE(4, 11, 2)
+    LEAN_CASE(1, 9, 3) LEAN_CASE(4, 9, 3)
 #undef LEAN_CASE
     *done = false;
     return HNSW_OK;
@@ -747,7 +751,7 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
         return HNSW_OK;
     }
     if (!std::strcmp(key, "visited_bounded")) { h->visited_bounded = value != 0; return HNSW_OK; }
-    if (!std::strcmp(key, "waves_per_cu")) { h->max_waves_per_cu = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 8); return HNSW_OK; }
+    if (!std::strcmp(key, "waves_per_cu")) { h->max_waves_per_cu = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 16); return HNSW_OK; }
     if (!std::strcmp(key, "fast_seed")) { h->fast_seed = (uint32_t)std::max<int64_t>(value, 1); return HNSW_OK; }
     if (!std::strcmp(key, "fast_batch_max")) { h->fast_batch_max = (uint32_t)std::max<int64_t>(value, 1); return HNSW_OK; }
     if (!std::strcmp(key, "fast_batch_div")) { h->fast_batch_div = (uint32_t)std::max<int64_t>(value, 1); return HNSW_OK; }
