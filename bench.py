@@ -264,8 +264,14 @@ def main():
                 gathered[s_].record(comm_stream)
 
     log("inputs resident; warm-up")
-    for i in range(max(args.warmup, 0)):
+    # the clocks of an idle GPU need more than a few half-millisecond launches to settle: a fixed number of
+    # untimed launches first (reported as config.prewarm_launches), then the W warm-up steps asked for
+    PREWARM = 48
+    for i in range(PREWARM):
         step(i)
+    torch.cuda.synchronize()
+    for i in range(max(args.warmup, 0)):
+        step(PREWARM + i)
     torch.cuda.synchronize()
     index.reset_counters()
     if world > 1:
@@ -274,11 +280,16 @@ def main():
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
     per_stream = [len(range(s_, args.steps, S)) for s_ in range(S)]
+    marks = [[] for _ in range(S)]                   # one event after every launch, on its stream
     t_start = time.perf_counter()
     for s_ in range(S):
         ev0[s_].record(streams[s_])
     for i in range(args.steps):
-        step(args.warmup + i)
+        step(PREWARM + args.warmup + i)
+        if world == 1:
+            e_ = torch.cuda.Event(enable_timing=True)
+            e_.record(streams[i % S])
+            marks[i % S].append(e_)
     for s_ in range(S):
         ev1[s_].record(streams[s_])
     torch.cuda.synchronize()
@@ -292,6 +303,15 @@ def main():
     # average duration of ONE k_search launch: launches on a stream run back to back, so the stream's
     # elapsed time / its launches (what rocprofv3 --kernel-trace reports as the kernel's average)
     kernel_ms = float(np.mean([ev0[s_].elapsed_time(ev1[s_]) / per_stream[s_] for s_ in range(S) if per_stream[s_]]))
+    # per-launch durations (launches on a stream run back to back): robust against a short timed region
+    per_launch = []
+    for s_ in range(S):
+        prev = ev0[s_]
+        for e_ in marks[s_]:
+            per_launch.append(prev.elapsed_time(e_))
+            prev = e_
+    kernel_ms_median = float(np.median(per_launch)) if per_launch else None
+    kernel_ms_p90 = float(np.percentile(per_launch, 90)) if per_launch else None
     log("timed region done: %.3f ms/step, %.3f ms per launch with %d in flight" % (1e3 * t_wall / args.steps, kernel_ms, S))
     sc, _ = index.counters()
 
@@ -497,7 +517,10 @@ def main():
         pass
     roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                    kernel="k_search", kernel_ms=round(kernel_ms, 4), launches_in_flight=in_flight,
+                    kernel="k_search", kernel_ms=round(kernel_ms, 4),
+                    kernel_ms_median=None if kernel_ms_median is None else round(kernel_ms_median, 4),
+                    kernel_ms_p90=None if kernel_ms_p90 is None else round(kernel_ms_p90, 4),
+                    launches_in_flight=in_flight,
                     per_launch_gbs=round(per_launch, 1),
                     note="achieved = launches_in_flight x algorithmic_bytes_per_launch / kernel_ms (average duration of one launch, HIP events per stream)",
                     algorithmic_bytes_per_launch=int(bytes_per_launch),
@@ -582,7 +605,7 @@ def main():
         "config": {"workload": "%s: %d nodes x dim %d, M=%d, ef=%d, k=%d, batch=%d queries/GPU, uniform[0,1) f32, replicated index"
                                % (cfg_name, N, dim, M, ef, k, B),
                    "nodes": N, "dim": dim, "M": M, "ef": ef, "k": k, "batch": B, "graph": mode, "graph_desc": graph_desc,
-                   "steps_in_flight": S,
+                   "steps_in_flight": S, "prewarm_launches": PREWARM,
                    "parallelism": "replica x%d, query batch sharded%s" % (
                        world, " (ranks share one device, gloo: functional check only)" if one_device and world > 1 else "")},
         "gather_verified": gather_ok,
