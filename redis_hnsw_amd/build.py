@@ -8,7 +8,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libhnsw_mi355x.so")
 SOURCES = ["hnsw_engine.hip"]
-DEPS = ["hnsw_engine.hip", "hnsw_device.hpp", "hnsw_kernels.hpp", "hnsw_insert.hpp", "hnsw_insert_host.inc",
+DEPS = ["hnsw_engine.hip", "hnsw_device.hpp", "hnsw_kernels.hpp", "hnsw_insert.hpp", "hnsw_insert_host.inc", "hnsw_search_lean.hpp", "hnsw_occ.hpp",
         os.path.join("..", "..", "include", "hnsw_mi355x.h")]
 # -ffp-contract=off: the metric must round exactly where the reference's does
 # (explicit fma only, metrics.rs:57); never -ffast-math.

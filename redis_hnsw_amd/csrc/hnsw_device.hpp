@@ -610,8 +610,25 @@ __device__ __forceinline__ void carve(unsigned char *smem, uint32_t dim, uint32_
     vis.idbits = tagcfg >> 8;
 }
 
+// One entry of a plan's read log (hnsw_occ.hpp: exact-order parallel insert).  A plan stays valid as long as
+// no row it read changed in a way that matters: `bound` = the distance bits of the accept threshold that was
+// in force when the row was read (W's furthest for a search_level expansion, core.rs:657; the last selected
+// for select_neighbors, core.rs:724-754), `full` clear = everything mattered (W / the selection not full yet).
+struct OccRead {
+    uint32_t row;
+    uint32_t meta;      // layer [0,5) | kind [5,7) | sub-operation [7,13) | full [13]
+    uint32_t bound;
+};
+constexpr uint32_t OCC_SEARCH = 0, OCC_SELECT = 1, OCC_SHRINK_NB = 2, OCC_SHRINK_ROW = 3;
+__host__ __device__ inline uint32_t occ_meta(uint32_t lc, uint32_t kind, uint32_t sub, bool full)
+{
+    return (lc & 31u) | (kind << 5) | ((sub & 63u) << 7) | (full ? 1u << 13 : 0u);
+}
+
 struct WorkCtr {
     uint32_t n_dist, n_ids, n_expand;
+    OccRead *log;            // nullptr: no read log
+    uint32_t log_n, log_cap; // entries written / capacity (log_n keeps counting past the capacity)
 #ifdef HNSW_PHASE_TIMERS
     unsigned long long ph[8];
 #endif
@@ -664,6 +681,8 @@ __device__ __forceinline__ uint32_t search_level_v1(const GraphView &g, const Wa
         __syncthreads();
         if (lane == 0) m.W[pos] = ckey | 1ull;
         ctr.n_expand += 1;
+        const uint32_t log_idx = ctr.log_n;
+        if (ctr.log) ctr.log_n += 1;
 
         const uint32_t *row = row_ptr(g, c, lc);          // core.rs:645
         uint32_t word = (uint32_t)lane < stride ? row[lane] : 0u;
@@ -696,6 +715,9 @@ __device__ __forceinline__ uint32_t search_level_v1(const GraphView &g, const Wa
             PH_MARK(ctr, 3);  // merge into W
         }
         __syncthreads();
+        // read log: the accept threshold once this row's keys are in (what a later change of the row is judged by)
+        if (ctr.log && lane == 0 && log_idx < ctr.log_cap)
+            ctr.log[log_idx] = OccRead{c, occ_meta(lc, OCC_SEARCH, 0, nW == ef), nW == ef ? (uint32_t)(m.W[ef - 1] >> 32) : 0u};
     }
     return nW;
 }
@@ -926,12 +948,32 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
     uint32_t pup[R], ppos = 0;     // its ranks, computed under the row-fetch latency
 #pragma unroll
     for (int r = 0; r < R; ++r) pup[r] = 0;
+    uint32_t log_cur = kEmpty, log_prev = kEmpty;     // read-log entries of this / the previous expansion
+#define OCC_PATCH_BOUND(idx)                                                                         \
+    do {                                                                                             \
+        if (ctr.log && (idx) < ctr.log_cap && lane == 0) {                                           \
+            ctr.log[idx].bound = (uint32_t)(worst >> 32);                                            \
+            ctr.log[idx].meta = occ_meta(lc, OCC_SEARCH, 0, worst != ~0ull);                         \
+        }                                                                                            \
+    } while (0)
     __syncthreads();
     PH_T0();
 
     for (;;) {
         // ckey is the candidate being expanded (already marked), `word` its adjacency row (core.rs:631-645)
         ctr.n_expand += 1;
+        if (ctr.log) {
+            // Read log.  The entry of an expansion must carry the accept threshold as it is once that
+            // expansion's keys are merged -- and those are merged one expansion later (pending keys).  So the
+            // entry is written with the current (older = farther = still sound) threshold and patched when its
+            // keys go in; an expansion that accepted nothing leaves the threshold as it is.
+            log_prev = log_cur;
+            if (log_prev != kEmpty && !__ballot(ptake)) OCC_PATCH_BOUND(log_prev);
+            log_cur = ctr.log_n;
+            if (lane == 0 && ctr.log_n < ctr.log_cap)
+                ctr.log[ctr.log_n] = OccRead{key_id(ckey), occ_meta(lc, OCC_SEARCH, 0, worst != ~0ull), (uint32_t)(worst >> 32)};
+            ctr.log_n += 1;
+        }
         uint32_t cnt = __builtin_amdgcn_readfirstlane(word);
         if (cnt > stride - 1) cnt = stride - 1;
         ctr.n_ids += cnt;
@@ -1002,6 +1044,7 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
                     if (r0 == 0 && __ballot(ptake)) {      // deferred scatter, under the loads just issued
                         nW = merge_apply<R>(w, m.W, nW, ef, pkey, ptake, pup, ppos, lane, &worst);
                         ptake = false;
+                        OCC_PATCH_BOUND(log_prev);
                         PH_MARK(ctr, 3);
                     }
                 });
@@ -1058,6 +1101,7 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
                             if (__ballot(ptake)) {      // deferred scatter of the previous expansion's keys
                                 nW = merge_apply<R>(w, m.W, nW, ef, pkey, ptake, pup, ppos, lane, &worst);
                                 ptake = false;
+                                OCC_PATCH_BOUND(log_prev);
                                 PH_MARK(ctr, 3);
                             }
                             // W is complete now: its first unexpanded entry is known before the
@@ -1104,6 +1148,7 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
             if (__ballot(ptake)) {
                 nW = merge_apply<R>(w, m.W, nW, ef, pkey, ptake, pup, ppos, lane, &worst);
                 ptake = false;
+                OCC_PATCH_BOUND(log_prev);
             }
             int r2, l2;
             have_next = first_unexpanded<R>(w, nkey, r2, l2);
@@ -1129,6 +1174,8 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
     }
     // the last expansion's keys were never ranked (the loop ended before that point)
     if (__ballot(ptake)) nW = merge_regs<R>(w, m.W, nW, ef, pkey, ptake, lane, &worst);
+    if (log_cur != kEmpty) OCC_PATCH_BOUND(log_cur);      // the last expansion's keys are in now
+#undef OCC_PATCH_BOUND
     // leave W in LDS for the callers (top-k output, select_neighbors)
 #pragma unroll
     for (int r = 0; r < R; ++r) m.W[r * 64 + lane] = w[r];

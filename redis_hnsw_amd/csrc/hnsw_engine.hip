@@ -6,6 +6,7 @@
 #include "hnsw_insert.hpp"
 #include "hnsw_kernels.hpp"
 #include "hnsw_search_lean.hpp"
+#include "hnsw_occ.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -53,6 +54,18 @@ struct hnsw_index {
     uint32_t *d_touched = nullptr;  // exact insert touched list
     uint32_t touched_cap = 0;
     uint32_t *d_work = nullptr;     // fast build: shrink worklist
+    // exact-order parallel insert (hnsw_occ.hpp)
+    OccSlot *d_occ_slots = nullptr;
+    OccRead *d_occ_reads = nullptr;
+    OccShr *d_occ_shr = nullptr;
+    OccDelta *d_occ_ring = nullptr;
+    OccCtl *d_occ_ctl = nullptr;
+    uint32_t occ_window = 32;       // tuning: window slots (0 = the serial path only)
+    uint32_t occ_min_batch = 64;    // batches smaller than this take the serial path
+    uint32_t occ_ahead_x10 = 25;    // tuning: look-ahead = this/10 x running yield + 3
+    double occ_yield = 4.0;         // commits per round, running average (sizes the look-ahead)
+    uint64_t occ_rounds = 0;
+    OccCtl occ_last = {};           // counters of the last windowed build (hnsw_debug_occ)
     uint32_t work_cap = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_sync = nullptr;
@@ -698,6 +711,7 @@ void hnsw_destroy(hnsw_index *h)
     (void)hipFree(h->d_spill); (void)hipFree(h->d_spill_one); (void)hipFree(h->d_Q); (void)hipFree(h->d_res);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
     (void)hipFree(h->d_plan); (void)hipFree(h->d_touched); (void)hipFree(h->d_work);
+    (void)hipFree(h->d_occ_slots); (void)hipFree(h->d_occ_reads); (void)hipFree(h->d_occ_shr); (void)hipFree(h->d_occ_ring); (void)hipFree(h->d_occ_ctl);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_sync) (void)hipEventDestroy(h->ev_sync);
@@ -745,6 +759,9 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
         h->bf16 = true;
         return HNSW_OK;
     }
+    if (!std::strcmp(key, "occ_window")) { h->occ_window = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), kOccMaxW); return HNSW_OK; }
+    if (!std::strcmp(key, "occ_ahead_x10")) { h->occ_ahead_x10 = (uint32_t)std::max<int64_t>(value, 5); return HNSW_OK; }
+    if (!std::strcmp(key, "occ_min_batch")) { h->occ_min_batch = (uint32_t)std::max<int64_t>(value, 1); return HNSW_OK; }
     if (!std::strcmp(key, "lean")) { h->lean = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "query_in_lds")) {     // dims 128 / 768 normally keep the query in registers (T = dim/32)
         if (h->mode == MODE_AVX) h->T = value ? 0 : ((h->dim == 128 || h->dim == 768) ? (int)(h->dim / 32) : 0);
@@ -804,7 +821,17 @@ hnsw_status hnsw_add_batch(hnsw_index *h, const float *V, uint32_t n, uint32_t d
     HIP_TRY(h, hipSetDevice(h->device));
     hnsw_status s;
     uint32_t done = 0;
-    // exact inserts: all of them (mode 0) or the seed prefix of the fast build
+    // exact inserts: all of them (mode 0) or the seed prefix of the fast build.  Large exact batches go
+    // through the optimistic window (same graph, planned in parallel, committed in order: hnsw_occ.hpp).
+    if (mode == 0 && h->occ_window >= 2 && n >= h->occ_min_batch) {
+        while (done < n && h->n - h->n_dead < 2) {           // the first nodes: serial (no graph to plan against)
+            if ((s = add_exact(h, V + (size_t)done * dim, nullptr, levels ? levels[done] : -1, nullptr, false, nullptr)) != HNSW_OK)
+                return s;
+            ++done;
+        }
+        if (done < n && (s = add_exact_window(h, V + (size_t)done * dim, n - done, levels ? levels + done : nullptr)) != HNSW_OK) return s;
+        return HNSW_OK;
+    }
     while (done < n && (mode == 0 || h->n < h->fast_seed)) {
         if ((s = add_exact(h, V + (size_t)done * dim, nullptr, levels ? levels[done] : -1, nullptr, false, nullptr)) != HNSW_OK)
             return s;
@@ -1358,6 +1385,16 @@ hnsw_status hnsw_reset_counters(hnsw_index *h)
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipDeviceSynchronize());
     HIP_TRY(h, hipMemset((char *)h->d_hdr + offsetof(DevHeader, ctr_search), 0, sizeof(unsigned long long) * 16));
+    return HNSW_OK;
+}
+
+// counters of the last windowed exact build: commits, speculative shrinks applied, shrinks recomputed at commit,
+// plans found stale by the parallel validation, journal entries (development aid; not in the public header)
+hnsw_status hnsw_debug_occ(hnsw_index *h, uint64_t *out5 /* [6] */)
+{
+    if (!h || !out5) return HNSW_ERR_INVALID;
+    out5[0] = h->occ_last.n_commit; out5[1] = h->occ_last.n_spec; out5[2] = h->occ_last.n_fallback;
+    out5[3] = h->occ_last.n_stale; out5[4] = h->occ_last.nJ; out5[5] = h->occ_last.stop;   // [5] = rounds
     return HNSW_OK;
 }
 

@@ -212,9 +212,31 @@ __global__ __launch_bounds__(64, 1) void k_insert_plan(GraphView g, uint32_t fir
 __device__ __forceinline__ void touch_push(uint32_t *touched, uint32_t cap, uint32_t &nt, uint32_t id, bool on,
                                            int lane);
 
+// Journal of row changes (hnsw_occ.hpp): every entry says "id z was added to / removed from row (row, layer)".
+// A ring; `n` counts entries ever written.  One wave writes it (the in-order commit).
+struct OccDelta { uint32_t row, lc_add, z; };        // lc_add = layer | added << 8
+constexpr uint32_t kOccJournalBits = 18;
+struct OccJournal {
+    OccDelta *ring;
+    uint32_t n;                                      // the committing wave's copy of the counter (wave-uniform)
+};
+// lanes flagged `on` each append one delta (wave-uniform call)
+__device__ __forceinline__ void journal_push(OccJournal *jr, bool on, uint32_t row, uint32_t lc, uint32_t z, bool add, int lane)
+{
+    if (!jr) return;
+    const uint64_t b = __ballot(on);
+    if (!b) return;
+    if (on) {
+        const uint32_t p = (jr->n + (uint32_t)__popcll(b & lanemask_lt(lane))) & ((1u << kOccJournalBits) - 1u);
+        jr->ring[p] = OccDelta{row, lc | (add ? 256u : 0u), z};
+    }
+    jr->n += (uint32_t)__popcll(b);
+}
+
 __device__ __forceinline__ void update_connections(const GraphView &g, const WaveMem &m, uint32_t e, uint32_t *erow, uint32_t cnt,
                                    uint32_t nS, uint32_t lc, uint32_t stride, uint32_t *maxdeg, uint32_t ignored,
-                                   uint32_t *touched, uint32_t touched_cap, uint32_t &nt, int lane)
+                                   uint32_t *touched, uint32_t touched_cap, uint32_t &nt, int lane,
+                                   OccJournal *jr = nullptr)
 {
     uint32_t kept = 0;
     for (uint32_t base = 0; base < cnt; base += 64) {
@@ -241,6 +263,8 @@ __device__ __forceinline__ void update_connections(const GraphView &g, const Wav
             }
         }
         touch_push(touched, touched_cap, nt, x, drop, lane); // :816
+        journal_push(jr, drop, e, lc, x, false, lane);
+        journal_push(jr, drop, x, lc, e, false, lane);
     }
     // new neighbours that were not adjacent before (:790-796)
     {
@@ -262,6 +286,8 @@ __device__ __forceinline__ void update_connections(const GraphView &g, const Wav
             }
         }
         kept += __popcll(nb);
+        journal_push(jr, isNew, e, lc, x, true, lane);
+        journal_push(jr, isNew, x, lc, e, true, lane);
         touch_push(touched, touched_cap, nt, x, (uint32_t)lane < nS, lane); // :796
     }
     if (lane == 0) erow[0] = kept;

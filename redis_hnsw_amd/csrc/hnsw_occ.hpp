@@ -1,0 +1,517 @@
+// hnsw_occ.hpp -- HNSW.NODE.ADD in the reference's serial order (core.rs:489-599), executed optimistically:
+// a window of consecutive inserts is PLANNED in parallel against one snapshot of the graph, then COMMITTED
+// strictly in id order by one wave, which first checks that nothing the plan read has changed in a way that
+// matters.  The result is the serial graph, row for row (tests: graphs_equal against the oracle); the scheme
+// and its validation rules were first proven on the CPU (tests/experiments/occ_model.c).
+//
+//   plan      k_occ_plan: per node the read-only part of insert(): descent, per layer search_level(efc) +
+//             select_neighbors(m) (core.rs:511-531) -- with a READ LOG (row, layer, accept bound in force) --
+//             the node's own rows, and speculatively the select_neighbors(m_max) of every selected neighbour e
+//             that the connect will push over m_max (core.rs:560-568), computed as if only this node's connect
+//             had happened since the snapshot.
+//   journal   every committed change of a row is appended as (row, layer, id, added | removed).
+//   validate  a plan is still the reference's plan if no journal entry since its snapshot is RELEVANT to a
+//             row it read.  Entry z on row h is relevant to
+//               a search_level expansion of h   iff W was not full then, or dist(q,z) <= W's furthest  (core.rs:657)
+//               select_neighbors over h          iff fewer than m were selected, or dist(q,z) <= the last selected
+//               a speculative shrink of e        iff h == e (any change but this node's own append), or h is one of
+//                                                e's neighbours and dist(e,z) <= the last selected
+//             (an irrelevant z is rejected by the same comparison whenever it is met, now or later: the accept
+//             threshold only improves).  Ties count as relevant.
+//   commit    k_occ_commit: in id order -- validate, connect (core.rs:532), then per selected neighbour the
+//             shrink: the speculative result if still valid, else recomputed on the spot (core.rs:540-574).
+//             The first node whose link plan is stale ends the round; the host re-plans what is stale.
+#pragma once
+#include "hnsw_insert.hpp"
+
+namespace hnsw {
+
+constexpr uint32_t kOccMaxW = 64;           // window slots
+constexpr uint32_t kOccMaxReads = 3072;     // read-log entries per slot
+constexpr uint32_t kOccMaxShr = 48;         // speculative shrinks per slot
+constexpr uint32_t kOccHash = 8192;         // validation hash slots (> 2 x reads)
+constexpr uint32_t kOccMaxHits = 1024;      // (reader, z) pairs whose distance must be evaluated per validation
+
+struct OccShr {
+    uint32_t lc, e, nS, bound;              // bound = distance bits of the last selected
+    uint32_t S[64];                         // selected ids, nearest first
+};
+struct OccSlot {
+    uint32_t node, planned, snap, epoch;
+    uint32_t n_reads, n_shr, top, fail;     // fail: the plan could not be logged (log overflow, visited overflow)
+};
+enum { OCC_STOP_NONE = 0, OCC_STOP_REPLAN = 1, OCC_STOP_RESTRIDE = 2, OCC_STOP_SERIAL = 3 };
+struct OccCtl {
+    uint32_t head;                          // next node id to commit
+    uint32_t nJ;                            // journal entries ever written
+    uint32_t epoch;                         // bumped when enterpoint / max_layer change (every plan reads them)
+    uint32_t stop;                          // why the last commit kernel stopped
+    unsigned long long n_commit, n_spec, n_fallback, n_stale;
+};
+
+struct OccBufs {
+    OccSlot *slots;
+    OccRead *reads;                         // [W][kOccMaxReads]
+    OccShr *shr;                            // [W][kOccMaxShr]
+    OccDelta *ring;                         // [1 << kOccJournalBits]
+    OccCtl *ctl;
+    uint32_t W;
+};
+
+// LDS scratch of a validation
+struct OccScratch {
+    uint32_t *hkey;     // [kOccHash]
+    uint32_t *hhead;    // [kOccHash]
+    uint32_t *hnext;    // [kOccMaxReads]
+    uint32_t *hits;     // [kOccMaxHits][3]: reader (0 = the node itself, 1 + sub = shrink sub), z, bound
+    uint32_t *flags;    // [0] link plan stale, [1] hit count, [2 + sub] shrink sub stale
+};
+constexpr size_t kOccScratchBytes = (size_t)(kOccHash * 2 + kOccMaxReads + kOccMaxHits * 3 + 2 + 64) * 4;
+
+__device__ __forceinline__ OccScratch occ_carve(unsigned char *p)
+{
+    OccScratch s;
+    s.hkey = reinterpret_cast<uint32_t *>(p);
+    s.hhead = s.hkey + kOccHash;
+    s.hnext = s.hhead + kOccHash;
+    s.hits = s.hnext + kOccMaxReads;
+    s.flags = s.hits + kOccMaxHits * 3;
+    return s;
+}
+__device__ __forceinline__ uint32_t occ_hash(uint32_t key) { return (key * 0x9E3779B1u) >> (32 - 13); }   // kOccHash = 2^13
+static_assert(kOccHash == (1u << 13), "occ_hash");
+
+// hash of the slot's read rows: (row, layer) -> chain of read indices
+__device__ __forceinline__ void occ_build_hash(const OccScratch &sc, const OccRead *reads, uint32_t n_reads, int lane)
+{
+    for (uint32_t i = lane; i < kOccHash; i += 64) { sc.hkey[i] = kEmpty; sc.hhead[i] = kEmpty; }
+    for (uint32_t i = lane; i < 2 + 64; i += 64) sc.flags[i] = 0;
+    __syncthreads();
+    for (uint32_t i = lane; i < n_reads; i += 64) {
+        const uint32_t key = (reads[i].row << 5) | (reads[i].meta & 31u);
+        uint32_t h = occ_hash(key);
+        for (;;) {
+            const uint32_t old = atomicCAS(&sc.hkey[h], kEmpty, key);
+            if (old == kEmpty || old == key) break;
+            h = (h + 1) & (kOccHash - 1);
+        }
+        sc.hnext[i] = atomicExch(&sc.hhead[h], i);
+    }
+    __syncthreads();
+}
+
+// Check journal[from, to) against the hashed reads.  q = the slot's node; own_connect: entries (row,+q) are
+// this node's own appends (its shrinks were planned with them in place).  Accumulates into sc.flags.
+template <int MODE, int T>
+__device__ __forceinline__ void occ_check_range(const GraphView &g, const WaveMem &m, const OccScratch &sc, const OccBufs &ob,
+                                                const OccRead *reads, const OccShr *shr, uint32_t q, uint32_t from,
+                                                uint32_t to, int lane, bool shrinks_only = false)
+{
+    if (to - from > (1u << kOccJournalBits) - 4096u) {      // the ring has wrapped past this plan: stale
+        if (lane == 0) sc.flags[0] = 1;
+        __syncthreads();
+        return;
+    }
+    // ---- collect: entries on rows the plan read ----
+    for (uint32_t base = from; base < to; base += 64) {
+        const uint32_t j = base + lane;
+        if (j < to) {
+            const OccDelta d = ob.ring[j & ((1u << kOccJournalBits) - 1u)];
+            const uint32_t key = (d.row << 5) | (d.lc_add & 31u);
+            const bool add = (d.lc_add & 256u) != 0;
+            uint32_t h = occ_hash(key);
+            while (sc.hkey[h] != kEmpty && sc.hkey[h] != key) h = (h + 1) & (kOccHash - 1);
+            if (sc.hkey[h] == key) {
+                for (uint32_t i = sc.hhead[h]; i != kEmpty; i = sc.hnext[i]) {
+                    const OccRead r = reads[i];
+                    const uint32_t kind = (r.meta >> 5) & 3u, sub = (r.meta >> 7) & 63u;
+                    const bool full = (r.meta >> 13) & 1u;
+                    if (kind == OCC_SHRINK_ROW) {
+                        if (d.z == q && add) continue;                   // this node's own connect
+                        sc.flags[2 + sub] = 1;
+                        continue;
+                    }
+                    if (kind == OCC_SHRINK_NB) {
+                        if (d.z == shr[sub].e || d.z == q) continue;     // e is excluded (core.rs:704); q is in econn already
+                        if (sc.flags[2 + sub]) continue;
+                        if (!full) { sc.flags[2 + sub] = 1; continue; }
+                    } else {
+                        if (shrinks_only) continue;                      // the link plan was already accepted
+                        if (!full) { sc.flags[0] = 1; continue; }
+                    }
+                    const uint32_t p = atomicAdd(&sc.flags[1], 1u);
+                    if (p < kOccMaxHits) {
+                        sc.hits[3 * p] = kind == OCC_SHRINK_NB ? 1u + sub : 0u;
+                        sc.hits[3 * p + 1] = d.z;
+                        sc.hits[3 * p + 2] = r.bound;
+                    } else sc.flags[0] = 1;                              // too many to evaluate: treat as stale
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- evaluate: dist(reader, z) <= bound ? ----
+    uint32_t nh = sc.flags[1];
+    if (nh > kOccMaxHits) nh = kOccMaxHits;
+    for (uint32_t base = 0; base < nh; base += 64) {
+        const uint32_t i = base + lane;
+        bool active = i < nh;
+        const uint32_t reader = active ? sc.hits[3 * i] : 0u, z = active ? sc.hits[3 * i + 1] : 0u;
+        const uint32_t bound = active ? sc.hits[3 * i + 2] : 0u;
+        // a shrink already known stale needs no more distances
+        if (active && reader && sc.flags[1 + reader]) active = false;
+        uint64_t am = __ballot(active);
+        while (am) {
+            const int first = __ffsll((unsigned long long)am) - 1;
+            const uint32_t rd = (uint32_t)__builtin_amdgcn_readlane((int)reader, first);
+            const bool sel = active && reader == rd;
+            const uint64_t sm = __ballot(sel);
+            const uint32_t nf = (uint32_t)__popcll(sm);
+            const uint32_t idx = (uint32_t)__popcll(sm & lanemask_lt(lane));
+            __syncthreads();
+            if (sel) m.fresh[idx] = z;
+            const uint32_t rid = rd ? shr[rd - 1].e : q;
+            QReg<T> qr;
+            load_query<MODE, T>(g.vec + (size_t)rid * g.dim, g.dim, qr, m.qlds, lane);
+            __syncthreads();
+            compute_dists<MODE, T>(g, qr, m, nf, lane);
+            __syncthreads();
+            if (sel && __float_as_uint(m.dsc[idx]) <= bound) {
+                if (rd) sc.flags[1 + rd] = 1;
+                else sc.flags[0] = 1;
+            }
+            am &= ~sm;
+        }
+    }
+    if (lane == 0) sc.flags[1] = 0;
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// plan: one wave per window node that has no valid plan
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE, int T, int R>
+__global__ __launch_bounds__(64, 1) void k_occ_plan(GraphView g, OccBufs ob, uint32_t first_node, uint32_t count, uint32_t ef,
+                                                 uint32_t mlinks, uint32_t lnb, uint32_t lcap, uint32_t *__restrict__ gspill,
+                                                 uint32_t gnb, uint32_t *__restrict__ plan)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const uint32_t id = first_node + blockIdx.x;
+    if (blockIdx.x >= count) return;
+    const uint32_t slot = id % ob.W;
+    OccSlot *sl = &ob.slots[slot];
+    if (sl->planned && sl->node == id) return;
+
+    WaveMem m;
+    Visited vis;
+    carve<R, T, true>(smem, g.dim, lnb, lcap, m, vis, g.tagcfg);
+    vis.glob = gspill + (size_t)blockIdx.x * gnb * 8;
+    vis.gnb = gnb;
+    vis.glob_dirty = false;
+    vis.spilled = false;
+    vis.count = 0;
+    vis.bounded = false;
+    vis.lossy = false;
+
+    OccRead *reads = ob.reads + (size_t)slot * kOccMaxReads;
+    OccShr *shr = ob.shr + (size_t)slot * kOccMaxShr;
+    WorkCtr ctr = {};
+    ctr.log = reads;
+    ctr.log_cap = kOccMaxReads;
+    const uint32_t snap = ob.ctl->nJ, epoch = ob.ctl->epoch;
+    const uint32_t lmax = g.hdr->max_layer;                 // core.rs:496
+    const uint32_t ep0 = (uint32_t)g.hdr->enterpoint;       // core.rs:508
+    const uint32_t l = g.levels[id];
+    uint32_t *pl0 = plan + (size_t)slot * kMaxLayers * kPlanStride;
+
+    QReg<T> qr;
+    load_query<MODE, T>(g.vec + (size_t)id * g.dim, g.dim, qr, m.qlds, lane);
+    bool fail = false;
+    uint32_t ep = ep0;
+    for (uint32_t lc = lmax; lc > l && !fail; --lc) {       // core.rs:511-520
+        search_level<MODE, T, 1>(g, m, vis, qr, ep, 1, lc, ctr, lane, fail);
+        ep = key_id(m.W[0]);                                // core.rs:514
+        __syncthreads();
+    }
+    const uint32_t top = lmax < l ? lmax : l;
+    for (uint32_t lc1 = top + 1; lc1-- > 0 && !fail;) {     // core.rs:523
+        const uint32_t lc = lc1;
+        const uint32_t nW = search_level<MODE, T, R>(g, m, vis, qr, ep, ef, lc, ctr, lane, fail); // :524
+        if (fail) break;
+        const uint32_t wnearest = key_id(m.W[0]);
+        // select's reads: the rows of all members of W (logged before S exists; the bound is patched in below)
+        const uint32_t sel_log0 = ctr.log_n;
+        for (uint32_t i = lane; i < nW; i += 64)
+            if (sel_log0 + i < kOccMaxReads) reads[sel_log0 + i] = OccRead{key_id(m.W[i]), occ_meta(lc, OCC_SELECT, 0, false), 0u};
+        ctr.log_n += nW;
+        const uint32_t nS = select_topm<MODE, T>(g, m, vis, qr, m.W, nW, id, mlinks, lc, ctr, lane, fail); // :531
+        if (fail) break;
+        const bool sfull = nS >= mlinks;
+        const uint32_t sbound = nS ? (uint32_t)(m.S[nS - 1] >> 32) : 0u;
+        for (uint32_t i = lane; i < nW; i += 64)
+            if (sel_log0 + i < kOccMaxReads) { reads[sel_log0 + i].meta = occ_meta(lc, OCC_SELECT, 0, sfull); reads[sel_log0 + i].bound = sbound; }
+        uint32_t *pl = pl0 + (size_t)lc * kPlanStride;
+        if (lane == 0) pl[0] = nS;
+        if ((uint32_t)lane < nS) pl[1 + lane] = key_id(m.S[lane]);
+        // the node's own row: what connect_neighbors will make it (core.rs:770); nobody can reach it yet
+        uint32_t *qrow = row_ptr(g, id, lc);
+        if (lane == 0) qrow[0] = nS;
+        if ((uint32_t)lane < nS) qrow[1 + lane] = key_id(m.S[lane]);
+        ep = wnearest;                                      // core.rs:576
+        __syncthreads();
+    }
+    __threadfence();
+    __syncthreads();
+
+    // ---- speculative shrinks (core.rs:540-574), each as if only this node's connect had happened ----
+    uint32_t n_shr = 0;
+    for (uint32_t lc1 = top + 1; lc1-- > 0 && !fail;) {
+        const uint32_t lc = lc1;
+        const uint32_t stride = lc ? g.strideU : g.stride0;
+        const uint32_t mmax = lc ? mlinks : 2 * mlinks;     // core.rs:560
+        const uint32_t *pl = pl0 + (size_t)lc * kPlanStride;
+        const uint32_t nsel = pl[0];
+        for (uint32_t si = 0; si < nsel && !fail; ++si) {
+            const uint32_t e = pl[1 + si];
+            const uint32_t *erow = row_ptr(g, e, lc);
+            uint32_t cnt = erow[0];
+            if (cnt > stride - 1) cnt = stride - 1;
+            if (cnt + 1 <= mmax) continue;                  // :561 (the row with this node appended)
+            if (n_shr >= kOccMaxShr || cnt + 1 > kAuxWords) { fail = true; break; }
+            // econn: e's row in stored order, this node last (core.rs:544-558)
+            QReg<T> qe;
+            load_query<MODE, T>(g.vec + (size_t)e * g.dim, g.dim, qe, m.qlds, lane);
+            uint32_t nE = 0;
+            const uint32_t tot = cnt + 1;
+            for (uint32_t base = 0; base < tot; base += 64) {
+                const uint32_t i = base + lane;
+                const uint32_t nf = tot - base < 64 ? tot - base : 64;
+                if (i < tot) { const uint32_t x = i < cnt ? erow[1 + i] : id; m.fresh[lane] = x; m.aux[i] = x; }
+                __syncthreads();
+                compute_dists<MODE, T>(g, qe, m, nf, lane);
+                __syncthreads();
+                const bool have = (uint32_t)lane < nf;
+                const uint64_t key = have ? pack_key(m.dsc[lane], m.fresh[lane]) : ~0ull;
+                nE = merge_sorted<R>(m.W, nE, R * 64, key, have, lane);
+            }
+            WorkCtr nolog = {};
+            const uint32_t nS = select_topm<MODE, T>(g, m, vis, qe, m.W, nE, e, mmax, lc, nolog, lane, fail); // :568
+            if (fail) break;
+            OccShr *sp = &shr[n_shr];
+            const uint32_t bound = (uint32_t)(m.S[nS - 1] >> 32);
+            if (lane == 0) { sp->lc = lc; sp->e = e; sp->nS = nS; sp->bound = bound; }
+            if ((uint32_t)lane < nS) sp->S[lane] = key_id(m.S[lane]);
+            // reads: row e itself, and the rows of econn's members
+            if (lane == 0 && ctr.log_n < kOccMaxReads) reads[ctr.log_n] = OccRead{e, occ_meta(lc, OCC_SHRINK_ROW, n_shr, true), 0u};
+            ctr.log_n += 1;
+            for (uint32_t i = lane; i < tot; i += 64)
+                if (ctr.log_n + i < kOccMaxReads) reads[ctr.log_n + i] = OccRead{m.aux[i], occ_meta(lc, OCC_SHRINK_NB, n_shr, true), bound};
+            ctr.log_n += tot;
+            n_shr += 1;
+            __syncthreads();
+        }
+    }
+    if (ctr.log_n > kOccMaxReads) fail = true;
+    if (vis.glob_dirty) visited_clear(vis, lane);
+    __threadfence();
+    if (lane == 0) {
+        sl->node = id; sl->snap = snap; sl->epoch = epoch;
+        sl->n_reads = ctr.log_n < kOccMaxReads ? ctr.log_n : kOccMaxReads;
+        sl->n_shr = n_shr; sl->top = top; sl->fail = fail ? 1u : 0u;
+        sl->planned = 1;
+        atomicAdd(&g.hdr->ctr_insert[0], (unsigned long long)ctr.n_dist);
+        atomicAdd(&g.hdr->ctr_insert[1], (unsigned long long)ctr.n_ids);
+        atomicAdd(&g.hdr->ctr_insert[2], (unsigned long long)ctr.n_expand);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// validate every planned slot of the window against the journal (parallel; stale ones are re-planned before
+// they reach the head).  A slot that passes moves its snapshot forward.
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE, int T>
+__global__ __launch_bounds__(64, 1) void k_occ_validate(GraphView g, OccBufs ob, uint32_t first_node, uint32_t count)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    if (blockIdx.x >= count) return;
+    const uint32_t id = first_node + blockIdx.x;
+    OccSlot *sl = &ob.slots[id % ob.W];
+    if (!sl->planned || sl->node != id) return;
+    const uint32_t nJ = ob.ctl->nJ;
+    if (sl->fail) return;                                   // the commit hands it to the serial path
+    if (sl->epoch != ob.ctl->epoch) { if (lane == 0) sl->planned = 0; return; }
+    if (sl->snap == nJ) return;
+    OccScratch sc = occ_carve(smem);
+    WaveMem m = {};
+    unsigned char *p = smem + kOccScratchBytes;
+    m.fresh = reinterpret_cast<uint32_t *>(p); p += 64 * 4;
+    m.dsc = reinterpret_cast<float *>(p); p += 64 * 4;
+    m.qlds = reinterpret_cast<float *>(p);
+    const OccRead *reads = ob.reads + (size_t)(id % ob.W) * kOccMaxReads;
+    const OccShr *shr = ob.shr + (size_t)(id % ob.W) * kOccMaxShr;
+    occ_build_hash(sc, reads, sl->n_reads, lane);
+    occ_check_range<MODE, T>(g, m, sc, ob, reads, shr, id, sl->snap, nJ, lane);
+    bool bad = sc.flags[0] != 0;
+    for (uint32_t k = 0; k < sl->n_shr; ++k) bad |= sc.flags[2 + k] != 0;
+    if (lane == 0) {
+        if (bad) { sl->planned = 0; atomicAdd(&ob.ctl->n_stale, 1ull); }
+        else sl->snap = nJ;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// commit: one wave, strictly in id order
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE, int T, int R>
+__global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, uint32_t end_node, uint32_t mlinks, uint32_t lnb,
+                                                   uint32_t lcap, uint32_t *__restrict__ gspill, uint32_t gnb,
+                                                   const uint32_t *__restrict__ plan)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    OccScratch sc = occ_carve(smem);
+    WaveMem m;
+    Visited vis;
+    carve<R, T, true>(smem + kOccScratchBytes, g.dim, lnb, lcap, m, vis, g.tagcfg);
+    vis.glob = gspill;
+    vis.gnb = gnb;
+    vis.glob_dirty = false;
+    vis.spilled = false;
+    vis.count = 0;
+    vis.bounded = false;
+    vis.lossy = false;
+
+    OccJournal jr;
+    jr.ring = ob.ring;
+    jr.n = ob.ctl->nJ;
+    uint32_t head = ob.ctl->head;
+    uint32_t stop = OCC_STOP_NONE;
+    unsigned long long n_commit = 0, n_spec = 0, n_fallback = 0;
+    uint32_t nt = 0;
+
+    while (head < end_node) {
+        const uint32_t id = head;
+        const uint32_t slot = id % ob.W;
+        OccSlot *sl = &ob.slots[slot];
+        if (!sl->planned || sl->node != id) { stop = OCC_STOP_REPLAN; break; }
+        if (sl->fail) { stop = OCC_STOP_SERIAL; break; }
+        if (sl->epoch != ob.ctl->epoch) { if (lane == 0) sl->planned = 0; stop = OCC_STOP_REPLAN; break; }
+        // one insert raises any row by at most m + 1 per layer (connect + third-party appends of its shrinks)
+        if (g.hdr->max_deg0 + mlinks + 2 > g.stride0 - 1 || g.hdr->max_degU + mlinks + 2 > g.strideU - 1) { stop = OCC_STOP_RESTRIDE; break; }
+        const OccRead *reads = ob.reads + (size_t)slot * kOccMaxReads;
+        const OccShr *shr = ob.shr + (size_t)slot * kOccMaxShr;
+        const uint32_t n_shr = sl->n_shr;
+        occ_build_hash(sc, reads, sl->n_reads, lane);
+        uint32_t checked = sl->snap;
+        occ_check_range<MODE, T>(g, m, sc, ob, reads, shr, id, checked, jr.n, lane);
+        checked = jr.n;
+        if (sc.flags[0]) {                                   // the link plan is stale: re-plan (end of the round)
+            __syncthreads();
+            if (lane == 0) sl->planned = 0;
+            stop = OCC_STOP_REPLAN;
+            break;
+        }
+        const uint32_t lmax = g.hdr->max_layer;
+        const uint32_t l = g.levels[id];
+        const uint32_t top = sl->top;
+        const uint32_t *pl0 = plan + (size_t)slot * kMaxLayers * kPlanStride;
+        bool fail = false;
+
+        for (uint32_t lc1 = top + 1; lc1-- > 0 && !fail;) { // core.rs:523
+            const uint32_t lc = lc1;
+            const uint32_t stride = lc ? g.strideU : g.stride0;
+            const uint32_t mmax = lc ? mlinks : 2 * mlinks; // core.rs:560
+            uint32_t *maxdeg = lc ? &g.hdr->max_degU : &g.hdr->max_deg0;
+            const uint32_t *pl = pl0 + (size_t)lc * kPlanStride;
+            const uint32_t nsel = pl[0];
+            const uint32_t myselid = (uint32_t)lane < nsel ? pl[1 + lane] : kEmpty;
+            // connect_neighbors (core.rs:759-774), nearest first; the node's own row was written by its plan
+            uint32_t *qrow = row_ptr(g, id, lc);
+            if (lane == 0) qrow[0] = nsel;
+            if ((uint32_t)lane < nsel) {
+                qrow[1 + lane] = myselid;
+                uint32_t *nrow = row_ptr(g, myselid, lc);
+                const uint32_t c = nrow[0];
+                if (c + 1 > stride - 1) atomicOr(&g.hdr->status, ST_ROW_OVERFLOW);
+                else { nrow[1 + c] = id; nrow[0] = c + 1; atomicMax(maxdeg, c + 1); }
+            }
+            if (lane == 0) atomicMax(maxdeg, nsel);
+            journal_push(&jr, (uint32_t)lane < nsel, myselid, lc, id, true, lane);
+            __threadfence();
+            __syncthreads();
+
+            for (uint32_t si = 0; si < nsel && !fail; ++si) {   // shrink loop (core.rs:540-574), e nearest first
+                const uint32_t e = pl[1 + si];
+                uint32_t *erow = row_ptr(g, e, lc);
+                uint32_t cnt = erow[0];
+                if (cnt > stride - 1) cnt = stride - 1;
+                if (cnt <= mmax) continue;                  // :561
+                // the speculative result, if nothing relevant happened since it was planned
+                int k = -1;
+                for (uint32_t t = 0; t < n_shr; ++t)
+                    if (shr[t].e == e && shr[t].lc == lc) k = (int)t;
+                if (k >= 0 && checked != jr.n) {
+                    occ_check_range<MODE, T>(g, m, sc, ob, reads, shr, id, checked, jr.n, lane, true);
+                    checked = jr.n;
+                }
+                for (uint32_t i = lane; i < cnt; i += 64) m.aux[i] = erow[1 + i];
+                __syncthreads();
+                uint32_t nS;
+                if (k >= 0 && !sc.flags[2 + k]) {
+                    nS = shr[k].nS;
+                    if ((uint32_t)lane < nS) m.S[lane] = (uint64_t)shr[k].S[lane] << 1;
+                    __syncthreads();
+                    n_spec += 1;
+                } else {
+                    // recompute on the spot (core.rs:544-568)
+                    QReg<T> qe;
+                    load_query<MODE, T>(g.vec + (size_t)e * g.dim, g.dim, qe, m.qlds, lane);
+                    uint32_t nE = 0;
+                    for (uint32_t base = 0; base < cnt; base += 64) {
+                        const uint32_t i = base + lane;
+                        const uint32_t nf = cnt - base < 64 ? cnt - base : 64;
+                        if (i < cnt) m.fresh[lane] = m.aux[i];
+                        __syncthreads();
+                        compute_dists<MODE, T>(g, qe, m, nf, lane);
+                        __syncthreads();
+                        const bool have = (uint32_t)lane < nf;
+                        const uint64_t key = have ? pack_key(m.dsc[lane], m.fresh[lane]) : ~0ull;
+                        nE = merge_sorted<R>(m.W, nE, R * 64, key, have, lane);
+                    }
+                    WorkCtr nolog = {};
+                    nS = select_topm<MODE, T>(g, m, vis, qe, m.W, nE, e, mmax, lc, nolog, lane, fail);
+                    if (fail) break;
+                    n_fallback += 1;
+                }
+                update_connections(g, m, e, erow, cnt, nS, lc, stride, maxdeg, kEmpty, nullptr, 0, nt, lane, &jr);
+            }
+        }
+        if (fail) { if (lane == 0) atomicOr(&g.hdr->status, ST_VISITED_OVERFLOW); stop = OCC_STOP_SERIAL; break; }
+        if (lane == 0) {
+            if (l > lmax) {                                 // core.rs:587-593
+                g.hdr->max_layer = l;
+                g.hdr->enterpoint = (int32_t)id;
+                ob.ctl->epoch += 1;
+            }
+            g.hdr->node_count = id + 1;
+            sl->planned = 0;
+        }
+        __threadfence();
+        __syncthreads();
+        n_commit += 1;
+        head += 1;
+    }
+    if (vis.glob_dirty) visited_clear(vis, lane);
+    if (lane == 0) {
+        ob.ctl->head = head;
+        ob.ctl->nJ = jr.n;
+        ob.ctl->stop = stop;
+        ob.ctl->n_commit += n_commit;
+        ob.ctl->n_spec += n_spec;
+        ob.ctl->n_fallback += n_fallback;
+    }
+}
+
+} // namespace hnsw

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Exact-order parallel insert (hnsw_occ.hpp) against the oracle: identical graphs, rate, window statistics.
+   python scripts/occ_probe.py N dim M ef [window] [check]"""
+import ctypes as C, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from redis_hnsw_amd import Index, _capi
+N, dim, M, ef = [int(x) for x in sys.argv[1:5]]
+W = int(sys.argv[5]) if len(sys.argv) > 5 else 32
+check = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+from oracle import oracle
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from tests.util import graphs_equal
+V = np.random.default_rng(1).random((N, dim), dtype=np.float32)
+lv = oracle.draw_levels(N, M, 7)
+gi = Index("occ", dim, M, ef)
+gi.set_tuning("occ_window", W)
+if os.environ.get("OCC_AHEAD"): gi.set_tuning("occ_ahead_x10", int(os.environ["OCC_AHEAD"]))
+t = time.time(); gi.add_batch(V, levels=lv, mode="exact"); dt = time.time() - t
+lib = _capi.load()
+out = (C.c_uint64 * 6)()
+lib.hnsw_debug_occ.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+lib.hnsw_debug_occ(gi._h, out)
+nc = max(out[0], 1)
+print("N=%d dim=%d M=%d ef=%d W=%d: %.2f s = %.0f inserts/s; commits %d, spec shrinks %d, recomputed %d (%.1f%%), stale plans %d, deltas/commit %.1f, rounds %d (%.2f commits/round)" % (
+    N, dim, M, ef, W, dt, N / dt, out[0], out[1], out[2], 100.0 * out[2] / max(out[1] + out[2], 1), out[3], out[4] / nc, out[5], out[0] / max(out[5], 1)), flush=True)
+if check:
+    t = time.time(); o = oracle.OracleIndex(dim, M, ef); o.add_batch(V, lv); to = time.time() - t
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    print("oracle build %.1f s; graphs identical: %s %s" % (to, ok, why))
+    sys.exit(0 if ok else 1)

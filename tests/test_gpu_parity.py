@@ -777,3 +777,55 @@ def test_full_size_c4_10m_properties_and_sampled_parity(eng, oracle_mod):
     sc, _ = gi.counters()
     assert (sc.n_dist, sc.n_ids, sc.n_expand) == (oct.n_dist, oct.n_ids, oct.n_expand)
     gi.close()
+
+
+# ---- exact-order PARALLEL insert (hnsw_occ.hpp): the window must reproduce the serial graph ----------
+@pytest.mark.parametrize("n,dim,m,ef,window", [
+    (3000, 32, 8, 64, 32),       # generic AVX dim
+    (2500, 128, 16, 200, 16),    # the C2 shape
+    (2500, 128, 16, 200, 64),
+    (1500, 12, 4, 24, 8),        # scalar metric order, m = 4: many layers, enterpoint changes inside windows
+    (1200, 768, 32, 400, 16),    # wide rows, R = 8
+])
+def test_windowed_exact_build_is_the_serial_graph(eng, oracle_mod, n, dim, m, ef, window):
+    """hnsw_add_batch(mode 0) plans a window of inserts in parallel and commits them in id order after
+    validating each plan against the journal of row changes: the graph, the enterpoint and
+    every adjacency row in stored order must be the oracle's, and searches on it bit-identical."""
+    V = make_data(n, dim, seed=81)
+    lv = oracle_mod.draw_levels(n, m, 5)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch(V, lv)
+    gi = eng.Index("w", dim, m, ef)
+    gi.set_tuning("occ_window", window)
+    half = n // 2
+    gi.add_batch(V[:half], levels=lv[:half], mode="exact")       # two batches: the second starts on a live graph
+    gi.add_batch(V[half:], levels=lv[half:], mode="exact")
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    Q = make_data(32, dim, seed=2)
+    ids, sims, n_out = gi.search_batch(Q, 5)
+    oids, osims, on, _ = o.search_batch(Q, 5)
+    assert np.array_equal(n_out, on) and np.array_equal(ids, oids) and np.array_equal(_bits(sims), _bits(osims))
+    # single exact inserts and deletes keep working on the result
+    W2 = make_data(20, dim, seed=82)
+    for i in range(20):
+        o.add(W2[i], 0)
+        gi.add_node("late%d" % i, W2[i], level=0)
+    o.delete(7)
+    gi.delete_node("node7")
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    gi.close()
+
+
+def test_windowed_and_serial_exact_builds_agree(eng):
+    n, dim, m, ef = 2000, 64, 6, 48
+    V = make_data(n, dim, seed=83)
+    a = eng.Index("a", dim, m, ef, seed=3)
+    b = eng.Index("b", dim, m, ef, seed=3)
+    a.set_tuning("occ_window", 0)                 # the serial kernels, one insert after the other
+    a.add_batch(V, mode="exact")                  # levels drawn by the engine: the same draws in both
+    b.add_batch(V, mode="exact")
+    ok, why = graphs_equal(a.export_graph(), b.export_graph())
+    assert ok, why
+    a.close(); b.close()
