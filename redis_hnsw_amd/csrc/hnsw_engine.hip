@@ -62,7 +62,7 @@ struct hnsw_index {
     OccCtl *d_occ_ctl = nullptr;
     uint32_t occ_window = 32;       // tuning: window slots (0 = the serial path only)
     uint32_t occ_min_batch = 64;    // batches smaller than this take the serial path
-    uint32_t occ_ahead_x10 = 25;    // tuning: look-ahead = this/10 x running yield + 3
+    uint32_t occ_ahead_x10 = 15;    // tuning: look-ahead = this/10 x running yield + 3
     double occ_yield = 4.0;         // commits per round, running average (sizes the look-ahead)
     uint64_t occ_rounds = 0;
     OccCtl occ_last = {};           // counters of the last windowed build (hnsw_debug_occ)
@@ -1390,11 +1390,13 @@ hnsw_status hnsw_reset_counters(hnsw_index *h)
 
 // counters of the last windowed exact build: commits, speculative shrinks applied, shrinks recomputed at commit,
 // plans found stale by the parallel validation, journal entries (development aid; not in the public header)
-hnsw_status hnsw_debug_occ(hnsw_index *h, uint64_t *out5 /* [6] */)
+hnsw_status hnsw_debug_occ(hnsw_index *h, uint64_t *out5 /* [16] */)
 {
     if (!h || !out5) return HNSW_ERR_INVALID;
     out5[0] = h->occ_last.n_commit; out5[1] = h->occ_last.n_spec; out5[2] = h->occ_last.n_fallback;
     out5[3] = h->occ_last.n_stale; out5[4] = h->occ_last.nJ; out5[5] = h->occ_last.stop;   // [5] = rounds
+    for (int i = 0; i < 8; ++i) out5[6 + i] = h->occ_last.prof[i];   // commit kernel phases, shader clocks
+    out5[14] = h->occ_last.n_norec; out5[15] = h->occ_last.n_rowstale;
     return HNSW_OK;
 }
 

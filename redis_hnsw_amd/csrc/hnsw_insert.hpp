@@ -248,19 +248,35 @@ __device__ __forceinline__ void update_connections(const GraphView &g, const Wav
         const uint64_t kb = __ballot(inS);
         if (inS) erow[1 + kept + __popcll(kb & lanemask_lt(lane))] = x;
         kept += __popcll(kb);
-        // bidirectionally remove old-but-not-new (:805-819)
+        // bidirectionally remove old-but-not-new (:805-819).  Each dropped neighbour's row is edited by the
+        // whole wave (one row load, one ballot, one shifted store) instead of one lane walking it word by word.
         const bool drop = i < cnt && !inS && x != ignored;
-        if (drop) {
-            uint32_t *xrow = row_ptr(g, x, lc);
+        uint64_t dm = __ballot(drop);
+        while (dm) {
+            const int j = __ffsll((unsigned long long)dm) - 1;
+            dm &= dm - 1;
+            const uint32_t xj = (uint32_t)__builtin_amdgcn_readlane((int)x, j);
+            uint32_t *xrow = row_ptr(g, xj, lc);
             uint32_t xc = xrow[0];
             if (xc > stride - 1) xc = stride - 1;
-            uint32_t p = 0;
-            while (p < xc && xrow[1 + p] != e) ++p;
-            if (p == xc) atomicOr(&g.hdr->status, ST_ASYMMETRIC); // reference panics, :150
-            else {
-                for (; p + 1 < xc; ++p) xrow[1 + p] = xrow[2 + p];
-                xrow[0] = xc - 1;
+            bool found = false;
+            for (uint32_t b2 = 0; b2 < xc; b2 += 64) {          // rows wider than 63 ids: more than one pass
+                const uint32_t p = b2 + lane;
+                const uint32_t v = p < xc ? xrow[1 + p] : kEmpty;
+                const uint32_t vnext = p + 1 < xc ? xrow[2 + p] : kEmpty;
+                const uint64_t hit = __ballot(p < xc && v == e);
+                if (!found && hit) {
+                    found = true;
+                    const uint32_t pos = b2 + (uint32_t)(__ffsll((unsigned long long)hit) - 1);
+                    __builtin_amdgcn_wave_barrier();
+                    if (p >= pos && p + 1 < xc) xrow[1 + p] = vnext;
+                } else if (found) {
+                    __builtin_amdgcn_wave_barrier();
+                    if (p + 1 < xc) xrow[1 + p] = vnext;
+                }
             }
+            if (!found) { if (lane == 0) atomicOr(&g.hdr->status, ST_ASYMMETRIC); }   // reference panics, :150
+            else if (lane == 0) xrow[0] = xc - 1;
         }
         touch_push(touched, touched_cap, nt, x, drop, lane); // :816
         journal_push(jr, drop, e, lc, x, false, lane);
@@ -273,14 +289,21 @@ __device__ __forceinline__ void update_connections(const GraphView &g, const Wav
         if (isNew)
             for (uint32_t i = 0; i < cnt; ++i) isNew &= m.aux[i] != x;
         const uint64_t nb = __ballot(isNew);
-        if (isNew) {
-            erow[1 + kept + __popcll(nb & lanemask_lt(lane))] = x;
-            uint32_t *xrow = row_ptr(g, x, lc);
+        if (isNew) erow[1 + kept + __popcll(nb & lanemask_lt(lane))] = x;
+        uint64_t am = nb;
+        while (am) {                                            // wave-cooperative append of e to each new neighbour's row
+            const int j = __ffsll((unsigned long long)am) - 1;
+            am &= am - 1;
+            const uint32_t xj = (uint32_t)__builtin_amdgcn_readlane((int)x, j);
+            uint32_t *xrow = row_ptr(g, xj, lc);
             uint32_t xc = xrow[0];
             if (xc > stride - 1) xc = stride - 1;
             bool present = false;
-            for (uint32_t p = 0; p < xc; ++p) present |= xrow[1 + p] == e;
-            if (!present) {
+            for (uint32_t b2 = 0; b2 < xc; b2 += 64) {
+                const uint32_t p = b2 + lane;
+                present |= __ballot(p < xc && xrow[1 + p] == e) != 0;
+            }
+            if (!present && lane == 0) {
                 if (xc + 1 > stride - 1) atomicOr(&g.hdr->status, ST_ROW_OVERFLOW);
                 else { xrow[1 + xc] = e; xrow[0] = xc + 1; atomicMax(maxdeg, xc + 1); }
             }
@@ -292,7 +315,7 @@ __device__ __forceinline__ void update_connections(const GraphView &g, const Wav
     }
     if (lane == 0) erow[0] = kept;
     touch_push(touched, touched_cap, nt, e, lane == 0, lane);               // :787
-    __threadfence();
+    fence_own_writes();
     __syncthreads();
 }
 

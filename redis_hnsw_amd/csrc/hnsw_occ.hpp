@@ -28,12 +28,13 @@ namespace hnsw {
 
 constexpr uint32_t kOccMaxW = 64;           // window slots
 constexpr uint32_t kOccMaxReads = 3072;     // read-log entries per slot
-constexpr uint32_t kOccMaxShr = 48;         // speculative shrinks per slot
-constexpr uint32_t kOccHash = 8192;         // validation hash slots (> 2 x reads)
+constexpr uint32_t kOccMaxShr = 32;         // speculative shrinks per slot (window slots x this <= HBM spill slots)
+constexpr uint32_t kOccHash = 4096;         // validation hash slots
 constexpr uint32_t kOccMaxHits = 1024;      // (reader, z) pairs whose distance must be evaluated per validation
 
 struct OccShr {
-    uint32_t lc, e, nS, bound;              // bound = distance bits of the last selected
+    uint32_t lc, e, nS, bound;              // bound = distance bits of the last selected; nS = 0: not computed yet
+    uint32_t log0, cnt, pad0, pad1;         // its read-log range starts at log0: 1 + cnt + 1 entries (row e, its members, this node)
     uint32_t S[64];                         // selected ids, nearest first
 };
 struct OccSlot {
@@ -46,7 +47,8 @@ struct OccCtl {
     uint32_t nJ;                            // journal entries ever written
     uint32_t epoch;                         // bumped when enterpoint / max_layer change (every plan reads them)
     uint32_t stop;                          // why the last commit kernel stopped
-    unsigned long long n_commit, n_spec, n_fallback, n_stale;
+    unsigned long long n_commit, n_spec, n_fallback, n_stale, n_norec, n_rowstale;
+    unsigned long long prof[8];             // commit kernel, shader clocks: hash, first check, connect, shrink checks, apply, recompute, finish, total
 };
 
 struct OccBufs {
@@ -63,10 +65,11 @@ struct OccScratch {
     uint32_t *hkey;     // [kOccHash]
     uint32_t *hhead;    // [kOccHash]
     uint32_t *hnext;    // [kOccMaxReads]
+    uint32_t *hslot;    // [kOccMaxReads] the slot each read went to (so that only used slots are cleared)
     uint32_t *hits;     // [kOccMaxHits][3]: reader (0 = the node itself, 1 + sub = shrink sub), z, bound
     uint32_t *flags;    // [0] link plan stale, [1] hit count, [2 + sub] shrink sub stale
 };
-constexpr size_t kOccScratchBytes = (size_t)(kOccHash * 2 + kOccMaxReads + kOccMaxHits * 3 + 2 + 64) * 4;
+constexpr size_t kOccScratchBytes = (size_t)(kOccHash * 2 + kOccMaxReads * 2 + kOccMaxHits * 3 + 2 + 64) * 4;
 
 __device__ __forceinline__ OccScratch occ_carve(unsigned char *p)
 {
@@ -74,17 +77,27 @@ __device__ __forceinline__ OccScratch occ_carve(unsigned char *p)
     s.hkey = reinterpret_cast<uint32_t *>(p);
     s.hhead = s.hkey + kOccHash;
     s.hnext = s.hhead + kOccHash;
-    s.hits = s.hnext + kOccMaxReads;
+    s.hslot = s.hnext + kOccMaxReads;
+    s.hits = s.hslot + kOccMaxReads;
     s.flags = s.hits + kOccMaxHits * 3;
     return s;
 }
-__device__ __forceinline__ uint32_t occ_hash(uint32_t key) { return (key * 0x9E3779B1u) >> (32 - 13); }   // kOccHash = 2^13
-static_assert(kOccHash == (1u << 13), "occ_hash");
+__device__ __forceinline__ uint32_t occ_hash(uint32_t key) { return (key * 0x9E3779B1u) >> (32 - 12); }   // kOccHash = 2^12
+static_assert(kOccHash == (1u << 12), "occ_hash");
 
 // hash of the slot's read rows: (row, layer) -> chain of read indices
-__device__ __forceinline__ void occ_build_hash(const OccScratch &sc, const OccRead *reads, uint32_t n_reads, int lane)
+__device__ __forceinline__ void occ_init_hash(const OccScratch &sc, int lane)       // once per kernel
 {
     for (uint32_t i = lane; i < kOccHash; i += 64) { sc.hkey[i] = kEmpty; sc.hhead[i] = kEmpty; }
+    __syncthreads();
+}
+__device__ __forceinline__ void occ_clear_hash(const OccScratch &sc, uint32_t n_reads, int lane)   // after a slot is done
+{
+    for (uint32_t i = lane; i < n_reads; i += 64) { const uint32_t h = sc.hslot[i]; sc.hkey[h] = kEmpty; sc.hhead[h] = kEmpty; }
+    __syncthreads();
+}
+__device__ __forceinline__ void occ_build_hash(const OccScratch &sc, const OccRead *reads, uint32_t n_reads, int lane)
+{
     for (uint32_t i = lane; i < 2 + 64; i += 64) sc.flags[i] = 0;
     __syncthreads();
     for (uint32_t i = lane; i < n_reads; i += 64) {
@@ -95,6 +108,7 @@ __device__ __forceinline__ void occ_build_hash(const OccScratch &sc, const OccRe
             if (old == kEmpty || old == key) break;
             h = (h + 1) & (kOccHash - 1);
         }
+        sc.hslot[i] = h;
         sc.hnext[i] = atomicExch(&sc.hhead[h], i);
     }
     __syncthreads();
@@ -128,6 +142,7 @@ __device__ __forceinline__ void occ_check_range(const GraphView &g, const WaveMe
                     const bool full = (r.meta >> 13) & 1u;
                     if (kind == OCC_SHRINK_ROW) {
                         if (d.z == q && add) continue;                   // this node's own connect
+                        if (!sc.flags[2 + sub]) atomicAdd(&ob.ctl->n_rowstale, 1ull);
                         sc.flags[2 + sub] = 1;
                         continue;
                     }
@@ -264,7 +279,8 @@ __global__ __launch_bounds__(64, 1) void k_occ_plan(GraphView g, OccBufs ob, uin
     __threadfence();
     __syncthreads();
 
-    // ---- speculative shrinks (core.rs:540-574), each as if only this node's connect had happened ----
+    // ---- the shrinks the connect will trigger (core.rs:560-561): listed here, computed speculatively by
+    // k_occ_shrinks, one wave each ----
     uint32_t n_shr = 0;
     for (uint32_t lc1 = top + 1; lc1-- > 0 && !fail;) {
         const uint32_t lc = lc1;
@@ -272,45 +288,31 @@ __global__ __launch_bounds__(64, 1) void k_occ_plan(GraphView g, OccBufs ob, uin
         const uint32_t mmax = lc ? mlinks : 2 * mlinks;     // core.rs:560
         const uint32_t *pl = pl0 + (size_t)lc * kPlanStride;
         const uint32_t nsel = pl[0];
-        for (uint32_t si = 0; si < nsel && !fail; ++si) {
-            const uint32_t e = pl[1 + si];
-            const uint32_t *erow = row_ptr(g, e, lc);
-            uint32_t cnt = erow[0];
-            if (cnt > stride - 1) cnt = stride - 1;
-            if (cnt + 1 <= mmax) continue;                  // :561 (the row with this node appended)
-            if (n_shr >= kOccMaxShr || cnt + 1 > kAuxWords) { fail = true; break; }
-            // econn: e's row in stored order, this node last (core.rs:544-558)
-            QReg<T> qe;
-            load_query<MODE, T>(g.vec + (size_t)e * g.dim, g.dim, qe, m.qlds, lane);
-            uint32_t nE = 0;
-            const uint32_t tot = cnt + 1;
-            for (uint32_t base = 0; base < tot; base += 64) {
-                const uint32_t i = base + lane;
-                const uint32_t nf = tot - base < 64 ? tot - base : 64;
-                if (i < tot) { const uint32_t x = i < cnt ? erow[1 + i] : id; m.fresh[lane] = x; m.aux[i] = x; }
-                __syncthreads();
-                compute_dists<MODE, T>(g, qe, m, nf, lane);
-                __syncthreads();
-                const bool have = (uint32_t)lane < nf;
-                const uint64_t key = have ? pack_key(m.dsc[lane], m.fresh[lane]) : ~0ull;
-                nE = merge_sorted<R>(m.W, nE, R * 64, key, have, lane);
-            }
-            WorkCtr nolog = {};
-            const uint32_t nS = select_topm<MODE, T>(g, m, vis, qe, m.W, nE, e, mmax, lc, nolog, lane, fail); // :568
-            if (fail) break;
-            OccShr *sp = &shr[n_shr];
-            const uint32_t bound = (uint32_t)(m.S[nS - 1] >> 32);
-            if (lane == 0) { sp->lc = lc; sp->e = e; sp->nS = nS; sp->bound = bound; }
-            if ((uint32_t)lane < nS) sp->S[lane] = key_id(m.S[lane]);
-            // reads: row e itself, and the rows of econn's members
-            if (lane == 0 && ctr.log_n < kOccMaxReads) reads[ctr.log_n] = OccRead{e, occ_meta(lc, OCC_SHRINK_ROW, n_shr, true), 0u};
-            ctr.log_n += 1;
-            for (uint32_t i = lane; i < tot; i += 64)
-                if (ctr.log_n + i < kOccMaxReads) reads[ctr.log_n + i] = OccRead{m.aux[i], occ_meta(lc, OCC_SHRINK_NB, n_shr, true), bound};
-            ctr.log_n += tot;
-            n_shr += 1;
-            __syncthreads();
+        const uint32_t e = (uint32_t)lane < nsel ? pl[1 + lane] : 0u;
+        uint32_t cnt = (uint32_t)lane < nsel ? row_ptr(g, e, lc)[0] : 0u;
+        if (cnt > stride - 1) cnt = stride - 1;
+        const bool need = (uint32_t)lane < nsel && cnt + 1 > mmax;   // :561 (the row with this node appended)
+        const uint64_t nm = __ballot(need);
+        const uint32_t k = n_shr + (uint32_t)__popcll(nm & lanemask_lt(lane));
+        // log ranges: running sum of (cnt + 2) over the lanes that need a shrink, in selection order
+        uint32_t off = 0;
+        uint32_t run = ctr.log_n;
+        for (uint64_t mm = nm; mm; mm &= mm - 1) {
+            const int j = __ffsll((unsigned long long)mm) - 1;
+            const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cnt, j);
+            if (lane == j) off = run;
+            run += cj + 2;
         }
+        if (need) {
+            if (k >= kOccMaxShr || cnt + 1 > kAuxWords) fail = true;
+            else {
+                OccShr *sp = &shr[k];
+                sp->lc = lc; sp->e = e; sp->nS = 0; sp->bound = 0; sp->log0 = off; sp->cnt = cnt;
+            }
+        }
+        fail = __ballot(fail) != 0;
+        ctr.log_n = run;
+        n_shr += (uint32_t)__popcll(nm);
     }
     if (ctr.log_n > kOccMaxReads) fail = true;
     if (vis.glob_dirty) visited_clear(vis, lane);
@@ -324,6 +326,71 @@ __global__ __launch_bounds__(64, 1) void k_occ_plan(GraphView g, OccBufs ob, uin
         atomicAdd(&g.hdr->ctr_insert[1], (unsigned long long)ctr.n_ids);
         atomicAdd(&g.hdr->ctr_insert[2], (unsigned long long)ctr.n_expand);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// speculative shrinks (core.rs:540-574): one wave per (window node, listed shrink), each as if only that
+// node's connect had happened since the snapshot.  The node's own rows hold its selection already (k_occ_plan).
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE, int T, int R>
+__global__ __launch_bounds__(64, 1) void k_occ_shrinks(GraphView g, OccBufs ob, uint32_t first_node, uint32_t count, uint32_t mlinks,
+                                                    uint32_t lnb, uint32_t lcap, uint32_t *__restrict__ gspill, uint32_t gnb)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const uint32_t b = blockIdx.x / kOccMaxShr, k = blockIdx.x % kOccMaxShr;
+    if (b >= count) return;
+    const uint32_t id = first_node + b;
+    const uint32_t slot = id % ob.W;
+    OccSlot *sl = &ob.slots[slot];
+    if (!sl->planned || sl->node != id || sl->fail || k >= sl->n_shr) return;
+    OccShr *sp = &ob.shr[(size_t)slot * kOccMaxShr + k];
+    if (sp->nS != 0) return;                                 // computed in an earlier round, plan still valid
+    OccRead *reads = ob.reads + (size_t)slot * kOccMaxReads;
+
+    WaveMem m;
+    Visited vis;
+    carve<R, T, true>(smem, g.dim, lnb, lcap, m, vis, g.tagcfg);
+    vis.glob = gspill + (size_t)blockIdx.x * gnb * 8;
+    vis.gnb = gnb;
+    vis.glob_dirty = false;
+    vis.spilled = false;
+    vis.count = 0;
+    vis.bounded = false;
+    vis.lossy = false;
+
+    const uint32_t lc = sp->lc, e = sp->e, cnt = sp->cnt, log0 = sp->log0;
+    const uint32_t mmax = lc ? mlinks : 2 * mlinks;         // core.rs:560
+    const uint32_t *erow = row_ptr(g, e, lc);
+    bool fail = false;
+    // econn: e's row in stored order, this node last (core.rs:544-558)
+    QReg<T> qe;
+    load_query<MODE, T>(g.vec + (size_t)e * g.dim, g.dim, qe, m.qlds, lane);
+    uint32_t nE = 0;
+    const uint32_t tot = cnt + 1;
+    for (uint32_t base = 0; base < tot; base += 64) {
+        const uint32_t i = base + lane;
+        const uint32_t nf = tot - base < 64 ? tot - base : 64;
+        if (i < tot) { const uint32_t x = i < cnt ? erow[1 + i] : id; m.fresh[lane] = x; m.aux[i] = x; }
+        __syncthreads();
+        compute_dists<MODE, T>(g, qe, m, nf, lane);
+        __syncthreads();
+        const bool have = (uint32_t)lane < nf;
+        const uint64_t key = have ? pack_key(m.dsc[lane], m.fresh[lane]) : ~0ull;
+        nE = merge_sorted<R>(m.W, nE, R * 64, key, have, lane);
+    }
+    WorkCtr nolog = {};
+    const uint32_t nS = select_topm<MODE, T>(g, m, vis, qe, m.W, nE, e, mmax, lc, nolog, lane, fail); // :568
+    if (vis.glob_dirty) visited_clear(vis, lane);
+    if (fail || nS == 0) { if (lane == 0) sl->fail = 1; return; }
+    const uint32_t bound = (uint32_t)(m.S[nS - 1] >> 32);
+    if ((uint32_t)lane < nS) sp->S[lane] = key_id(m.S[lane]);
+    // reads: row e itself, and the rows of econn's members
+    if (lane == 0 && log0 < kOccMaxReads) reads[log0] = OccRead{e, occ_meta(lc, OCC_SHRINK_ROW, k, true), 0u};
+    for (uint32_t i = lane; i < tot; i += 64)
+        if (log0 + 1 + i < kOccMaxReads) reads[log0 + 1 + i] = OccRead{m.aux[i], occ_meta(lc, OCC_SHRINK_NB, k, true), bound};
+    __threadfence();
+    if (lane == 0) { sp->bound = bound; sp->nS = nS; }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -351,6 +418,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_validate(GraphView g, OccBufs ob,
     m.qlds = reinterpret_cast<float *>(p);
     const OccRead *reads = ob.reads + (size_t)(id % ob.W) * kOccMaxReads;
     const OccShr *shr = ob.shr + (size_t)(id % ob.W) * kOccMaxShr;
+    occ_init_hash(sc, lane);
     occ_build_hash(sc, reads, sl->n_reads, lane);
     occ_check_range<MODE, T>(g, m, sc, ob, reads, shr, id, sl->snap, nJ, lane);
     bool bad = sc.flags[0] != 0;
@@ -386,10 +454,15 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
     OccJournal jr;
     jr.ring = ob.ring;
     jr.n = ob.ctl->nJ;
+    occ_init_hash(sc, lane);
     uint32_t head = ob.ctl->head;
     uint32_t stop = OCC_STOP_NONE;
-    unsigned long long n_commit = 0, n_spec = 0, n_fallback = 0;
+    unsigned long long n_commit = 0, n_spec = 0, n_fallback = 0, n_norec = 0;
     uint32_t nt = 0;
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = __builtin_readcyclecounter();
+    unsigned long long t_ = t_begin;
+#define OCC_T(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); prof[i] += n_ - t_; t_ = n_; } while (0)
 
     while (head < end_node) {
         const uint32_t id = head;
@@ -403,12 +476,16 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
         const OccRead *reads = ob.reads + (size_t)slot * kOccMaxReads;
         const OccShr *shr = ob.shr + (size_t)slot * kOccMaxShr;
         const uint32_t n_shr = sl->n_shr;
+        OCC_T(6);
         occ_build_hash(sc, reads, sl->n_reads, lane);
+        OCC_T(0);
         uint32_t checked = sl->snap;
         occ_check_range<MODE, T>(g, m, sc, ob, reads, shr, id, checked, jr.n, lane);
         checked = jr.n;
+        OCC_T(1);
         if (sc.flags[0]) {                                   // the link plan is stale: re-plan (end of the round)
             __syncthreads();
+            occ_clear_hash(sc, sl->n_reads, lane);
             if (lane == 0) sl->planned = 0;
             stop = OCC_STOP_REPLAN;
             break;
@@ -439,8 +516,9 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
             }
             if (lane == 0) atomicMax(maxdeg, nsel);
             journal_push(&jr, (uint32_t)lane < nsel, myselid, lc, id, true, lane);
-            __threadfence();
+            fence_own_writes();
             __syncthreads();
+            OCC_T(2);
 
             for (uint32_t si = 0; si < nsel && !fail; ++si) {   // shrink loop (core.rs:540-574), e nearest first
                 const uint32_t e = pl[1 + si];
@@ -451,11 +529,12 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
                 // the speculative result, if nothing relevant happened since it was planned
                 int k = -1;
                 for (uint32_t t = 0; t < n_shr; ++t)
-                    if (shr[t].e == e && shr[t].lc == lc) k = (int)t;
+                    if (shr[t].e == e && shr[t].lc == lc && shr[t].nS != 0) k = (int)t;
                 if (k >= 0 && checked != jr.n) {
                     occ_check_range<MODE, T>(g, m, sc, ob, reads, shr, id, checked, jr.n, lane, true);
                     checked = jr.n;
                 }
+                OCC_T(3);
                 for (uint32_t i = lane; i < cnt; i += 64) m.aux[i] = erow[1 + i];
                 __syncthreads();
                 uint32_t nS;
@@ -484,8 +563,11 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
                     nS = select_topm<MODE, T>(g, m, vis, qe, m.W, nE, e, mmax, lc, nolog, lane, fail);
                     if (fail) break;
                     n_fallback += 1;
+                    if (k < 0) n_norec += 1;
+                    OCC_T(5);
                 }
                 update_connections(g, m, e, erow, cnt, nS, lc, stride, maxdeg, kEmpty, nullptr, 0, nt, lane, &jr);
+                OCC_T(4);
             }
         }
         if (fail) { if (lane == 0) atomicOr(&g.hdr->status, ST_VISITED_OVERFLOW); stop = OCC_STOP_SERIAL; break; }
@@ -498,8 +580,9 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
             g.hdr->node_count = id + 1;
             sl->planned = 0;
         }
-        __threadfence();
+        fence_own_writes();
         __syncthreads();
+        occ_clear_hash(sc, sl->n_reads, lane);
         n_commit += 1;
         head += 1;
     }
@@ -511,7 +594,12 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
         ob.ctl->n_commit += n_commit;
         ob.ctl->n_spec += n_spec;
         ob.ctl->n_fallback += n_fallback;
+        ob.ctl->n_norec += n_norec;
+        OCC_T(6);
+        prof[7] = __builtin_readcyclecounter() - t_begin;
+        for (int i = 0; i < 8; ++i) ob.ctl->prof[i] += prof[i];
     }
+#undef OCC_T
 }
 
 } // namespace hnsw

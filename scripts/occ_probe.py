@@ -18,12 +18,15 @@ gi.set_tuning("occ_window", W)
 if os.environ.get("OCC_AHEAD"): gi.set_tuning("occ_ahead_x10", int(os.environ["OCC_AHEAD"]))
 t = time.time(); gi.add_batch(V, levels=lv, mode="exact"); dt = time.time() - t
 lib = _capi.load()
-out = (C.c_uint64 * 6)()
+out = (C.c_uint64 * 16)()
 lib.hnsw_debug_occ.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 lib.hnsw_debug_occ(gi._h, out)
 nc = max(out[0], 1)
 print("N=%d dim=%d M=%d ef=%d W=%d: %.2f s = %.0f inserts/s; commits %d, spec shrinks %d, recomputed %d (%.1f%%), stale plans %d, deltas/commit %.1f, rounds %d (%.2f commits/round)" % (
     N, dim, M, ef, W, dt, N / dt, out[0], out[1], out[2], 100.0 * out[2] / max(out[1] + out[2], 1), out[3], out[4] / nc, out[5], out[0] / max(out[5], 1)), flush=True)
+names = ["hash", "first check", "connect", "shrink checks", "apply", "recompute", "finish/other", "total"]
+print("commit kernel, clocks per commit: " + ", ".join("%s %.0f" % (nm, out[6 + i] / nc) for i, nm in enumerate(names)), flush=True)
+print("recomputed shrinks without a speculative record: %d; row-changed flags (validate+commit): %d" % (out[14], out[15]))
 if check:
     t = time.time(); o = oracle.OracleIndex(dim, M, ef); o.add_batch(V, lv); to = time.time() - t
     ok, why = graphs_equal(o.export(), gi.export_graph())
