@@ -139,6 +139,30 @@ __device__ __forceinline__ uint32_t select_topm(const GraphView &g, const WaveMe
 }
 
 // ---------------------------------------------------------------------------
+// select_neighbors right after search_level, the short way.  When search_level(ef) returns, every member
+// of W has been expanded: the loop (core.rs:630-668) only stops when the nearest unexpanded candidate is
+// strictly farther than W's furthest, which no member of W is.  So every neighbour of every member was
+// visited by that search -- evaluated, and either kept in W or rejected / evicted against a threshold
+// that is no farther than W's final furthest.  The extension of select_neighbors (core.rs:698-721) walks
+// exactly those neighbours (same rows, nothing changed in between): everything it can add is farther than
+// all of W, and the r / wd passes (:724-754) return the m nearest of the pool.  Hence, whenever ef >= m (or W
+// never filled, in which case nothing was ever rejected and the pool IS W):
+//        select_neighbors(query, W, m) = the m nearest of W,
+// no distance evaluation needed (the reference spends about half of an insert's evaluations there:
+// SURVEY 8a-6).  Checked on the CPU against the full procedure (0 differences in 51 k calls, ties and
+// ef == m included) and by the graph-equality tests, which run with it.  `select_shortcut = 0` keeps the full
+// extension (its work counters then equal the reference's).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool select_is_head_of_W(uint32_t ef, uint32_t mcap, uint32_t nW) { return ef >= mcap || nW < ef; }
+__device__ __forceinline__ uint32_t select_head_of_W(const WaveMem &m, uint32_t nW, uint32_t mcap, int lane)
+{
+    const uint32_t nS = nW < mcap ? nW : mcap;
+    if ((uint32_t)lane < nS) m.S[lane] = m.W[lane] & ~1ull;
+    __syncthreads();
+    return nS;
+}
+
+// ---------------------------------------------------------------------------
 // plan kernel: one wave per new node (ids first_id .. first_id+count-1, whose
 // vectors / levels / upper slots are already in HBM and whose rows are empty).
 // plan[(slot*kMaxLayers + lc)*kPlanStride] = n, then n ids nearest first.
@@ -146,7 +170,7 @@ __device__ __forceinline__ uint32_t select_topm(const GraphView &g, const WaveMe
 template <int MODE, int T, int R>
 __global__ __launch_bounds__(64, 1) void k_insert_plan(GraphView g, uint32_t first_id, uint32_t count, uint32_t ef,
                                                     uint32_t mlinks, uint32_t lnb, uint32_t lcap, uint32_t *__restrict__ gspill,
-                                                    uint32_t gnb, uint32_t *__restrict__ plan)
+                                                    uint32_t gnb, uint32_t *__restrict__ plan, uint32_t shortcut)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -183,7 +207,9 @@ __global__ __launch_bounds__(64, 1) void k_insert_plan(GraphView g, uint32_t fir
             const uint32_t nW = search_level<MODE, T, R>(g, m, vis, qr, ep, ef, lc, ctr, lane, fail); // :524
             if (fail) break;
             const uint32_t wnearest = key_id(m.W[0]);
-            const uint32_t nS = select_topm<MODE, T>(g, m, vis, qr, m.W, nW, id, mlinks, lc, ctr, lane, fail); // :531
+            const uint32_t nS = shortcut && select_is_head_of_W(ef, mlinks, nW)
+                                    ? select_head_of_W(m, nW, mlinks, lane)
+                                    : select_topm<MODE, T>(g, m, vis, qr, m.W, nW, id, mlinks, lc, ctr, lane, fail); // :531
             if (fail) break;
             uint32_t *pl = plan + ((size_t)s * kMaxLayers + lc) * kPlanStride;
             if (lane == 0) pl[0] = nS;

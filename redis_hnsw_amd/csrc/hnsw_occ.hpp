@@ -208,7 +208,7 @@ __device__ __forceinline__ void occ_check_range(const GraphView &g, const WaveMe
 template <int MODE, int T, int R>
 __global__ __launch_bounds__(64, 1) void k_occ_plan(GraphView g, OccBufs ob, uint32_t first_node, uint32_t count, uint32_t ef,
                                                  uint32_t mlinks, uint32_t lnb, uint32_t lcap, uint32_t *__restrict__ gspill,
-                                                 uint32_t gnb, uint32_t *__restrict__ plan)
+                                                 uint32_t gnb, uint32_t *__restrict__ plan, uint32_t shortcut)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -255,17 +255,23 @@ __global__ __launch_bounds__(64, 1) void k_occ_plan(GraphView g, OccBufs ob, uin
         const uint32_t nW = search_level<MODE, T, R>(g, m, vis, qr, ep, ef, lc, ctr, lane, fail); // :524
         if (fail) break;
         const uint32_t wnearest = key_id(m.W[0]);
-        // select's reads: the rows of all members of W (logged before S exists; the bound is patched in below)
-        const uint32_t sel_log0 = ctr.log_n;
-        for (uint32_t i = lane; i < nW; i += 64)
-            if (sel_log0 + i < kOccMaxReads) reads[sel_log0 + i] = OccRead{key_id(m.W[i]), occ_meta(lc, OCC_SELECT, 0, false), 0u};
-        ctr.log_n += nW;
-        const uint32_t nS = select_topm<MODE, T>(g, m, vis, qr, m.W, nW, id, mlinks, lc, ctr, lane, fail); // :531
-        if (fail) break;
-        const bool sfull = nS >= mlinks;
-        const uint32_t sbound = nS ? (uint32_t)(m.S[nS - 1] >> 32) : 0u;
-        for (uint32_t i = lane; i < nW; i += 64)
-            if (sel_log0 + i < kOccMaxReads) { reads[sel_log0 + i].meta = occ_meta(lc, OCC_SELECT, 0, sfull); reads[sel_log0 + i].bound = sbound; }
+        uint32_t nS;
+        if (shortcut && select_is_head_of_W(ef, mlinks, nW)) {
+            // the selection is the head of W (see select_head_of_W): it reads nothing the search did not read
+            nS = select_head_of_W(m, nW, mlinks, lane);
+        } else {
+            // select's reads: the rows of all members of W (logged before S exists; the bound is patched in below)
+            const uint32_t sel_log0 = ctr.log_n;
+            for (uint32_t i = lane; i < nW; i += 64)
+                if (sel_log0 + i < kOccMaxReads) reads[sel_log0 + i] = OccRead{key_id(m.W[i]), occ_meta(lc, OCC_SELECT, 0, false), 0u};
+            ctr.log_n += nW;
+            nS = select_topm<MODE, T>(g, m, vis, qr, m.W, nW, id, mlinks, lc, ctr, lane, fail); // :531
+            if (fail) break;
+            const bool sfull = nS >= mlinks;
+            const uint32_t sbound = nS ? (uint32_t)(m.S[nS - 1] >> 32) : 0u;
+            for (uint32_t i = lane; i < nW; i += 64)
+                if (sel_log0 + i < kOccMaxReads) { reads[sel_log0 + i].meta = occ_meta(lc, OCC_SELECT, 0, sfull); reads[sel_log0 + i].bound = sbound; }
+        }
         uint32_t *pl = pl0 + (size_t)lc * kPlanStride;
         if (lane == 0) pl[0] = nS;
         if ((uint32_t)lane < nS) pl[1 + lane] = key_id(m.S[lane]);

@@ -348,6 +348,7 @@ def test_exact_insert_builds_identical_graph(eng, oracle_mod, n, dim, m, ef):
     lv = oracle_mod.draw_levels(n, m, 5)
     o = oracle_mod.OracleIndex(dim, m, ef)
     gi = eng.Index("foo", dim, m, ef)
+    gi.set_tuning("select_shortcut", 0)     # the full select_neighbors extension: its evaluations are the reference's
     for i in range(n):
         if i % 7 == 0:   # compare the touched sets on a sample
             oid, ot = o.add(V[i], int(lv[i]), want_touched=True)
@@ -363,6 +364,30 @@ def test_exact_insert_builds_identical_graph(eng, oracle_mod, n, dim, m, ef):
     _, ic = gi.counters()
     oc = o.insert_counters()
     assert ic.n_dist + ic.n_spill == oc.n_dist
+    gi.close()
+
+
+@pytest.mark.parametrize("n,dim,m,ef", [(700, 128, 16, 200), (500, 32, 8, 8), (400, 16, 5, 3), (300, 4, 5, 16)])
+def test_select_is_the_head_of_W(eng, oracle_mod, n, dim, m, ef):
+    """select_neighbors right after search_level(ef >= m) is the m nearest of W (hnsw_insert.hpp): the default path
+    skips the extension's evaluations and must still build the reference's graph -- including ef == m, and
+    ef < m where the shortcut must NOT apply -- with fewer distance evaluations than the reference makes."""
+    V = make_data(n, dim, seed=12)
+    lv = oracle_mod.draw_levels(n, m, 5)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    gi = eng.Index("foo", dim, m, ef)
+    gi.set_tuning("occ_window", 0)
+    for i in range(n):
+        o.add(V[i], int(lv[i]))
+        gi.add_node("node%d" % i, V[i], level=int(lv[i]))
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    _, ic = gi.counters()
+    oc = o.insert_counters()
+    if ef >= m:
+        assert ic.n_dist + ic.n_spill < oc.n_dist
+    else:
+        assert ic.n_dist + ic.n_spill == oc.n_dist
     gi.close()
 
 
