@@ -20,3 +20,16 @@ def test_occ_model_reproduces_the_serial_graph(tmp_path):
         assert "graphs IDENTICAL" in r.stdout
         m = re.search(r"commits/round=([0-9.]+)", r.stdout)
         assert m and float(m.group(1)) >= 1.0
+
+
+def test_select_after_search_is_the_head_of_W(tmp_path):
+    """tests/experiments/select_head.c: the reference's insert() with the full select_neighbors never returns
+    anything but the m nearest of W (what the engine's plan kernels use instead of the extension)."""
+    exe = str(tmp_path / "select_head")
+    src = os.path.join(ROOT, "tests", "experiments", "select_head.c")
+    subprocess.check_call(["gcc", "-O2", "-mavx2", "-mfma", "-ffp-contract=off", "-w", "-o", exe, src, "-lm", "-lpthread"])
+    for args in (["4000", "32", "16", "200"], ["3000", "16", "5", "16"], ["2500", "8", "4", "8"], ["2500", "8", "5", "16", "dup"],
+                 ["2000", "16", "8", "8"]):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "differing from the m nearest of W: 0" in r.stdout
