@@ -81,8 +81,11 @@ hnsw_status hnsw_add(hnsw_index *h, const float *v, uint32_t dim, int32_t level,
                      uint32_t *out_id, uint32_t *touched, uint32_t touched_cap,
                      uint32_t *n_touched);
 
-/* Bulk build (BASELINE.json config 5).  mode 0 = exact: n sequential
- * hnsw_add() calls without per-call host round trips for `touched`.
+/* Bulk build (BASELINE.json config 5).  mode 0 = exact: the graph of n sequential
+ * hnsw_add() calls (core.rs:489-599 in insert order), link for link.  Batches of
+ * 64 or more are planned in parallel and committed strictly in id order after
+ * each plan has been validated against the rows changed since it was made
+ * (csrc/hnsw_occ.hpp; "occ_window" = 0 runs the inserts one after the other).
  * mode 1 = fast: inserts are planned in data-parallel batches against a
  * snapshot and committed together -- NOT link-for-link identical to the
  * reference's serial order; judged by recall parity only.  levels may be NULL. */
@@ -142,9 +145,18 @@ hnsw_status hnsw_serialize(hnsw_index *h, void *buf, uint64_t cap, uint64_t *wri
 hnsw_status hnsw_deserialize(const void *buf, uint64_t bytes, uint64_t seed, int device,
                              hnsw_index **out);
 
-/* Engine knobs (not part of the reference surface): "lds_buckets" (32-byte
- * buckets of the per-query LDS visited table), "grid" (cap on resident query waves), "tag_table" (16-bit tag visited table on/off), "tag_bb" (force its log2 size),
- * "fast_seed" / "fast_batch_max" / "fast_batch_div" (fast build schedule).   */
+/* Engine knobs (not part of the reference surface).
+ *   search    "launch_concurrency" (search launches the caller keeps in flight: sizes the LDS share),
+ *             "waves_per_cu" (residency the visited table is sized for, default 8), "visited_bounded"
+ *             (1: a full LDS visited table stops recording -- exact results, distance evaluations may
+ *             exceed the reference's; 0: the table continues in HBM -- counters equal the reference's),
+ *             "lean" (specialised dim-128 kernel on/off), "query_in_lds", "time_launches",
+ *             "lds_buckets" / "lds_hash_bits" / "tag_table" / "tag_bb" / "idbits" / "grid" (tests)
+ *   build     "occ_window" (slots of the exact parallel insert, 0 = serial), "occ_min_batch",
+ *             "occ_ahead_x10", "select_shortcut" (1: select_neighbors after search_level is the head
+ *             of W, see csrc/hnsw_insert.hpp), "fast_seed" / "fast_batch_max" / "fast_batch_div"
+ *   storage   "compress_bf16" (one way: bf16 vector storage, the index becomes read-only; dim 128),
+ *             "force_restride" (tests)                                                              */
 hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value);
 
 hnsw_status hnsw_get_counters(hnsw_index *h, hnsw_counters *search, hnsw_counters *insert);
