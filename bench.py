@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--streams", type=int, default=2, help="steps in flight (HIP streams used round-robin)")
+    ap.add_argument("--waves-per-cu", type=int, default=0, help="engine tuning waves_per_cu (0 = default 8)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clustered", action="store_true")
@@ -200,6 +201,8 @@ def main():
         raise SystemExit("--graph reference needs %s (python tests/fixtures/make_ref_graph.py --out ...)" % fixture)
     index = Index("bench", dim, M, ef, device=local_rank)
     index.set_tuning("launch_concurrency", S)
+    if args.waves_per_cu:
+        index.set_tuning("waves_per_cu", args.waves_per_cu)
     graph = None
     t_build = None
     graph_desc = {"reference": "reference-order (serial core.rs:489-599 order; fixture built by the CPU oracle, imported with hnsw_import)",
@@ -349,7 +352,7 @@ def main():
         search_now(myQ[b * B:(b + 1) * B], B)
     sx, _ = index.counters()
     index.set_tuning("visited_bounded", 1)
-    index.set_tuning("waves_per_cu", 8)
+    index.set_tuning("waves_per_cu", args.waves_per_cu or 8)
     index.set_tuning("launch_concurrency", S)
     n_dist_q, n_ids_q, n_exp_q = sx.n_dist / (nb_exact * B), sx.n_ids / (nb_exact * B), sx.n_expand / (nb_exact * B)
     redo = sc.n_dist / (args.steps * B) / n_dist_q - 1.0 if args.steps else 0.0
