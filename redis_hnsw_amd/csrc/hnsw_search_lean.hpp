@@ -209,7 +209,6 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
             uint64_t key = ~0ull;
             bool take = false;
             uint64_t rkey = ~0ull;                                // first unexpanded entry of W (last chunk only)
-            uint32_t word_spec = 0;                               // ... and its adjacency row, requested early
             if (nch) {
                 // slot s = r*SPR + grp of this chunk sits in lane c0 + 1 + s; empty slots re-read the first id
                 const uint32_t safe = (uint32_t)__builtin_amdgcn_readlane((int)word, (int)(c0 + 1));
@@ -241,15 +240,11 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
                     ptake = false;
                 }
                 if (last) {
-                    // W is complete: unless one of this chunk's keys beats it, its first unexpanded entry is the
-                    // next candidate.  Requesting that row now, behind the vector loads, takes one of the two
-                    // dependent memory round trips of an expansion off the chain whenever the guess holds (a
-                    // wrong guess costs one 256-byte row).
+                    // W is complete: its first unexpanded entry is the next candidate unless one of this chunk's
+                    // keys beats it.  (Requesting that entry's row here, one round trip early, was measured:
+                    // no gain -- the rank loop already covers the row fetch -- so it is not done.)
                     int r2, l2;
-                    if (first_unexpanded<R>(w, rkey, r2, l2)) {
-                        const uint32_t *rs = row_ptr(g, key_id(rkey), lc);
-                        word_spec = (uint32_t)lane < stride ? rs[lane] : 0u;
-                    } else rkey = ~0ull;
+                    if (!first_unexpanded<R>(w, rkey, r2, l2)) rkey = ~0ull;
                 }
                 // ---- distances ----
                 float dsel = 0.f;
@@ -290,11 +285,8 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
                 }
                 have_next = nkey != ~0ull;
                 if (have_next) {
-                    if (nkey == rkey && nch) word_next = word_spec;          // the early request was the right one
-                    else {
-                        row = row_ptr(g, key_id(nkey), lc);
-                        word_next = (uint32_t)lane < stride ? row[lane] : 0u;
-                    }
+                    row = row_ptr(g, key_id(nkey), lc);
+                    word_next = (uint32_t)lane < stride ? row[lane] : 0u;
                 }
                 pkey = key;
                 ptake = take;
