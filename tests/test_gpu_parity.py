@@ -811,6 +811,9 @@ def test_full_size_c4_10m_properties_and_sampled_parity(eng, oracle_mod):
     (2500, 128, 16, 200, 64),
     (1500, 12, 4, 24, 8),        # scalar metric order, m = 4: many layers, enterpoint changes inside windows
     (1200, 768, 32, 400, 16),    # wide rows, R = 8
+    (3000, 8, 2, 8, 16),         # m = 2: rows outgrow the initial stride inside a window (restride between rounds)
+    (2500, 16, 3, 12, 32),
+    (20000, 128, 16, 200, 32),   # C2's shape at 20 k nodes
 ])
 def test_windowed_exact_build_is_the_serial_graph(eng, oracle_mod, n, dim, m, ef, window):
     """hnsw_add_batch(mode 0) plans a window of inserts in parallel and commits them in id order after
@@ -830,7 +833,10 @@ def test_windowed_exact_build_is_the_serial_graph(eng, oracle_mod, n, dim, m, ef
     Q = make_data(32, dim, seed=2)
     ids, sims, n_out = gi.search_batch(Q, 5)
     oids, osims, on, _ = o.search_batch(Q, 5)
-    assert np.array_equal(n_out, on) and np.array_equal(ids, oids) and np.array_equal(_bits(sims), _bits(osims))
+    assert np.array_equal(n_out, on)
+    for i in range(len(Q)):                      # min(k, ef, reachable) results: m = 2 graphs have tiny components
+        c = int(on[i])
+        assert np.array_equal(ids[i, :c], oids[i, :c]) and np.array_equal(_bits(sims[i, :c]), _bits(osims[i, :c]))
     # single exact inserts and deletes keep working on the result
     W2 = make_data(20, dim, seed=82)
     for i in range(20):
