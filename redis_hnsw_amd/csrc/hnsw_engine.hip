@@ -62,6 +62,8 @@ struct hnsw_index {
     OccCtl *d_occ_ctl = nullptr;
     uint32_t occ_window = 32;       // tuning: window slots (0 = the serial path only)
     uint32_t occ_min_batch = 64;    // batches smaller than this take the serial path
+    uint32_t occ_log_cap = kOccMaxReads;   // tests: a tiny read log sends every node of the window to the serial kernels
+    uint32_t occ_slack_extra = 0;   // tests: demand this much more free room per row (exercises the restride stop)
     uint32_t occ_ahead_x10 = 15;    // tuning: look-ahead = this/10 x running yield + 3
     double occ_yield = 4.0;         // commits per round, running average (sizes the look-ahead)
     uint64_t occ_rounds = 0;
@@ -763,6 +765,8 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
     if (!std::strcmp(key, "select_shortcut")) { h->select_shortcut = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "occ_window")) { h->occ_window = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), kOccMaxW); return HNSW_OK; }
     if (!std::strcmp(key, "occ_ahead_x10")) { h->occ_ahead_x10 = (uint32_t)std::max<int64_t>(value, 5); return HNSW_OK; }
+    if (!std::strcmp(key, "occ_slack_extra")) { h->occ_slack_extra = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 64); return HNSW_OK; }
+    if (!std::strcmp(key, "occ_log_cap")) { h->occ_log_cap = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), kOccMaxReads); return HNSW_OK; }
     if (!std::strcmp(key, "occ_min_batch")) { h->occ_min_batch = (uint32_t)std::max<int64_t>(value, 1); return HNSW_OK; }
     if (!std::strcmp(key, "lean")) { h->lean = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "query_in_lds")) {     // dims 128 / 768 normally keep the query in registers (T = dim/32)

@@ -208,7 +208,7 @@ __device__ __forceinline__ void occ_check_range(const GraphView &g, const WaveMe
 template <int MODE, int T, int R>
 __global__ __launch_bounds__(64, 1) void k_occ_plan(GraphView g, OccBufs ob, uint32_t first_node, uint32_t count, uint32_t ef,
                                                  uint32_t mlinks, uint32_t lnb, uint32_t lcap, uint32_t *__restrict__ gspill,
-                                                 uint32_t gnb, uint32_t *__restrict__ plan, uint32_t shortcut)
+                                                 uint32_t gnb, uint32_t *__restrict__ plan, uint32_t shortcut, uint32_t log_cap)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_plan(GraphView g, OccBufs ob, uin
         ctr.log_n = run;
         n_shr += (uint32_t)__popcll(nm);
     }
-    if (ctr.log_n > kOccMaxReads) fail = true;
+    if (ctr.log_n > log_cap) fail = true;           // (log_cap < kOccMaxReads only in tests: forces the serial path)
     if (vis.glob_dirty) visited_clear(vis, lane);
     __threadfence();
     if (lane == 0) {
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_validate(GraphView g, OccBufs ob,
 template <int MODE, int T, int R>
 __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, uint32_t end_node, uint32_t mlinks, uint32_t lnb,
                                                    uint32_t lcap, uint32_t *__restrict__ gspill, uint32_t gnb,
-                                                   const uint32_t *__restrict__ plan)
+                                                   const uint32_t *__restrict__ plan, uint32_t slack)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
         if (sl->fail) { stop = OCC_STOP_SERIAL; break; }
         if (sl->epoch != ob.ctl->epoch) { if (lane == 0) sl->planned = 0; stop = OCC_STOP_REPLAN; break; }
         // one insert raises any row by at most m + 1 per layer (connect + third-party appends of its shrinks)
-        if (g.hdr->max_deg0 + mlinks + 2 > g.stride0 - 1 || g.hdr->max_degU + mlinks + 2 > g.strideU - 1) { stop = OCC_STOP_RESTRIDE; break; }
+        if (g.hdr->max_deg0 + slack > g.stride0 - 1 || g.hdr->max_degU + slack > g.strideU - 1) { stop = OCC_STOP_RESTRIDE; break; }
         const OccRead *reads = ob.reads + (size_t)slot * kOccMaxReads;
         const OccShr *shr = ob.shr + (size_t)slot * kOccMaxShr;
         const uint32_t n_shr = sl->n_shr;

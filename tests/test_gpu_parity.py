@@ -849,6 +849,40 @@ def test_windowed_exact_build_is_the_serial_graph(eng, oracle_mod, n, dim, m, ef
     gi.close()
 
 
+def test_windowed_build_survives_restrides(eng, oracle_mod):
+    """The committing wave stops the round when a row could run out of room; the host widens the adjacency
+    tables and the window continues with the plans it has.  Forced here by demanding extra room per row."""
+    n, dim, m, ef = 1500, 32, 8, 48
+    V = make_data(n, dim, seed=84)
+    lv = oracle_mod.draw_levels(n, m, 5)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch(V, lv)
+    gi = eng.Index("r", dim, m, ef)
+    gi.set_tuning("occ_slack_extra", 30)
+    s0 = gi.info().stride0
+    gi.add_batch(V, levels=lv, mode="exact")
+    assert gi.info().stride0 > s0                       # at least one restride happened inside the build
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    gi.close()
+
+
+def test_windowed_build_falls_back_to_the_serial_kernels(eng, oracle_mod):
+    """A plan whose read log does not fit cannot be validated: the window hands that node to the serial
+    plan + commit kernels and starts a new epoch.  Forced for every node by a tiny log."""
+    n, dim, m, ef = 500, 32, 6, 32
+    V = make_data(n, dim, seed=85)
+    lv = oracle_mod.draw_levels(n, m, 5)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch(V, lv)
+    gi = eng.Index("s", dim, m, ef)
+    gi.set_tuning("occ_log_cap", 8)
+    gi.add_batch(V, levels=lv, mode="exact")
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    gi.close()
+
+
 def test_windowed_and_serial_exact_builds_agree(eng):
     n, dim, m, ef = 2000, 64, 6, 48
     V = make_data(n, dim, seed=83)
