@@ -849,6 +849,24 @@ def test_windowed_exact_build_is_the_serial_graph(eng, oracle_mod, n, dim, m, ef
     gi.close()
 
 
+def test_windowed_exact_build_on_clustered_and_duplicated_data(eng, oracle_mod):
+    """Not uniform: a 16-cluster Gaussian mixture (dense neighbourhoods, many more relevant row changes per
+    window) with every 10th vector repeated (tied similarities: the validation counts ties as relevant)."""
+    from bench import clustered
+    n, dim, m, ef = 4000, 32, 8, 64
+    centers = np.random.default_rng(3).random((16, dim), dtype=np.float32)
+    V = clustered(n, dim, 4, centers)
+    V[10::10] = V[9::10][: len(V[10::10])]
+    lv = oracle_mod.draw_levels(n, m, 6)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch(V, lv)
+    gi = eng.Index("c", dim, m, ef)
+    gi.add_batch(V, levels=lv, mode="exact")
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    gi.close()
+
+
 def test_windowed_build_survives_restrides(eng, oracle_mod):
     """The committing wave stops the round when a row could run out of room; the host widens the adjacency
     tables and the window continues with the plans it has.  Forced here by demanding extra room per row."""
