@@ -6,7 +6,7 @@
 // same work counters as search_level_v2; what is gone is everything that made the general routine's
 // instruction stream long: the HBM spill path and its three table formats inside the loop, the second code
 // path for rows wider than 32, and the closures the compiler spilled scalar registers for.  A row is walked
-// in chunks of 32 ids; the rounds of 8 vectors a chunk does not need are skipped (uniform branches), which is
+// in chunks of 40 ids; the rounds of 8 vectors a chunk does not need are skipped (uniform branches), which is
 // what the narrow rows of C1 (M=5) want.
 #pragma once
 #include "hnsw_device.hpp"
@@ -78,10 +78,10 @@ __device__ __forceinline__ bool tagset_visit(TagSet<BB, DB> &v, bool valid, uint
 
 // ---- vector formats ------------------------------------------------------------------------------------
 // f32 rows (the reference's data): 8 lanes per vector, each the 16-byte piece piece_of_lane() of every
-// 128-byte block; 8 vectors per round, 4 rounds per chunk of 32 ids.  AVX2 order of metrics.rs:48-77.
+// 128-byte block; 8 vectors per round, up to 5 rounds per chunk of 40 ids.  AVX2 order of metrics.rs:48-77.
 template <int T>
 struct VecF32 {
-    static constexpr int LPV = 8, SPR = 8, NR = 4;
+    static constexpr int LPV = 8, SPR = 8, NR = 5;      // 5 rounds: a chunk is 40 ids (rows of 33-40 ids are 10 % of the expansions)
     struct Q { float4 q[T]; };
     struct V { float4 v[T]; };
     static __device__ __forceinline__ void load_q(const float *src, Q &q, int lane)
@@ -105,10 +105,10 @@ struct VecF32 {
 // f32 -- same 4 x 8 accumulators, same FMA order in t, same reduction tree -- so results are bit-identical
 // to the reference run on the bf16-rounded vectors.  A 16-byte load is 8 consecutive elements = the 8 AVX
 // lanes of ONE accumulator of one 32-element block, so a vector takes 4 lanes (lane a = accumulator a),
-// 16 vectors per round, 2 rounds per chunk.
+// 16 vectors per round, up to 3 rounds per chunk.
 template <int T>
 struct VecBF16 {
-    static constexpr int LPV = 4, SPR = 16, NR = 2;
+    static constexpr int LPV = 4, SPR = 16, NR = 3;     // a chunk is 48 ids
     struct Q { f32x2 q[T][4]; };          // q[t][k] = elements 32t + 8a + 2k, +1
     struct V { uint4 x[T]; };
     static __device__ __forceinline__ void load_q(const float *src, Q &q, int lane)
@@ -203,9 +203,10 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
         uint32_t word_next = 0;
 
         uint32_t c0 = 0;
-        do {                                                      // chunks of 32 ids (core.rs:646 stored order)
-            const uint32_t nch = cnt - c0 < 32u ? cnt - c0 : 32u;
-            const bool last = c0 + 32u >= cnt;
+        constexpr uint32_t CH = (uint32_t)(NR * SPR);             // ids per chunk
+        do {                                                      // chunks of CH ids (core.rs:646 stored order)
+            const uint32_t nch = cnt - c0 < CH ? cnt - c0 : CH;
+            const bool last = c0 + CH >= cnt;
             uint64_t key = ~0ull;
             bool take = false;
             uint64_t rkey = ~0ull;                                // first unexpanded entry of W (last chunk only)
@@ -224,7 +225,7 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
                 for (int r = 0; r < NR; ++r)
                     if (r == 0 || nch > (uint32_t)(r * SPR)) VEC::load_v(g, idr[r], lane, v[r]);   // uniform: skipped rounds cost nothing
                 // ---- under those loads: visited filter (core.rs:648-649) and the deferred merge ----
-                if (!vis.lossy && vis.count + 32u > vis.lcap) {
+                if (!vis.lossy && vis.count + CH > vis.lcap) {
                     vis.lossy = true;
                     if (lane == 0) atomicAdd(lossy_ctr, 1ull);
                 }
@@ -291,7 +292,7 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
                 pkey = key;
                 ptake = take;
             }
-            c0 += 32u;
+            c0 += CH;
         } while (c0 < cnt);
 
         if (!have_next) break;                                    // core.rs:630,635
