@@ -245,6 +245,8 @@ constexpr uint32_t kOccJournalBits = 18;
 struct OccJournal {
     OccDelta *ring;
     uint32_t n;                                      // the committing wave's copy of the counter (wave-uniform)
+    OccDelta *own;                                   // optional LDS mirror of the entries from own_base on
+    uint32_t own_base;
 };
 // lanes flagged `on` each append one delta (wave-uniform call)
 __device__ __forceinline__ void journal_push(OccJournal *jr, bool on, uint32_t row, uint32_t lc, uint32_t z, bool add, int lane)
@@ -254,7 +256,10 @@ __device__ __forceinline__ void journal_push(OccJournal *jr, bool on, uint32_t r
     if (!b) return;
     if (on) {
         const uint32_t p = (jr->n + (uint32_t)__popcll(b & lanemask_lt(lane))) & ((1u << kOccJournalBits) - 1u);
-        jr->ring[p] = OccDelta{row, lc | (add ? 256u : 0u), z};
+        const OccDelta d = OccDelta{row, lc | (add ? 256u : 0u), z};
+        jr->ring[p] = d;
+        const uint32_t o = jr->n + (uint32_t)__popcll(b & lanemask_lt(lane)) - jr->own_base;
+        if (jr->own && o < 256u) jr->own[o] = d;
     }
     jr->n += (uint32_t)__popcll(b);
 }

@@ -30,6 +30,7 @@ constexpr uint32_t kOccMaxW = 64;           // window slots
 constexpr uint32_t kOccMaxReads = 3072;     // read-log entries per slot
 constexpr uint32_t kOccMaxShr = 32;         // speculative shrinks per slot (window slots x this <= HBM spill slots)
 constexpr uint32_t kOccHash = 4096;         // validation hash slots
+constexpr uint32_t kOccOwn = 256;           // own deltas of one commit mirrored in LDS
 constexpr uint32_t kOccMaxHits = 1024;      // (reader, z) pairs whose distance must be evaluated per validation
 
 struct OccShr {
@@ -66,10 +67,13 @@ struct OccScratch {
     uint32_t *hhead;    // [kOccHash]
     uint32_t *hnext;    // [kOccMaxReads]
     uint32_t *hslot;    // [kOccMaxReads] the slot each read went to (so that only used slots are cleared)
+    uint32_t *rmeta;    // [kOccMaxReads] copies of the reads' meta / bound words (the chain walk stays in LDS)
+    uint32_t *rbound;   // [kOccMaxReads]
+    OccDelta *own;      // [kOccOwn] the committing node's own deltas (mirror of the journal tail)
     uint32_t *hits;     // [kOccMaxHits][3]: reader (0 = the node itself, 1 + sub = shrink sub), z, bound
     uint32_t *flags;    // [0] link plan stale, [1] hit count, [2 + sub] shrink sub stale
 };
-constexpr size_t kOccScratchBytes = (size_t)(kOccHash * 2 + kOccMaxReads * 2 + kOccMaxHits * 3 + 2 + 64) * 4;
+constexpr size_t kOccScratchBytes = (size_t)(kOccHash * 2 + kOccMaxReads * 4 + kOccOwn * 3 + kOccMaxHits * 3 + 2 + 64) * 4;
 
 __device__ __forceinline__ OccScratch occ_carve(unsigned char *p)
 {
@@ -78,7 +82,10 @@ __device__ __forceinline__ OccScratch occ_carve(unsigned char *p)
     s.hhead = s.hkey + kOccHash;
     s.hnext = s.hhead + kOccHash;
     s.hslot = s.hnext + kOccMaxReads;
-    s.hits = s.hslot + kOccMaxReads;
+    s.rmeta = s.hslot + kOccMaxReads;
+    s.rbound = s.rmeta + kOccMaxReads;
+    s.own = reinterpret_cast<OccDelta *>(s.rbound + kOccMaxReads);
+    s.hits = s.rbound + kOccMaxReads + kOccOwn * 3;
     s.flags = s.hits + kOccMaxHits * 3;
     return s;
 }
@@ -101,7 +108,10 @@ __device__ __forceinline__ void occ_build_hash(const OccScratch &sc, const OccRe
     for (uint32_t i = lane; i < 2 + 64; i += 64) sc.flags[i] = 0;
     __syncthreads();
     for (uint32_t i = lane; i < n_reads; i += 64) {
-        const uint32_t key = (reads[i].row << 5) | (reads[i].meta & 31u);
+        const OccRead r = reads[i];
+        sc.rmeta[i] = r.meta;
+        sc.rbound[i] = r.bound;
+        const uint32_t key = (r.row << 5) | (r.meta & 31u);
         uint32_t h = occ_hash(key);
         for (;;) {
             const uint32_t old = atomicCAS(&sc.hkey[h], kEmpty, key);
@@ -119,8 +129,9 @@ __device__ __forceinline__ void occ_build_hash(const OccScratch &sc, const OccRe
 template <int MODE, int T>
 __device__ __forceinline__ void occ_check_range(const GraphView &g, const WaveMem &m, const OccScratch &sc, const OccBufs &ob,
                                                 const OccRead *reads, const OccShr *shr, uint32_t q, uint32_t from,
-                                                uint32_t to, int lane, bool shrinks_only = false)
+                                                uint32_t to, int lane, bool shrinks_only = false, uint32_t own_base = kEmpty)
 {
+    (void)reads;
     if (to - from > (1u << kOccJournalBits) - 4096u) {      // the ring has wrapped past this plan: stale
         if (lane == 0) sc.flags[0] = 1;
         __syncthreads();
@@ -130,16 +141,18 @@ __device__ __forceinline__ void occ_check_range(const GraphView &g, const WaveMe
     for (uint32_t base = from; base < to; base += 64) {
         const uint32_t j = base + lane;
         if (j < to) {
-            const OccDelta d = ob.ring[j & ((1u << kOccJournalBits) - 1u)];
+            // the committing node's own entries are mirrored in LDS (own_base = journal index of own[0])
+            const OccDelta d = (j >= own_base && j - own_base < kOccOwn) ? sc.own[j - own_base]
+                                                                         : ob.ring[j & ((1u << kOccJournalBits) - 1u)];
             const uint32_t key = (d.row << 5) | (d.lc_add & 31u);
             const bool add = (d.lc_add & 256u) != 0;
             uint32_t h = occ_hash(key);
             while (sc.hkey[h] != kEmpty && sc.hkey[h] != key) h = (h + 1) & (kOccHash - 1);
             if (sc.hkey[h] == key) {
                 for (uint32_t i = sc.hhead[h]; i != kEmpty; i = sc.hnext[i]) {
-                    const OccRead r = reads[i];
-                    const uint32_t kind = (r.meta >> 5) & 3u, sub = (r.meta >> 7) & 63u;
-                    const bool full = (r.meta >> 13) & 1u;
+                    const uint32_t rm = sc.rmeta[i];
+                    const uint32_t kind = (rm >> 5) & 3u, sub = (rm >> 7) & 63u;
+                    const bool full = (rm >> 13) & 1u;
                     if (kind == OCC_SHRINK_ROW) {
                         if (d.z == q && add) continue;                   // this node's own connect
                         if (!sc.flags[2 + sub]) atomicAdd(&ob.ctl->n_rowstale, 1ull);
@@ -158,7 +171,7 @@ __device__ __forceinline__ void occ_check_range(const GraphView &g, const WaveMe
                     if (p < kOccMaxHits) {
                         sc.hits[3 * p] = kind == OCC_SHRINK_NB ? 1u + sub : 0u;
                         sc.hits[3 * p + 1] = d.z;
-                        sc.hits[3 * p + 2] = r.bound;
+                        sc.hits[3 * p + 2] = sc.rbound[i];
                     } else sc.flags[0] = 1;                              // too many to evaluate: treat as stale
                 }
             }
@@ -460,6 +473,8 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
     OccJournal jr;
     jr.ring = ob.ring;
     jr.n = ob.ctl->nJ;
+    jr.own = nullptr;
+    jr.own_base = 0;
     occ_init_hash(sc, lane);
     uint32_t head = ob.ctl->head;
     uint32_t stop = OCC_STOP_NONE;
@@ -496,6 +511,8 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
             stop = OCC_STOP_REPLAN;
             break;
         }
+        jr.own = sc.own;                                     // this node's deltas are mirrored in LDS from here on
+        jr.own_base = jr.n;
         const uint32_t lmax = g.hdr->max_layer;
         const uint32_t l = g.levels[id];
         const uint32_t top = sl->top;
@@ -537,7 +554,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
                 for (uint32_t t = 0; t < n_shr; ++t)
                     if (shr[t].e == e && shr[t].lc == lc && shr[t].nS != 0) k = (int)t;
                 if (k >= 0 && checked != jr.n) {
-                    occ_check_range<MODE, T>(g, m, sc, ob, reads, shr, id, checked, jr.n, lane, true);
+                    occ_check_range<MODE, T>(g, m, sc, ob, reads, shr, id, checked, jr.n, lane, true, jr.own_base);
                     checked = jr.n;
                 }
                 OCC_T(3);
