@@ -45,13 +45,17 @@ __device__ __forceinline__ uint32_t select_topm(const GraphView &g, const WaveMe
     // (core.rs:728-731 skips it when popping; HNSW.NODE.DEL passes the node being removed)
     uint32_t nS;
     {
-        const uint32_t take = ncand < mcap + 1 ? ncand : mcap + 1;
-        const bool in = (uint32_t)lane < take;
-        const uint64_t ck = in ? cand[lane] : ~0ull;
-        const uint64_t ign = __ballot(in && key_id(ck) == ignored);
-        const uint32_t dst = (uint32_t)lane - (uint32_t)__popcll(ign & lanemask_lt(lane));
-        if (in && !((ign >> lane) & 1ull) && dst < mcap) m.S[dst] = ck & ~1ull;
-        nS = take - (uint32_t)__popcll(ign);
+        const uint32_t take = ncand < mcap + 1 ? ncand : mcap + 1;     // up to 65 when m_max0 = 64 (M = 32)
+        nS = 0;
+        for (uint32_t base = 0; base < take; base += 64) {
+            const uint32_t i = base + (uint32_t)lane;
+            const bool in = i < take;
+            const uint64_t ck = in ? cand[i] : ~0ull;
+            const uint64_t ign = __ballot(in && key_id(ck) == ignored);
+            const uint32_t dst = nS + (uint32_t)lane - (uint32_t)__popcll(ign & lanemask_lt(lane));
+            if (in && !((ign >> lane) & 1ull) && dst < mcap) m.S[dst] = ck & ~1ull;
+            nS += (take - base < 64 ? take - base : 64) - (uint32_t)__popcll(ign);
+        }
         if (nS > mcap) nS = mcap;
     }
     __syncthreads();

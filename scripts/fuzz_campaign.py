@@ -1,0 +1,35 @@
+"""Run tests/test_gpu_fuzz.py's differential op sequences over many random configurations (GPU box).
+usage: python scripts/fuzz_campaign.py [seconds] [first_seed]"""
+import sys
+import time
+import traceback
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from oracle import oracle as oracle_mod
+from redis_hnsw_amd import index as eng
+from tests.test_gpu_fuzz import test_random_op_sequences_match_the_oracle as run
+
+oracle_mod.build()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+t0 = time.time()
+done = bad = 0
+while time.time() - t0 < budget:
+    rng = np.random.default_rng(seed)
+    kind = str(rng.choice(["uniform", "clustered", "line", "lattice", "dupes"]))
+    dim = int(rng.choice([4, 12, 32, 33, 64, 96, 100, 128, 256]))
+    m = int(rng.choice([2, 3, 4, 5, 8, 12, 16, 24, 31, 32]))
+    ef = int(rng.choice([m, m + 1, 16, 40, 100, 200, 300]))
+    ef = max(ef, 2)
+    case = (kind, dim, m, ef, int(rng.choice([40, 80, 120])), seed)
+    try:
+        run(eng, oracle_mod, *case)
+    except Exception as e:                                  # report and go on: one line per failing case
+        bad += 1
+        print("FAIL", case, type(e).__name__, str(e).split("\n")[0][:200], flush=True)
+        traceback.print_exc(limit=2)
+    done += 1
+    seed += 1
+print("cases %d, failures %d, %.0f s" % (done, bad, time.time() - t0))
