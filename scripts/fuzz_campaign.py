@@ -24,6 +24,15 @@ while time.time() - t0 < budget:
     ef = int(rng.choice([m, m + 1, 16, 40, 100, 200, 300]))
     ef = max(ef, 2)
     case = (kind, dim, m, ef, int(rng.choice([40, 80, 120])), seed)
+    tun = []
+    if rng.random() < 0.6:                                  # non-default engine paths, results must not change
+        for key, vals in (("occ_window", [2, 5, 16, 64]), ("occ_log_cap", [40, 300, 3072]), ("select_shortcut", [0, 1]),
+                          ("visited_bounded", [0, 1]), ("lean", [0, 1]), ("lds_hash_bits", [8, 10]),
+                          ("occ_min_batch", [2, 64]), ("occ_ahead_x10", [10, 30]), ("waves_per_cu", [1, 4, 8]),
+                          ("tag_table", [0, 1])):
+            if rng.random() < 0.4:
+                tun.append((key, int(rng.choice(vals))))
+    case = case + (tuple(tun),)
     try:
         run(eng, oracle_mod, *case)
     except Exception as e:                                  # report and go on: one line per failing case

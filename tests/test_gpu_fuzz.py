@@ -61,12 +61,14 @@ CASES = [
 
 
 @pytest.mark.parametrize("kind,dim,m,ef,n_ops,seed", CASES)
-def test_random_op_sequences_match_the_oracle(eng, oracle_mod, kind, dim, m, ef, n_ops, seed):
+def test_random_op_sequences_match_the_oracle(eng, oracle_mod, kind, dim, m, ef, n_ops, seed, tunings=()):
     rng = np.random.default_rng(seed)
     pool = _data(kind, 6000, dim, rng)
     used = 0
     o = oracle_mod.OracleIndex(dim, m, ef)
     gi = eng.Index("fz", dim, m, ef)
+    for key, val in tunings:                             # scripts/fuzz_campaign.py: non-default engine paths
+        gi.set_tuning(key, val)
     live = []
     level_seed = 100 + seed
 
@@ -133,6 +135,8 @@ def test_random_op_sequences_match_the_oracle(eng, oracle_mod, kind, dim, m, ef,
             gi.close()
             gi = eng.Index.deserialize(blob)
             assert dict(gi._ids) == names
+            for key, val in tunings:
+                gi.set_tuning(key, val)
         if op_i % 6 == 5:
             check_graph("after op %d" % op_i)
     check_graph("end")
