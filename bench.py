@@ -4,8 +4,12 @@
 
 A step = one pass of the hot path (hnsw_search_batch_device = one k_search launch) over one batch of
 1024 queries already resident in HBM.  Consecutive steps are issued round-robin on `--streams` HIP streams
-(default 2), so two batches are in flight at a time -- a lone 1024-query launch puts one wavefront on each
-SIMD, and a SIMD needs two to keep issuing.  One process per GPU; the index is
+(default 3), so three batches are in flight at a time: the chip holds 2048 queries (two wavefronts per SIMD --
+a lone 1024-query launch puts one on each, and a SIMD needs two to keep issuing), and
+the third batch is what the dispatcher backfills from while the first two drain their long queries.  Three
+streams need three hardware queues: the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES (default 4,
+shared with the null stream and the engine's own), and two streams on one queue serialise -- the bench asks
+for 8 before the runtime starts (measured: 3 streams 1.75 M QPS on 4 queues, 2.52 M on 8).  One process per GPU; the index is
 replicated, every rank serves its own batches (weak scaling) and the [B,k] results are all-gathered over
 RCCL.  Prints ONE JSON line on rank 0.
 
@@ -22,6 +26,8 @@ import json
 import os
 import sys
 import time
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # read by the HIP runtime when it starts (before torch is imported)
 
 import numpy as np
 
@@ -141,8 +147,10 @@ def main():
     ap.add_argument("--ef", type=int, default=200)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1024)
-    ap.add_argument("--streams", type=int, default=2, help="steps in flight (HIP streams used round-robin)")
+    ap.add_argument("--streams", type=int, default=3, help="steps in flight (HIP streams used round-robin)")
     ap.add_argument("--waves-per-cu", type=int, default=0, help="engine tuning waves_per_cu (0 = default 8)")
+    ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE",
+                    help="extra engine tuning for experiments (hnsw_set_tuning), repeatable")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clustered", action="store_true")
@@ -203,6 +211,9 @@ def main():
     index.set_tuning("launch_concurrency", S)
     if args.waves_per_cu:
         index.set_tuning("waves_per_cu", args.waves_per_cu)
+    for kv in args.tuning:
+        key, val = kv.split("=")
+        index.set_tuning(key, int(val))
     graph = None
     t_build = None
     graph_desc = {"reference": "reference-order (serial core.rs:489-599 order; fixture built by the CPU oracle, imported with hnsw_import)",
@@ -608,7 +619,8 @@ def main():
         "config": {"workload": "%s: %d nodes x dim %d, M=%d, ef=%d, k=%d, batch=%d queries/GPU, uniform[0,1) f32, replicated index"
                                % (cfg_name, N, dim, M, ef, k, B),
                    "nodes": N, "dim": dim, "M": M, "ef": ef, "k": k, "batch": B, "graph": mode, "graph_desc": graph_desc,
-                   "steps_in_flight": S, "prewarm_launches": PREWARM,
+                   "steps_in_flight": S, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                   "prewarm_launches": PREWARM,
                    "parallelism": "replica x%d, query batch sharded%s" % (
                        world, " (ranks share one device, gloo: functional check only)" if one_device and world > 1 else "")},
         "gather_verified": gather_ok,

@@ -93,6 +93,9 @@ def load():
         raise RuntimeError(
             f"{path} is missing: build it with `python -m redis_hnsw_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    # More than two search streams only overlap if each has a hardware queue of its own: the HIP runtime's
+    # default of 4 is shared with the null stream and the engine's stream (read once, when the runtime starts).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     _share_hip_runtime_with_torch()
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():

@@ -42,6 +42,12 @@ struct hnsw_index {
     uint32_t spill_gnb = 0, spill_slots = 0;
     hipEvent_t spill_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool spill_busy[4] = {false, false, false, false};
+    // the specialised search kernel uses no spill region: one "last search" event per caller stream instead
+    static constexpr uint32_t kSearchStreams = 16;
+    hipEvent_t search_ev[kSearchStreams] = {};
+    hipStream_t search_st[kSearchStreams] = {};
+    bool search_busy[kSearchStreams] = {};
+    uint32_t search_rr = 0;
     uint32_t spill_rr = 0;
     float *d_Q = nullptr;
     uint32_t *d_res = nullptr;       // [ids B*k][sims B*k][n_out B] of the host-buffer entry points
@@ -83,6 +89,7 @@ struct hnsw_index {
     bool bf16 = false;               // vectors are stored as bf16 (compress_bf16): read-only, dim 128, specialised kernel only
     bool select_shortcut = true;     // select_neighbors after search_level = the head of W (hnsw_insert.hpp); 0 = the full extension
     bool lean = true;                // dim-128 searches use the specialised kernel (hnsw_search_lean.hpp) when its preconditions hold
+    bool grid_stride = false;        // specialised kernel: cap the grid at the resident waves and walk the batch grid-stride (tuning, for comparison)
     bool visited_bounded = true;     // k_search: a full LDS visited table stops recording (exact results)
     uint32_t max_waves_per_cu = 8;
     uint32_t launch_concurrency = 1; // tuning: search launches the caller keeps in flight at once (sizes the LDS share)   // residency the LDS visited table is sized for (tuning: waves_per_cu)
@@ -383,11 +390,35 @@ hnsw_status spill_release(hnsw_index *h, hipStream_t st, uint32_t region)
     h->spill_busy[region] = true;
     return HNSW_OK;
 }
+// a search without a spill region: remember its stream's latest launch (one slot per distinct stream)
+hnsw_status note_search(hnsw_index *h, hipStream_t st)
+{
+    uint32_t slot = hnsw_index::kSearchStreams;
+    for (uint32_t i = 0; i < hnsw_index::kSearchStreams; ++i)
+        if (h->search_busy[i] && h->search_st[i] == st) { slot = i; break; }
+    if (slot == hnsw_index::kSearchStreams)
+        for (uint32_t i = 0; i < hnsw_index::kSearchStreams; ++i)
+            if (!h->search_busy[i]) { slot = i; break; }
+    if (slot == hnsw_index::kSearchStreams) {            // more distinct streams than slots: retire one
+        slot = h->search_rr++ % hnsw_index::kSearchStreams;
+        HIP_TRY(h, hipEventSynchronize(h->search_ev[slot]));
+    }
+    if (!h->search_ev[slot]) HIP_TRY(h, hipEventCreateWithFlags(&h->search_ev[slot], hipEventDisableTiming));
+    HIP_TRY(h, hipEventRecord(h->search_ev[slot], st));
+    h->search_st[slot] = st;
+    h->search_busy[slot] = true;
+    return HNSW_OK;
+}
 // an insert must not start while searches enqueued on other streams are still reading the graph
 hnsw_status wait_inflight_searches(hnsw_index *h)
 {
     for (uint32_t r = 0; r < kSpillRegions; ++r)
         if (h->spill_busy[r]) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->spill_ev[r], 0));
+    for (uint32_t i = 0; i < hnsw_index::kSearchStreams; ++i)
+        if (h->search_busy[i]) {
+            HIP_TRY(h, hipStreamWaitEvent(h->stream, h->search_ev[i], 0));
+            h->search_busy[i] = false;                   // ordered behind it from here on (h->stream is in order)
+        }
     return HNSW_OK;
 }
 
@@ -506,7 +537,9 @@ hnsw_status launch_lean_t(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k
         }
     }
     // as many blocks as the CUs hold at this table size; a larger batch is walked grid-stride
-    uint32_t grid = std::min(B, 256u * std::max(per_cu, 8u));
+    // one block per query: a batch larger than the chip holds queues in the dispatcher, which hands a new query to
+    // whichever slot frees first (queries differ in length by 2x; a grid-stride loop would fix the pairing up front)
+    uint32_t grid = h->grid_stride ? std::min(B, 256u * std::max(per_cu, 8u)) : B;
     if (h->grid_override > 0) grid = std::min<uint32_t>(grid, (uint32_t)h->grid_override);
     if (h->time_launches) HIP_TRY(h, hipEventRecord(h->ev0, st));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, st, view(h), dQ, B, k, h->efc, (1u << BB) * 6u, idbits, d_ids, d_sims,
@@ -516,9 +549,7 @@ hnsw_status launch_lean_t(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k
         HIP_TRY(h, hipEventRecord(h->ev1, st));
         h->ev_valid = true;
     }
-    // inserts wait for searches in flight through the spill-region events: keep that ordering
-    const uint32_t region = h->spill_rr++ % kSpillRegions;
-    return spill_release(h, st, region);
+    return note_search(h, st);                           // inserts wait for searches in flight
 }
 
 // returns HNSW_OK and sets *done when the specialised kernel was launched
@@ -719,6 +750,7 @@ void hnsw_destroy(hnsw_index *h)
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_sync) (void)hipEventDestroy(h->ev_sync);
     for (uint32_t r = 0; r < kSpillRegions; ++r) if (h->spill_ev[r]) (void)hipEventDestroy(h->spill_ev[r]);
+    for (uint32_t i = 0; i < hnsw_index::kSearchStreams; ++i) if (h->search_ev[i]) (void)hipEventDestroy(h->search_ev[i]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -769,6 +801,7 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
     if (!std::strcmp(key, "occ_log_cap")) { h->occ_log_cap = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), kOccMaxReads); return HNSW_OK; }
     if (!std::strcmp(key, "occ_min_batch")) { h->occ_min_batch = (uint32_t)std::max<int64_t>(value, 1); return HNSW_OK; }
     if (!std::strcmp(key, "lean")) { h->lean = value != 0; return HNSW_OK; }
+    if (!std::strcmp(key, "grid_stride")) { h->grid_stride = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "query_in_lds")) {     // dims 128 / 768 normally keep the query in registers (T = dim/32)
         if (h->mode == MODE_AVX) h->T = value ? 0 : ((h->dim == 128 || h->dim == 768) ? (int)(h->dim / 32) : 0);
         return HNSW_OK;

@@ -82,6 +82,7 @@ __device__ __forceinline__ bool tagset_visit(TagSet<BB, DB> &v, bool valid, uint
 template <int T>
 struct VecF32 {
     static constexpr int LPV = 8, SPR = 8, NR = 5;      // 5 rounds: a chunk is 40 ids (rows of 33-40 ids are 10 % of the expansions)
+    static constexpr int MIN_WAVES = 2;
     struct Q { float4 q[T]; };
     struct V { float4 v[T]; };
     static __device__ __forceinline__ void load_q(const float *src, Q &q, int lane)
@@ -109,6 +110,7 @@ struct VecF32 {
 template <int T>
 struct VecBF16 {
     static constexpr int LPV = 4, SPR = 16, NR = 3;     // a chunk is 48 ids
+    static constexpr int MIN_WAVES = 2;                 // per SIMD: the register budget the kernel is compiled for (3 spills: measured 0.6x)
     struct Q { f32x2 q[T][4]; };          // q[t][k] = elements 32t + 8a + 2k, +1
     struct V { uint4 x[T]; };
     static __device__ __forceinline__ void load_q(const float *src, Q &q, int lane)
@@ -314,7 +316,7 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
 
 // HNSW.SEARCH (core.rs:477-486 -> :865-892): one wave per query, grid-stride over the batch.
 template <class VEC, int R, int BB, int DB>
-__global__ __launch_bounds__(64) void k_search_lean(GraphView g, const float *__restrict__ Q, uint32_t B, uint32_t k,
+__global__ __launch_bounds__(64, VEC::MIN_WAVES) void k_search_lean(GraphView g, const float *__restrict__ Q, uint32_t B, uint32_t k,
                                                     uint32_t ef, uint32_t lcap, uint32_t idbits,
                                                     uint32_t *__restrict__ out_ids, float *__restrict__ out_sims,
                                                     uint32_t *__restrict__ out_n)
