@@ -114,7 +114,12 @@ hnsw_status hnsw_search_batch(hnsw_index *h, const float *Q, uint32_t B, uint32_
                               uint32_t k, uint32_t *ids, float *sims, uint32_t *n_out);
 
 /* Same, with every buffer already resident in HBM; enqueues on `stream`
- * (a hipStream_t, NULL = the null stream) and returns without synchronising. */
+ * (a hipStream_t, NULL = the null stream) and returns without synchronising.
+ * Throughput: keep three 1024-query calls in flight on three streams (a batch of 1024 fills half of
+ * the chip's 2048 wave slots; the third is what the dispatcher backfills from) and export
+ * GPU_MAX_HW_QUEUES=8 before the HIP runtime starts -- with the default of 4 hardware queues two of
+ * the streams share one and serialise.  Inserts and deletes wait for every search
+ * enqueued before them, whatever its stream.                                                       */
 hnsw_status hnsw_search_batch_device(hnsw_index *h, const float *dQ, uint32_t B,
                                      uint32_t dim, uint32_t k, uint32_t *d_ids,
                                      float *d_sims, uint32_t *d_n_out, void *stream);
@@ -150,7 +155,7 @@ hnsw_status hnsw_deserialize(const void *buf, uint64_t bytes, uint64_t seed, int
  *             "waves_per_cu" (residency the visited table is sized for, default 8), "visited_bounded"
  *             (1: a full LDS visited table stops recording -- exact results, distance evaluations may
  *             exceed the reference's; 0: the table continues in HBM -- counters equal the reference's),
- *             "lean" (specialised dim-128 kernel on/off), "query_in_lds", "time_launches",
+ *             "lean" (specialised dim-128 kernel on/off), "grid_stride", "query_in_lds", "time_launches",
  *             "lds_buckets" / "lds_hash_bits" / "tag_table" / "tag_bb" / "idbits" / "grid" (tests)
  *   build     "occ_window" (slots of the exact parallel insert, 0 = serial), "occ_min_batch",
  *             "occ_ahead_x10", "select_shortcut" (1: select_neighbors after search_level is the head
