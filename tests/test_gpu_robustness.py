@@ -296,3 +296,53 @@ def test_bf16_storage_mode_is_the_reference_on_rounded_vectors(eng, oracle_mod):
     with pytest.raises(eng.HNSWError):
         gi.delete_node("node3")
     gi.close()
+
+
+def test_inserts_wait_for_searches_in_flight_on_other_streams(eng, oracle_mod):
+    """hnsw_search_batch_device only enqueues; an insert / delete issued right behind searches that are still
+    running on OTHER streams must not change the graph under them.  Six streams (more than the runtime's
+    default hardware queues), large batches so that the searches are still running when the inserts are
+    issued: every search must equal the oracle's on the graph as it was when the search was enqueued."""
+    import torch
+    n, dim, m, ef, k, B = 6000, 128, 16, 200, 10, 3000
+    V = make_data(n + 400, dim, seed=31)
+    lv = oracle_mod.draw_levels(n + 400, m, 9)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch(V[:n], lv[:n])
+    gi = eng.Index("s", dim, m, ef)
+    gi.import_graph(o.export())
+    streams = [torch.cuda.Stream() for _ in range(6)]
+    gi.set_tuning("launch_concurrency", len(streams))
+    Q = make_data(B, dim, seed=32)
+    dQ = torch.from_numpy(Q).cuda()
+    torch.cuda.synchronize()
+    outs, wants = [], []
+    added = n
+    for rnd in range(4):
+        for st in streams:
+            ids = torch.empty((B, k), dtype=torch.int32, device="cuda")
+            sims = torch.empty((B, k), dtype=torch.float32, device="cuda")
+            nn = torch.empty(B, dtype=torch.int32, device="cuda")
+            gi.search_batch_device(dQ.data_ptr(), B, k, ids.data_ptr(), sims.data_ptr(), nn.data_ptr(), st.cuda_stream)
+            outs.append((ids, sims, nn, len(wants)))
+        wants.append(o.search_batch(Q, k, threads=8))                    # the graph these searches must see
+        # mutate right behind them: single adds, a windowed bulk add, a delete
+        for i in range(added, added + 3):
+            o.add(V[i], int(lv[i]))
+            gi.add_node("node%d" % i, V[i], level=int(lv[i]))
+        added += 3
+        o.add_batch(V[added:added + 80], lv[added:added + 80])
+        gi.add_batch(V[added:added + 80], levels=lv[added:added + 80], mode="exact")
+        added += 80
+        victim = 100 + rnd
+        o.delete(victim)
+        gi.delete_node("node%d" % victim)
+    torch.cuda.synchronize()
+    for ids, sims, nn, w in outs:
+        oids, osims, on, _ = wants[w]
+        assert np.array_equal(nn.cpu().numpy().astype(np.uint32), on)
+        assert np.array_equal(ids.cpu().numpy().view(np.uint32), oids)
+        assert np.array_equal(_bits(sims.cpu().numpy()), _bits(osims))
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    gi.close()
