@@ -881,7 +881,6 @@ hnsw_status hnsw_add_batch(hnsw_index *h, const float *V, uint32_t n, uint32_t d
     // ---- fast build ---------------------------------------------------------
     h->asymmetric = true;
     const uint32_t first = h->n, rest = n - done;
-    if (std::max(h->stride0, h->strideU) > 129) return fail(h, HNSW_ERR_INVALID, "fast build needs row strides <= 129");
     std::vector<uint32_t> lv(rest);
     for (uint32_t i = 0; i < rest; ++i) {
         uint32_t l = levels ? (levels[done + i] >= 0 ? (uint32_t)levels[done + i] : draw_level(h)) : draw_level(h);
