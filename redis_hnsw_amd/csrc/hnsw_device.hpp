@@ -621,9 +621,11 @@ __device__ __forceinline__ void carve(unsigned char *smem, uint32_t dim, uint32_
 }
 
 // One entry of a plan's read log (hnsw_occ.hpp: exact-order parallel insert).  A plan stays valid as long as
-// no row it read changed in a way that matters: `bound` = the distance bits of the accept threshold that was
-// in force when the row was read (W's furthest for a search_level expansion, core.rs:657; the last selected
-// for select_neighbors, core.rs:724-754), `full` clear = everything mattered (W / the selection not full yet).
+// no row it read changed in a way that matters: an id z added to / removed from the row matters iff
+// dist(reader, z) <= `bound` (distance bits); `full` clear = everything matters.
+//   select_neighbors (core.rs:724-754): bound = the last selected candidate.
+//   search_level expansion (core.rs:630-668): bound = max(W's final furthest, the furthest candidate popped
+//   AFTER this expansion) -- occ_finalize_search_log, where the argument is written out.
 struct OccRead {
     uint32_t row;
     uint32_t meta;      // layer [0,5) | kind [5,7) | sub-operation [7,13) | full [13]
@@ -643,6 +645,52 @@ struct WorkCtr {
     unsigned long long ph[8];
 #endif
 };
+// The threshold of a search_level read.  W(t) is always the ef nearest of everything evaluated so far, and the
+// loop pops the nearest unexpanded member, stopping at the first pop farther than W's furthest (core.rs:635).
+// Take an id z that appears in (or vanishes from) a row expanded at time t, with
+//        dist(q, z) > T := max( W's furthest at the end, every candidate popped after t ).
+// Present, z can enter W and the candidate heap for a while (the accept threshold of the moment may be far
+// looser than T -- it is infinite until W fills), but: every later pop is nearer than z, so z is never the
+// nearest unexpanded candidate before the loop ends, hence never expanded; the members it displaces from W,
+// and the ones that its presence keeps from being accepted, are all farther than z, so none of them is ever
+// popped either; the stop test compares pops (nearer than z) with a furthest that is >= dist(z) while z is in
+// W and unchanged once z has been pushed out; and at the end the nearest unexpanded candidate, z or the
+// original one, is farther than the final furthest, which z is not part of.  Pops, expansions and the final W
+// are the same with and without z.  With dist(q, z) <= T nothing is claimed: the plan is redone.
+// The accept threshold at time t (what the log carried before) is >= T: this bound is never looser, and for the
+// rows expanded while W is still filling -- the hubs every search passes through -- it replaces "everything
+// matters" by roughly the ef-th neighbour's distance.
+// Entries [log_start, ctr.log_n) were written by lane 0 with the popped candidate's distance as `bound`.
+__device__ __forceinline__ void occ_finalize_search_log(WorkCtr &ctr, uint32_t log_start, uint32_t lc, uint64_t worst, int lane)
+{
+    if (!ctr.log) return;
+    const uint32_t end = ctr.log_n < ctr.log_cap ? ctr.log_n : ctr.log_cap;
+    if (end <= log_start) return;
+    fence_own_writes();                                   // lane 0's entries, read back by all lanes
+    const bool full = worst != ~0ull;
+    uint32_t running = (uint32_t)(worst >> 32);           // all ones while W never filled: everything matters
+    const uint32_t meta = occ_meta(lc, OCC_SEARCH, 0, full);
+    for (uint32_t hi = end; hi > log_start;) {
+        const uint32_t n = hi - log_start < 64u ? hi - log_start : 64u;
+        const bool on = (uint32_t)lane < n;
+        const uint32_t idx = hi - 1u - (uint32_t)lane;    // lane 0 = the latest expansion of this chunk
+        const uint32_t pop = on ? ctr.log[idx].bound : 0u;
+        uint32_t incl = pop;                              // max over lanes <= this one (= this and later expansions)
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+            if (lane >= d && o > incl) incl = o;
+        }
+        uint32_t excl = (uint32_t)__shfl_up((int)incl, 1, 64);
+        if (lane == 0) excl = 0u;
+        const uint32_t t = running > excl ? running : excl;
+        if (on) { ctr.log[idx].bound = t; ctr.log[idx].meta = meta; }
+        const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (all > running) running = all;
+        hi -= n;
+    }
+}
+
 #ifdef HNSW_PHASE_TIMERS
 #define PH_T0() unsigned long long ph_t_ = __builtin_readcyclecounter()
 #define PH_MARK(ctr, i)                                              \
@@ -682,6 +730,7 @@ __device__ __forceinline__ uint32_t search_level_v1(const GraphView &g, const Wa
     __syncthreads();
     const uint32_t stride = lc ? g.strideU : g.stride0;
 
+    const uint32_t log_start = ctr.log_n;
     PH_T0();
     for (;;) {
         const int pos = find_unexpanded<R>(m.W, nW, lane); // core.rs:631
@@ -727,8 +776,9 @@ __device__ __forceinline__ uint32_t search_level_v1(const GraphView &g, const Wa
         __syncthreads();
         // read log: the accept threshold once this row's keys are in (what a later change of the row is judged by)
         if (ctr.log && lane == 0 && log_idx < ctr.log_cap)
-            ctr.log[log_idx] = OccRead{c, occ_meta(lc, OCC_SEARCH, 0, nW == ef), nW == ef ? (uint32_t)(m.W[ef - 1] >> 32) : 0u};
+            ctr.log[log_idx] = OccRead{c, occ_meta(lc, OCC_SEARCH, 0, false), (uint32_t)(ckey >> 32)};
     }
+    occ_finalize_search_log(ctr, log_start, lc, nW == ef ? m.W[ef - 1] : ~0ull, lane);
     return nW;
 }
 
@@ -958,14 +1008,7 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
     uint32_t pup[R], ppos = 0;     // its ranks, computed under the row-fetch latency
 #pragma unroll
     for (int r = 0; r < R; ++r) pup[r] = 0;
-    uint32_t log_cur = kEmpty, log_prev = kEmpty;     // read-log entries of this / the previous expansion
-#define OCC_PATCH_BOUND(idx)                                                                         \
-    do {                                                                                             \
-        if (ctr.log && (idx) < ctr.log_cap && lane == 0) {                                           \
-            ctr.log[idx].bound = (uint32_t)(worst >> 32);                                            \
-            ctr.log[idx].meta = occ_meta(lc, OCC_SEARCH, 0, worst != ~0ull);                         \
-        }                                                                                            \
-    } while (0)
+    const uint32_t log_start = ctr.log_n;             // read log of this call (occ_finalize_search_log)
     __syncthreads();
     PH_T0();
 
@@ -973,15 +1016,9 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
         // ckey is the candidate being expanded (already marked), `word` its adjacency row (core.rs:631-645)
         ctr.n_expand += 1;
         if (ctr.log) {
-            // Read log.  The entry of an expansion must carry the accept threshold as it is once that
-            // expansion's keys are merged -- and those are merged one expansion later (pending keys).  So the
-            // entry is written with the current (older = farther = still sound) threshold and patched when its
-            // keys go in; an expansion that accepted nothing leaves the threshold as it is.
-            log_prev = log_cur;
-            if (log_prev != kEmpty && !__ballot(ptake)) OCC_PATCH_BOUND(log_prev);
-            log_cur = ctr.log_n;
+            // read log: the expanded row and, for now, the popped candidate's distance (thresholds at the end)
             if (lane == 0 && ctr.log_n < ctr.log_cap)
-                ctr.log[ctr.log_n] = OccRead{key_id(ckey), occ_meta(lc, OCC_SEARCH, 0, worst != ~0ull), (uint32_t)(worst >> 32)};
+                ctr.log[ctr.log_n] = OccRead{key_id(ckey), occ_meta(lc, OCC_SEARCH, 0, false), (uint32_t)(ckey >> 32)};
             ctr.log_n += 1;
         }
         uint32_t cnt = __builtin_amdgcn_readfirstlane(word);
@@ -1054,7 +1091,6 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
                     if (r0 == 0 && __ballot(ptake)) {      // deferred scatter, under the loads just issued
                         nW = merge_apply<R>(w, m.W, nW, ef, pkey, ptake, pup, ppos, lane, &worst);
                         ptake = false;
-                        OCC_PATCH_BOUND(log_prev);
                         PH_MARK(ctr, 3);
                     }
                 });
@@ -1111,8 +1147,7 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
                             if (__ballot(ptake)) {      // deferred scatter of the previous expansion's keys
                                 nW = merge_apply<R>(w, m.W, nW, ef, pkey, ptake, pup, ppos, lane, &worst);
                                 ptake = false;
-                                OCC_PATCH_BOUND(log_prev);
-                                PH_MARK(ctr, 3);
+                                        PH_MARK(ctr, 3);
                             }
                             // W is complete now: its first unexpanded entry is known before the
                             // distances are (one scan less between the vectors and the next row request)
@@ -1158,7 +1193,6 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
             if (__ballot(ptake)) {
                 nW = merge_apply<R>(w, m.W, nW, ef, pkey, ptake, pup, ppos, lane, &worst);
                 ptake = false;
-                OCC_PATCH_BOUND(log_prev);
             }
             int r2, l2;
             have_next = first_unexpanded<R>(w, nkey, r2, l2);
@@ -1184,8 +1218,7 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
     }
     // the last expansion's keys were never ranked (the loop ended before that point)
     if (__ballot(ptake)) nW = merge_regs<R>(w, m.W, nW, ef, pkey, ptake, lane, &worst);
-    if (log_cur != kEmpty) OCC_PATCH_BOUND(log_cur);      // the last expansion's keys are in now
-#undef OCC_PATCH_BOUND
+    occ_finalize_search_log(ctr, log_start, lc, worst, lane);
     // leave W in LDS for the callers (top-k output, select_neighbors)
 #pragma unroll
     for (int r = 0; r < R; ++r) m.W[r * 64 + lane] = w[r];

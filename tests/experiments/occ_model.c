@@ -36,7 +36,7 @@ static void jpush(uint32_t row, uint32_t lc, uint32_t z, int add)
     J[nJ++] = (delta){row, lc, z, add};
 }
 
-static uint64_t why[2][2][2]; static int g_count_why; static int g_refine = 1;
+static uint64_t why[2][2][2]; static int g_count_why; static int g_refine = 1; static int g_tight = 1;
 enum { RK_SEARCH = 0, RK_SELECT = 1, RK_SHRINK_NB = 2, RK_SHRINK_ROW = 3 };
 typedef struct { uint32_t row, lc; simpair bound; int full, kind, sub; int32_t t; } rd;
 typedef struct { uint32_t lc, e; simpair S[64]; uint32_t nS; int valid; } shr;
@@ -86,6 +86,7 @@ static void search_level_log(const hnsw_oracle *o, scratch *s, const float *quer
     heap *C = &s->C, *W = &s->W;
     heap_clear(C); heap_clear(W);
     heap_push(C, qpair); heap_push(W, qpair);
+    const uint32_t log_start = t->nr;
     while (C->n) {
         simpair c = heap_pop(C);
         simpair f = heap_peek(W);
@@ -100,7 +101,21 @@ static void search_level_log(const hnsw_oracle *o, scratch *s, const float *quer
             simpair ep2 = { hnsw_oracle_euclidean(query, vec(o, e), o->dim), e };
             if (nearer(ep2, f) || W->n < ef) { heap_push(C, ep2); heap_push(W, ep2); if (W->n > ef) heap_pop(W); }
         }
-        rd_push(t, c.id, level, heap_peek(W), W->n >= ef, RK_SEARCH, 0);
+        /* g_tight: the popped candidate for now (thresholds in the backward pass below); else the accept
+           threshold of the moment (the rule of the first version) */
+        if (g_tight) rd_push(t, c.id, level, c, 0, RK_SEARCH, 0);
+        else rd_push(t, c.id, level, heap_peek(W), W->n >= ef, RK_SEARCH, 0);
+    }
+    if (g_tight) {
+        /* bound of an expansion = the farther of W's final furthest and every candidate popped after it
+           (hnsw_device.hpp, occ_finalize_search_log) */
+        int full = W->n >= ef;
+        simpair running = heap_peek(W);
+        for (uint32_t j = t->nr; j-- > log_start;) {
+            simpair pop = t->r[j].bound;
+            t->r[j].bound = running; t->r[j].full = full;
+            if (nearer(running, pop)) running = pop;
+        }
     }
 }
 
@@ -272,6 +287,7 @@ int main(int argc, char **argv)
     uint32_t N0 = argc > 1 ? atoi(argv[1]) : 20000, K = argc > 2 ? atoi(argv[2]) : 2048, Wn = argc > 3 ? atoi(argv[3]) : 64;
     uint32_t dim = argc > 4 ? atoi(argv[4]) : 128, M = argc > 5 ? atoi(argv[5]) : 16, ef = argc > 6 ? atoi(argv[6]) : 200;
     if (getenv("NOREFINE")) g_refine = 0;
+    if (getenv("LOOSE")) g_tight = 0;            /* the first version's rule: accept threshold at expansion time */
     hnsw_oracle *A = hnsw_oracle_new(dim, M, ef, 7);
     uint32_t total = N0 + K;
     float *V = malloc((size_t)total * dim * 4);
