@@ -61,6 +61,95 @@ __device__ __forceinline__ uint32_t select_topm(const GraphView &g, const WaveMe
     __syncthreads();
 
     const uint32_t stride = lc ? g.strideU : g.stride0;
+    if constexpr (MODE == MODE_AVX) {
+        // The pool is a set (core.rs:699-721 evaluates every unvisited neighbour of every candidate, whatever the
+        // order) and the result its mcap nearest: the rows are fetched eight candidates at a time, their unvisited
+        // ids queue up in LDS (fresh[64] + dsc[64], adjacent and unused on this path), and distances are evaluated
+        // 64 ids at a time -- full rounds of eight vectors instead of one short pass per candidate.
+        uint32_t *queue = m.fresh;
+        uint32_t qn = 0;
+        const int grp = lane >> 3, pp = piece_of_lane(lane), sub = lane & 7;
+        const float4 *vec4 = reinterpret_cast<const float4 *>(g.vec);
+        const uint32_t row4 = g.dim >> 2;
+        auto evaluate = [&](uint32_t count) {               // the first `count` (<= 64) ids of the queue
+            const uint32_t safe_id = queue[0];
+            for (uint32_t pass = 0; pass * 32 < count; ++pass) {
+                constexpr int RB = (T <= 4) ? 4 : (T <= 8 ? 2 : 1);
+                uint64_t key = ~0ull;
+                bool have = false;
+#pragma unroll
+                for (int r0 = 0; r0 < 4; r0 += RB) {
+                    uint32_t idr[RB];
+                    bool live[RB];
+#pragma unroll
+                    for (int rr = 0; rr < RB; ++rr) {
+                        const uint32_t slot = pass * 32 + (uint32_t)((r0 + rr) * 8 + grp);
+                        live[rr] = slot < count;
+                        idr[rr] = live[rr] ? queue[slot] : safe_id;
+                    }
+                    float dd[RB];
+                    dist_rounds<T, RB>(vec4, row4, idr, qr, m.qlds, pp, dd, [] {});   // core.rs:711
+#pragma unroll
+                    for (int rr = 0; rr < RB; ++rr)
+                        if (sub == r0 + rr && live[rr]) { key = pack_key(dd[rr], idr[rr]); have = true; }
+                }
+                const uint64_t worst = nS == mcap ? m.S[mcap - 1] : ~0ull;
+                nS = merge_sorted<1>(m.S, nS, mcap, key, have && key < worst, lane);   // core.rs:717
+            }
+        };
+        auto drain = [&](uint32_t keep_below) {             // evaluate blocks of 64 until fewer than keep_below wait
+            while (qn >= keep_below && qn) {
+                const uint32_t n = qn < 64u ? qn : 64u;
+                __syncthreads();
+                evaluate(n);
+                __syncthreads();
+                const uint32_t rest = qn - n;                // < 64
+                const uint32_t mv = (uint32_t)lane < rest ? queue[n + lane] : 0u;
+                __syncthreads();
+                if ((uint32_t)lane < rest) queue[lane] = mv;
+                qn = rest;
+            }
+        };
+        constexpr uint32_t G = 8;
+        for (uint32_t c0 = 0; c0 < ncand; c0 += G) {          // core.rs:699-700 (the order does not matter, see above)
+            uint32_t wordp[G];
+#pragma unroll
+            for (uint32_t j = 0; j < G; ++j) {
+                wordp[j] = 0u;
+                if (c0 + j < ncand) {
+                    const uint32_t *rj = row_ptr(g, key_id(cand[c0 + j]), lc);
+                    wordp[j] = (uint32_t)lane < stride ? rj[lane] : 0u;
+                }
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < G; ++j) {
+                if (c0 + j >= ncand) break;
+                const uint32_t *row = row_ptr(g, key_id(cand[c0 + j]), lc);
+                uint32_t word = wordp[j];
+                uint32_t cnt = __builtin_amdgcn_readfirstlane(word);
+                if (cnt > stride - 1) cnt = stride - 1;
+                ctr.n_ids += cnt;
+                for (uint32_t wbase = 0; wbase <= cnt; wbase += 64) { // core.rs:702
+                    const uint32_t wi = wbase + lane;
+                    if (wbase) word = wi < stride ? row[wi] : 0u;
+                    const bool valid = wi >= 1 && wi <= cnt && word != qid && word != ignored; // core.rs:704-708
+                    if (!visited_reserve(vis, lane, nullptr)) { fail = true; return 0; }
+                    const bool fresh = visited_insert_wave(vis, valid, word, lane, nullptr);  // core.rs:710,718
+                    const uint64_t fm = __ballot(fresh);
+                    const uint32_t nf = __popcll(fm);
+                    if (nf == 0) continue;
+                    vis.count += nf;
+                    ctr.n_dist += nf;
+                    if (fresh) queue[qn + (uint32_t)__popcll(fm & lanemask_lt(lane))] = word;   // qn < 64 here
+                    qn += nf;
+                    drain(64);
+                }
+            }
+        }
+        drain(1);
+        __syncthreads();
+        return nS;
+    }
     // software prefetch: the next candidate's row is requested before the
     // current one's distances are computed
     uint32_t word_next = 0;
@@ -90,52 +179,14 @@ __device__ __forceinline__ uint32_t select_topm(const GraphView &g, const WaveMe
             if (nf == 0) continue;
             vis.count += nf;
             ctr.n_dist += nf;
-            if constexpr (MODE == MODE_AVX) {
-                // same gather as search_level_v2: ids reach the 8-lane groups with ds_bpermute, the
-                // four rounds of a pass are one straight-line block, keys stay in their owning lane
-                const int grp = lane >> 3, pp = piece_of_lane(lane), sub = lane & 7;
-                const float4 *vec4 = reinterpret_cast<const float4 *>(g.vec);
-                const uint32_t row4 = g.dim >> 2;
-                const int shift = wbase ? 0 : 1;
-                const uint64_t fms = fm >> shift;
-                const uint32_t safe_id =
-                    (uint32_t)__builtin_amdgcn_readlane((int)word, __ffsll((unsigned long long)fm) - 1);
-                for (int pass = 0; pass < 2; ++pass) {
-                    const uint32_t pm = (uint32_t)(fms >> (32 * pass));
-                    if (pm == 0) continue;
-                    constexpr int RB = (T <= 4) ? 4 : (T <= 8 ? 2 : 1);
-                    uint64_t key = ~0ull;
-                    bool have = false;
-#pragma unroll
-                    for (int r0 = 0; r0 < 4; r0 += RB) {
-                        uint32_t idr[RB];
-#pragma unroll
-                        for (int rr = 0; rr < RB; ++rr) {
-                            const int r = r0 + rr;
-                            const uint32_t got = bperm(word, (pass * 32 + r * 8 + grp + shift) & 63);
-                            idr[rr] = ((pm >> (r * 8 + grp)) & 1u) ? got : safe_id;
-                        }
-                        float dd[RB];
-                        dist_rounds<T, RB>(vec4, row4, idr, qr, m.qlds, pp, dd, [] {});   // core.rs:711
-#pragma unroll
-                        for (int rr = 0; rr < RB; ++rr) {
-                            const int r = r0 + rr;
-                            if (sub == r && ((pm >> (r * 8 + grp)) & 1u)) { key = pack_key(dd[rr], idr[rr]); have = true; }
-                        }
-                    }
-                    const uint64_t worst = nS == mcap ? m.S[mcap - 1] : ~0ull;
-                    nS = merge_sorted<1>(m.S, nS, mcap, key, have && key < worst, lane);   // core.rs:717
-                }
-            } else {
-                if (fresh) m.fresh[__popcll(fm & lanemask_lt(lane))] = word;
-                __syncthreads();
-                compute_dists<MODE, T>(g, qr, m, nf, lane);      // core.rs:711
-                __syncthreads();
-                const bool have = (uint32_t)lane < nf;
-                const uint64_t key = have ? pack_key(m.dsc[lane], m.fresh[lane]) : ~0ull;
-                const uint64_t worst = nS == mcap ? m.S[mcap - 1] : ~0ull;
-                nS = merge_sorted<1>(m.S, nS, mcap, key, have && key < worst, lane); // core.rs:717
-            }
+            if (fresh) m.fresh[__popcll(fm & lanemask_lt(lane))] = word;
+            __syncthreads();
+            compute_dists<MODE, T>(g, qr, m, nf, lane);      // core.rs:711
+            __syncthreads();
+            const bool have = (uint32_t)lane < nf;
+            const uint64_t key = have ? pack_key(m.dsc[lane], m.fresh[lane]) : ~0ull;
+            const uint64_t worst = nS == mcap ? m.S[mcap - 1] : ~0ull;
+            nS = merge_sorted<1>(m.S, nS, mcap, key, have && key < worst, lane); // core.rs:717
         }
     }
     __syncthreads();
