@@ -73,6 +73,28 @@ __device__ __forceinline__ uint32_t select_topm(const GraphView &g, const WaveMe
         const uint32_t row4 = g.dim >> 2;
         auto evaluate = [&](uint32_t count) {               // the first `count` (<= 64) ids of the queue
             const uint32_t safe_id = queue[0];
+            if constexpr (T > 0 && T <= 4) {
+                // all eight rounds of eight vectors in flight at once (128 VGPRs at dim 128): one memory latency
+                // and one merge per 64 ids; lane (grp, sub) ends up with the key of slot sub * 8 + grp
+                uint32_t idr[8];
+                bool live[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const uint32_t slot = (uint32_t)(r * 8 + grp);
+                    live[r] = slot < count;
+                    idr[r] = live[r] ? queue[slot] : safe_id;
+                }
+                float dd[8];
+                dist_rounds<T, 8>(vec4, row4, idr, qr, m.qlds, pp, dd, [] {});       // core.rs:711
+                uint64_t key = ~0ull;
+                bool have = false;
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    if (sub == r && live[r]) { key = pack_key(dd[r], idr[r]); have = true; }
+                const uint64_t worst = nS == mcap ? m.S[mcap - 1] : ~0ull;
+                nS = merge_sorted<1>(m.S, nS, mcap, key, have && key < worst, lane);   // core.rs:717
+                return;
+            }
             for (uint32_t pass = 0; pass * 32 < count; ++pass) {
                 constexpr int RB = (T <= 4) ? 4 : (T <= 8 ? 2 : 1);
                 uint64_t key = ~0ull;
