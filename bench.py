@@ -441,6 +441,20 @@ def main():
                           note="hnsw_add_batch mode 1 (batched GPU build, BASELINE config 5): not the reference's insert order")
         ifast.close()
         log("fast GPU build: %.2f s, recall@10 %.4f" % (tfb, fast_build["recall_at_10"]))
+    exact_build = None
+    if cfg_is_c2 and extras and world == 1:
+        # the reference-order build (hnsw_add_batch mode 0: plans in parallel, validated in-order commits) on a
+        # bounded prefix; the full 1 M build and its row-for-row identity check are scripts/exact_build_check.py
+        NE = 50_000
+        ie = Index("bench-exact", dim, M, ef, device=local_rank)
+        te = time.time()
+        ie.add_batch(V[:NE], levels=levels[:NE], mode="exact")
+        te = time.time() - te
+        exact_build = dict(nodes=NE, build_seconds=round(te, 2), inserts_per_s=round(NE / te, 1),
+                           note="hnsw_add_batch mode 0 on the first 50 k nodes (the rate grows with the index: 3.8 k/s over "
+                                "the whole 1 M build, profiles/r2_c5_exact_build_1m.json, graph identical to the CPU oracle's)")
+        ie.close()
+        log("exact GPU build of %d nodes: %.1f s" % (NE, te))
     if cfg_is_c2 and extras and not args.no_clustered:
         centers = np.random.default_rng(3).random((64, dim), dtype=np.float32)
         Vc = clustered(N, dim, 3, centers)
@@ -633,7 +647,7 @@ def main():
         "recall_at_%d" % k: None if recall is None else round(recall, 4),
         "build_seconds": None if t_build is None else round(t_build, 2),
         "host_buffers_qps": round(host_qps, 1),
-        "gpu_fast_build": fast_build,
+        "gpu_fast_build": fast_build, "gpu_exact_build": exact_build,
         "clustered": clus,
         "bf16_storage_mode": bf16,
         "c1_single_query": c1,
