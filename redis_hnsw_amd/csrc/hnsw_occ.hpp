@@ -103,10 +103,13 @@ __device__ __forceinline__ void occ_clear_hash(const OccScratch &sc, uint32_t n_
     for (uint32_t i = lane; i < n_reads; i += 64) { const uint32_t h = sc.hslot[i]; sc.hkey[h] = kEmpty; sc.hhead[h] = kEmpty; }
     __syncthreads();
 }
-__device__ __forceinline__ void occ_build_hash(const OccScratch &sc, const OccRead *reads, uint32_t n_reads, int lane)
+__device__ __forceinline__ void occ_build_hash(const OccScratch &sc, const OccRead *reads, uint32_t n_reads, const OccShr *shr,
+                                               uint32_t n_shr, int lane)
 {
     for (uint32_t i = lane; i < 2 + 64; i += 64) sc.flags[i] = 0;
     __syncthreads();
+    // the shrinks' rows, for the chain walk: flags[2 + kOccMaxShr + sub] = shr[sub].e
+    if ((uint32_t)lane < n_shr && (uint32_t)lane < kOccMaxShr) sc.flags[2 + kOccMaxShr + lane] = shr[lane].e;
     for (uint32_t i = lane; i < n_reads; i += 64) {
         const OccRead r = reads[i];
         sc.rmeta[i] = r.meta;
@@ -160,7 +163,7 @@ __device__ __forceinline__ void occ_check_range(const GraphView &g, const WaveMe
                         continue;
                     }
                     if (kind == OCC_SHRINK_NB) {
-                        if (d.z == shr[sub].e || d.z == q) continue;     // e is excluded (core.rs:704); q is in econn already
+                        if (d.z == sc.flags[2 + kOccMaxShr + sub] || d.z == q) continue;   // e is excluded (core.rs:704); q is in econn already
                         if (sc.flags[2 + sub]) continue;
                         if (!full) { sc.flags[2 + sub] = 1; continue; }
                     } else {
@@ -198,7 +201,7 @@ __device__ __forceinline__ void occ_check_range(const GraphView &g, const WaveMe
             const uint32_t idx = (uint32_t)__popcll(sm & lanemask_lt(lane));
             __syncthreads();
             if (sel) m.fresh[idx] = z;
-            const uint32_t rid = rd ? shr[rd - 1].e : q;
+            const uint32_t rid = rd ? sc.flags[2 + kOccMaxShr + rd - 1] : q;
             QReg<T> qr;
             load_query<MODE, T>(g.vec + (size_t)rid * g.dim, g.dim, qr, m.qlds, lane);
             __syncthreads();
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_validate(GraphView g, OccBufs ob,
     const OccRead *reads = ob.reads + (size_t)(id % ob.W) * kOccMaxReads;
     const OccShr *shr = ob.shr + (size_t)(id % ob.W) * kOccMaxShr;
     occ_init_hash(sc, lane);
-    occ_build_hash(sc, reads, sl->n_reads, lane);
+    occ_build_hash(sc, reads, sl->n_reads, shr, sl->n_shr, lane);
     occ_check_range<MODE, T>(g, m, sc, ob, reads, shr, id, sl->snap, nJ, lane);
     bool bad = sc.flags[0] != 0;
     for (uint32_t k = 0; k < sl->n_shr; ++k) bad |= sc.flags[2 + k] != 0;
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
         const OccShr *shr = ob.shr + (size_t)slot * kOccMaxShr;
         const uint32_t n_shr = sl->n_shr;
         OCC_T(6);
-        occ_build_hash(sc, reads, sl->n_reads, lane);
+        occ_build_hash(sc, reads, sl->n_reads, shr, n_shr, lane);
         OCC_T(0);
         uint32_t checked = sl->snap;
         occ_check_range<MODE, T>(g, m, sc, ob, reads, shr, id, checked, jr.n, lane);
@@ -551,8 +554,11 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
                 if (cnt <= mmax) continue;                  // :561
                 // the speculative result, if nothing relevant happened since it was planned
                 int k = -1;
-                for (uint32_t t = 0; t < n_shr; ++t)
-                    if (shr[t].e == e && shr[t].lc == lc && shr[t].nS != 0) k = (int)t;
+                {
+                    const bool mine = (uint32_t)lane < n_shr && shr[lane].e == e && shr[lane].lc == lc && shr[lane].nS != 0;
+                    const uint64_t mb = __ballot(mine);
+                    if (mb) k = 63 - __builtin_clzll((unsigned long long)mb);
+                }
                 if (k >= 0 && checked != jr.n) {
                     occ_check_range<MODE, T>(g, m, sc, ob, reads, shr, id, checked, jr.n, lane, true, jr.own_base);
                     checked = jr.n;
