@@ -365,8 +365,23 @@ __device__ __forceinline__ void update_connections(const GraphView &g, const Wav
             dm &= dm - 1;
             const uint32_t xj = (uint32_t)__builtin_amdgcn_readlane((int)x, j);
             uint32_t *xrow = row_ptr(g, xj, lc);
-            uint32_t xc = xrow[0];
-            if (xc > stride - 1) xc = stride - 1;
+            // the first 64 words in one load (lane 0 = the count): rows of <= 63 ids need nothing else, one round
+            // trip instead of two
+            const uint32_t wx = (uint32_t)lane < stride ? xrow[lane] : kEmpty;
+            uint32_t xc1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wx);
+            if (xc1 > stride - 1) xc1 = stride - 1;
+            if (xc1 <= 63) {
+                const uint64_t hit = __ballot(lane >= 1 && (uint32_t)lane <= xc1 && wx == e);
+                if (!hit) { if (lane == 0) atomicOr(&g.hdr->status, ST_ASYMMETRIC); }      // reference panics, :150
+                else {
+                    const int pos = __ffsll((unsigned long long)hit) - 1;                  // word index of e
+                    const uint32_t nxt = (uint32_t)__shfl_down((int)wx, 1, 64);             // word lane + 1
+                    if (lane >= pos && (uint32_t)lane < xc1) xrow[lane] = nxt;
+                    if (lane == 0) xrow[0] = xc1 - 1;
+                }
+                continue;
+            }
+            const uint32_t xc = xc1;
             bool found = false;
             for (uint32_t b2 = 0; b2 < xc; b2 += 64) {          // rows wider than 63 ids: more than one pass
                 const uint32_t p = b2 + lane;
@@ -404,8 +419,18 @@ __device__ __forceinline__ void update_connections(const GraphView &g, const Wav
             am &= am - 1;
             const uint32_t xj = (uint32_t)__builtin_amdgcn_readlane((int)x, j);
             uint32_t *xrow = row_ptr(g, xj, lc);
-            uint32_t xc = xrow[0];
-            if (xc > stride - 1) xc = stride - 1;
+            const uint32_t wx = (uint32_t)lane < stride ? xrow[lane] : kEmpty;
+            uint32_t xc1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wx);
+            if (xc1 > stride - 1) xc1 = stride - 1;
+            if (xc1 < 63) {                                         // the row and the appended slot are words 0..63
+                const bool there = __ballot(lane >= 1 && (uint32_t)lane <= xc1 && wx == e) != 0;
+                if (!there && lane == 0) {
+                    if (xc1 + 1 > stride - 1) atomicOr(&g.hdr->status, ST_ROW_OVERFLOW);
+                    else { xrow[1 + xc1] = e; xrow[0] = xc1 + 1; atomicMax(maxdeg, xc1 + 1); }
+                }
+                continue;
+            }
+            const uint32_t xc = xc1;
             bool present = false;
             for (uint32_t b2 = 0; b2 < xc; b2 += 64) {
                 const uint32_t p = b2 + lane;

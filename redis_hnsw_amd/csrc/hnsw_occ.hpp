@@ -568,8 +568,9 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
                 __syncthreads();
                 uint32_t nS;
                 if (k >= 0 && !sc.flags[2 + k]) {
+                    const uint32_t sv = shr[k].S[lane];          // S[64]: loaded alongside nS, not after it
                     nS = shr[k].nS;
-                    if ((uint32_t)lane < nS) m.S[lane] = (uint64_t)shr[k].S[lane] << 1;
+                    if ((uint32_t)lane < nS) m.S[lane] = (uint64_t)sv << 1;
                     __syncthreads();
                     n_spec += 1;
                 } else {
