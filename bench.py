@@ -451,7 +451,7 @@ def main():
         ie.add_batch(V[:NE], levels=levels[:NE], mode="exact")
         te = time.time() - te
         exact_build = dict(nodes=NE, build_seconds=round(te, 2), inserts_per_s=round(NE / te, 1),
-                           note="hnsw_add_batch mode 0 on the first 50 k nodes (the rate grows with the index: 3.8 k/s over "
+                           note="hnsw_add_batch mode 0 on the first 50 k nodes (the rate grows with the index: 4.1 k/s over "
                                 "the whole 1 M build, profiles/r2_c5_exact_build_1m.json, graph identical to the CPU oracle's)")
         ie.close()
         log("exact GPU build of %d nodes: %.1f s" % (NE, te))
