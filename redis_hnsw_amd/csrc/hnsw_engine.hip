@@ -89,6 +89,7 @@ struct hnsw_index {
     bool bf16 = false;               // vectors are stored as bf16 (compress_bf16): read-only, dim 128, specialised kernel only
     bool select_shortcut = true;     // select_neighbors after search_level = the head of W (hnsw_insert.hpp); 0 = the full extension
     bool lean = true;                // dim-128 searches use the specialised kernel (hnsw_search_lean.hpp) when its preconditions hold
+    size_t lds_reserve = 0;          // LDS a kernel needs besides the wave's own share (the OCC kernels' validation scratch)
     bool grid_stride = false;        // specialised kernel: cap the grid at the resident waves and walk the batch grid-stride (tuning, for comparison)
     bool visited_bounded = true;     // k_search: a full LDS visited table stops recording (exact results)
     uint32_t max_waves_per_cu = 8;
@@ -334,6 +335,8 @@ uint32_t pick_lnb(const hnsw_index *h, int R, int T, bool ins, uint32_t nwaves)
     per_cu = std::min(std::max(per_cu, 1u), max_per_cu);
     size_t budget = tiers[per_cu - 1];
     while (budget <= fixed + 64 && per_cu > 1) budget = tiers[--per_cu - 1];
+    if (h->lds_reserve) budget = std::min(budget, tiers[0] - h->lds_reserve);   // one block per CU still has to fit
+    if (budget <= fixed + 64) return 2u;
     const uint32_t fit = (uint32_t)((budget - fixed) / 32);
     const uint32_t useful = (uint32_t)(0.8 * (double)h->efc * (double)h->m_max0 * 3.0 / 6.0) + 2;
     return std::max(std::min(fit, useful), 2u);

@@ -141,3 +141,14 @@ def test_random_op_sequences_match_the_oracle(eng, oracle_mod, kind, dim, m, ef,
             check_graph("after op %d" % op_i)
     check_graph("end")
     gi.close()
+
+
+@pytest.mark.parametrize("kind,dim,m,ef,n_ops,seed,tunings", [
+    # found by scripts/fuzz_campaign.py: waves_per_cu = 1 gave the insert kernels the whole CU's LDS for the visited
+    # table and left none for the validation scratch of the windowed insert (launch refused, "invalid argument")
+    ("dupes", 100, 31, 200, 40, 70010, (("select_shortcut", 0), ("visited_bounded", 1), ("waves_per_cu", 1))),
+    ("dupes", 96, 16, 200, 40, 70119, (("visited_bounded", 0), ("occ_min_batch", 2), ("occ_ahead_x10", 30), ("waves_per_cu", 1))),
+    ("uniform", 128, 32, 700, 30, 5, (("waves_per_cu", 1),)),
+])
+def test_random_op_sequences_under_non_default_tunings(eng, oracle_mod, kind, dim, m, ef, n_ops, seed, tunings):
+    test_random_op_sequences_match_the_oracle(eng, oracle_mod, kind, dim, m, ef, n_ops, seed, tunings)
