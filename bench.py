@@ -6,12 +6,14 @@ A step = one pass of the hot path (hnsw_search_batch_device = one k_search launc
 1024 queries already resident in HBM.  Consecutive steps are issued round-robin on `--streams` HIP streams
 (default 3), so three batches are in flight at a time: the chip holds 2048 queries (two wavefronts per SIMD --
 a lone 1024-query launch puts one on each, and a SIMD needs two to keep issuing), and
-the third batch is what the dispatcher backfills from while the first two drain their long queries.  Three
-streams need three hardware queues: the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES (default 4,
-shared with the null stream and the engine's own), and two streams on one queue serialise -- the bench asks
-for 8 before the runtime starts (measured: 3 streams 1.75 M QPS on 4 queues, 2.52 M on 8).  One process per GPU; the index is
-replicated, every rank serves its own batches (weak scaling) and the [B,k] results are all-gathered over
-RCCL.  Prints ONE JSON line on rank 0.
+the third batch is what the dispatcher backfills from while the first two drain their long queries.  Nothing is
+tuned for that: the engine sizes every launch from the launches it sees in flight, and the library asks the HIP
+runtime for 8 hardware queues when it is loaded (streams that share a queue serialise; what the engine's own
+lanes got is measured and reported as config.pipeline).  The same pipelining lives INSIDE the library for
+callers that hand over one large batch: `host_buffers` (hnsw_search_batch, 8192 queries from host memory, PCIe
+in and out) and `device_call` (one hnsw_search_batch_device call of 4096 / 8192 / 16384 queries) report it.
+One process per GPU; the index is replicated, every rank serves its own batches (weak scaling) and the [B,k]
+results are all-gathered over RCCL.  Prints ONE JSON line on rank 0.
 
 The graph the headline runs on (--graph):
   reference  the REFERENCE-ORDER graph (core.rs:489-599, one insert after the other): read from the fixture
@@ -35,8 +37,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec -- the roofline's denominator
+HBM_MEASURED_GBS = 6300.0  # same guide: what a streaming copy sustains from DRAM on this part
 FIXTURES = {(1_000_000, 128, 16, 200): os.path.join(ROOT, "data", "c2_ref_graph_1m.npz")}
+FIXTURE_50K = os.path.join(ROOT, "data", "c2_ref_graph_50k.npz")
 
 
 def draw_levels(n, m, seed=7):
@@ -136,6 +140,68 @@ def spawn_ranks(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def measure_traffic(argv, log):
+    """HBM bytes per k_search launch of THIS command line, measured now: two short re-runs under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes: the two do not fit one), the most frequent
+    k_search launch shape of each, FETCH x 2 (gfx950 correction) + WRITE.  (None, None) if rocprofv3 is missing or
+    a pass fails -- the caller then falls back to the committed figure and says so."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, None
+    keep, skip = [], False
+    for a in argv:                                   # same workload; fewer steps, no extras, no nested profiling
+        if skip:
+            skip = False
+            continue
+        if a in ("--steps", "--warmup", "--cpu-seconds"):
+            skip = True
+            continue
+        if a.startswith(("--steps=", "--warmup=", "--cpu-seconds=")):
+            continue
+        keep.append(a)
+    sub = keep + ["--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--no-extras", "--no-traffic"]
+    tmp = tempfile.mkdtemp(prefix="hnsw_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    vals = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__)] + sub
+            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            db = None
+            for dp, _, files in os.walk(out):
+                for f in files:
+                    if f.endswith("_results.db"):
+                        db = os.path.join(dp, f)
+            if p.returncode != 0 or db is None:
+                log("rocprofv3 --pmc %s failed (rc %s): roofline.traffic falls back to profiles/traffic.json" % (ctr, p.returncode))
+                return None, None
+            cur = sqlite3.connect(db).cursor()
+            rows = list(cur.execute(
+                "select kernel_name, lds_block_size, grid_size, count(*), avg(value) from counters_collection "
+                "where kernel_name like '%k_search%' and counter_name = ? group by kernel_name, lds_block_size, grid_size "
+                "order by count(*) desc", (ctr,)))
+            if not rows:
+                return None, None
+            vals[ctr] = rows[0]
+        kib_r, kib_w = vals["FETCH_SIZE"][4], vals["WRITE_SIZE"][4]
+        traffic = int(kib_r * 1024 * 2.0 + kib_w * 1024)
+        src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE, then --pmc WRITE_SIZE, of `bench.py %s`; "
+               "%d launches of %s; FETCH_SIZE %.0f KiB x 2 (gfx950) + WRITE_SIZE %.0f KiB per launch; launches are serialised "
+               "under --pmc" % (" ".join(sub), vals["FETCH_SIZE"][3], vals["FETCH_SIZE"][0].split("(")[0].replace("void ", ""), kib_r, kib_w))
+        log("traffic per launch %.3f GB (in-run PMC)" % (traffic / 1e9))
+        return traffic, src
+    except (subprocess.TimeoutExpired, OSError, sqlite3.Error) as e:
+        log("in-run traffic measurement failed: %r" % (e,))
+        return None, None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,6 +215,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--streams", type=int, default=3, help="steps in flight (HIP streams used round-robin)")
     ap.add_argument("--waves-per-cu", type=int, default=0, help="engine tuning waves_per_cu (0 = default 8)")
+    ap.add_argument("--launch-concurrency", type=int, default=0,
+                    help="engine tuning launch_concurrency (0 = default: the engine observes the launches in flight)")
+    ap.add_argument("--no-traffic", action="store_true", help="do not re-run under rocprofv3 --pmc for roofline.traffic")
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE",
                     help="extra engine tuning for experiments (hnsw_set_tuning), repeatable")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
@@ -208,7 +277,8 @@ def main():
     if mode == "reference" and not (fixture and os.path.exists(fixture)):
         raise SystemExit("--graph reference needs %s (python tests/fixtures/make_ref_graph.py --out ...)" % fixture)
     index = Index("bench", dim, M, ef, device=local_rank)
-    index.set_tuning("launch_concurrency", S)
+    if args.launch_concurrency:
+        index.set_tuning("launch_concurrency", args.launch_concurrency)
     if args.waves_per_cu:
         index.set_tuning("waves_per_cu", args.waves_per_cu)
     for kv in args.tuning:
@@ -365,7 +435,7 @@ def main():
     sx, _ = index.counters()
     index.set_tuning("visited_bounded", 1)
     index.set_tuning("waves_per_cu", args.waves_per_cu or 8)
-    index.set_tuning("launch_concurrency", S)
+    index.set_tuning("launch_concurrency", args.launch_concurrency)
     n_dist_q, n_ids_q, n_exp_q = sx.n_dist / (nb_exact * B), sx.n_ids / (nb_exact * B), sx.n_expand / (nb_exact * B)
     redo = sc.n_dist / (args.steps * B) / n_dist_q - 1.0 if args.steps else 0.0
 
@@ -394,31 +464,53 @@ def main():
         return
 
     extras = world == 1 and not args.no_extras
-    # ---- informational: one large batch in one launch (the kernel alone on the GPU, 8 waves per CU) ----
-    big = None
-    if extras:
-        Bb = 4096
-        Qb = torch.from_numpy(np.random.default_rng(5).random((Bb, dim), dtype=np.float32)).to(dev)
-        bi = torch.empty((Bb, k), dtype=torch.int32, device=dev)
-        bs = torch.empty((Bb, k), dtype=torch.float32, device=dev)
-        bn = torch.empty((Bb,), dtype=torch.int32, device=dev)
-        index.set_tuning("launch_concurrency", 1)
-        for _ in range(2):
-            index.search_batch_device(Qb.data_ptr(), Bb, k, bi.data_ptr(), bs.data_ptr(), bn.data_ptr(), cur.cuda_stream)
-        torch.cuda.synchronize()
+    # ---- the literal BASELINE shape: ONE 1024-query launch at a time (one wave per SIMD, nothing to backfill from)
+    lone = None
+    if world == 1:
+        for _ in range(3):
+            search_now(myQ[:B], B)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 10
+        reps = 12
         e0.record(cur)
-        for _ in range(reps):
-            index.search_batch_device(Qb.data_ptr(), Bb, k, bi.data_ptr(), bs.data_ptr(), bn.data_ptr(), cur.cuda_stream)
+        for r_ in range(reps):
+            q = myQ[(r_ % n_qbatches) * B:(r_ % n_qbatches + 1) * B]
+            index.search_batch_device(q.data_ptr(), B, k, d_ids.data_ptr(), d_sims.data_ptr(), d_n.data_ptr(), cur.cuda_stream)
         e1.record(cur)
         torch.cuda.synchronize()
-        msb = e0.elapsed_time(e1) / reps
-        byb = Bb * (n_dist_q * 4 * dim + n_ids_q * 4 + 4 * dim + 8 * k)
-        big = dict(batch=Bb, launches_in_flight=1, kernel_ms=round(msb, 4), value=round(Bb / msb * 1e3, 1), unit="queries/s",
-                   achieved=round(byb / (msb * 1e-3) / 1e9, 1), frac=round(byb / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
-        index.set_tuning("launch_concurrency", S)
-        log("one %d-query launch: %.3f ms, %.0f GB/s" % (Bb, msb, big["achieved"]))
+        msl = e0.elapsed_time(e1) / reps
+        byl = B * (n_dist_q * 4 * dim + n_ids_q * 4 + 4 * dim + 8 * k)
+        lone = dict(batch=B, launches_in_flight=1, kernel_ms=round(msl, 4), value=round(B / msl * 1e3, 1), unit="queries/s",
+                    achieved=round(byl / (msl * 1e-3) / 1e9, 1), frac=round(byl / (msl * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+        log("lone %d-query launches: %.3f ms each, %.0f GB/s" % (B, msl, lone["achieved"]))
+
+    # ---- one hnsw_search_batch_device CALL per size, calls back to back on one stream: the engine splits a call
+    # into 1024-query chunks over its own lanes and joins them back, so every call pays its own drain
+    big = None
+    dev_calls = []
+    if extras:
+        for Bb in (4096, 8192, 16384):
+            Qb = torch.from_numpy(np.random.default_rng(5).random((Bb, dim), dtype=np.float32)).to(dev)
+            bi = torch.empty((Bb, k), dtype=torch.int32, device=dev)
+            bs = torch.empty((Bb, k), dtype=torch.float32, device=dev)
+            bn = torch.empty((Bb,), dtype=torch.int32, device=dev)
+            for _ in range(2):
+                index.search_batch_device(Qb.data_ptr(), Bb, k, bi.data_ptr(), bs.data_ptr(), bn.data_ptr(), cur.cuda_stream)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 8
+            e0.record(cur)
+            for _ in range(reps):
+                index.search_batch_device(Qb.data_ptr(), Bb, k, bi.data_ptr(), bs.data_ptr(), bn.data_ptr(), cur.cuda_stream)
+            e1.record(cur)
+            torch.cuda.synchronize()
+            msb = e0.elapsed_time(e1) / reps
+            byb = Bb * (n_dist_q * 4 * dim + n_ids_q * 4 + 4 * dim + 8 * k)
+            ent = dict(batch=Bb, calls_in_flight=1, ms_per_call=round(msb, 4), value=round(Bb / msb * 1e3, 1), unit="queries/s",
+                       achieved=round(byb / (msb * 1e-3) / 1e9, 1), frac=round(byb / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+            dev_calls.append(ent)
+            log("one %d-query device call: %.3f ms, %.0f GB/s" % (Bb, msb, ent["achieved"]))
+            del Qb, bi, bs, bn
+        big = dev_calls[0]
 
     # ---- informational: the same configuration on clustered data, where the reference algorithm's
     # recall is high enough for recall parity to mean something (uniform 128-d: 0.22-0.27 at 1 M)
@@ -444,17 +536,31 @@ def main():
     exact_build = None
     if cfg_is_c2 and extras and world == 1:
         # the reference-order build (hnsw_add_batch mode 0: plans in parallel, validated in-order commits) on a
-        # bounded prefix; the full 1 M build and its row-for-row identity check are scripts/exact_build_check.py
+        # bounded prefix, CHECKED row for row against the oracle's serial build of the same prefix (committed
+        # fixture, tests/fixtures/make_ref_graph.py --nodes 50000); the full 1 M build and its identity check are
+        # scripts/exact_build_check.py
         NE = 50_000
         ie = Index("bench-exact", dim, M, ef, device=local_rank)
         te = time.time()
         ie.add_batch(V[:NE], levels=levels[:NE], mode="exact")
         te = time.time() - te
-        exact_build = dict(nodes=NE, build_seconds=round(te, 2), inserts_per_s=round(NE / te, 1),
-                           note="hnsw_add_batch mode 0 on the first 50 k nodes (the rate grows with the index: 4.1 k/s over "
-                                "the whole 1 M build, profiles/r2_c5_exact_build_1m.json, graph identical to the CPU oracle's)")
+        identical, why = None, "data/c2_ref_graph_50k.npz is missing"
+        if os.path.exists(FIXTURE_50K):
+            want, _ = load_graph_fixture(FIXTURE_50K, V)
+            got = ie.export_graph()
+            identical = (want["enterpoint"] == got["enterpoint"] and want["max_layer"] == got["max_layer"]
+                         and np.array_equal(want["levels"], got["levels"])
+                         and all(np.array_equal(a_, b_) for a_, b_ in zip(want["row_ptr"], got["row_ptr"]))
+                         and all(np.array_equal(a_, b_) for a_, b_ in zip(want["col"], got["col"])))
+            why = "levels, enterpoint and every adjacency row of every layer in stored order == the CPU oracle's serial build"
+            if not identical:
+                raise SystemExit("gpu_exact_build: the GPU's reference-order graph differs from the oracle's fixture")
+        exact_build = dict(nodes=NE, build_seconds=round(te, 2), inserts_per_s=round(NE / te, 1), identical=identical,
+                           checked_against=why,
+                           note="hnsw_add_batch mode 0 on the first 50 k nodes (the rate grows with the index; the whole 1 M "
+                                "build: profiles/r3_c5_exact_build_1m.json)")
         ie.close()
-        log("exact GPU build of %d nodes: %.1f s" % (NE, te))
+        log("exact GPU build of %d nodes: %.1f s, identical to the oracle's: %s" % (NE, te, identical))
     if cfg_is_c2 and extras and not args.no_clustered:
         centers = np.random.default_rng(3).random((64, dim), dtype=np.float32)
         Vc = clustered(N, dim, 3, centers)
@@ -488,7 +594,6 @@ def main():
         gb["vectors"] = V
         ib.import_graph(gb)
         ib.set_tuning("compress_bf16", 1)
-        ib.set_tuning("launch_concurrency", S)
         for i in range(4):
             ib.search_batch_device(myQ[:B].data_ptr(), B, k, bufs[i % S][0].data_ptr(), bufs[i % S][1].data_ptr(),
                                    d_ns[i % S].data_ptr(), streams[i % S].cuda_stream)
@@ -519,13 +624,23 @@ def main():
         ib.close()
         log("bf16 copy: %.3f ms/step, recall@10 %.4f" % (1e3 * tb16, bf16["recall_at_10"]))
 
-    # ---- the same batch through the host-buffer entry point (PCIe in and out); informational
-    Qh = Qall[:B]
+    # ---- host memory in, host memory out (PCIe both ways; never `value`): hnsw_search_batch pipelines a large
+    # batch itself -- pinned staging, H2D / kernel / D2H of different chunks overlapped on the engine's lanes
+    Qh = Qall[:8 * B]
     index.search_batch(Qh, k)
     th = time.perf_counter()
-    for _ in range(5):
-        index.search_batch(Qh, k)
-    host_qps = 5 * B / (time.perf_counter() - th)
+    for _ in range(4):
+        hb_ids, _, _ = index.search_batch(Qh, k)
+    host_qps = 4 * Qh.shape[0] / (time.perf_counter() - th)
+    index.search_batch(Qall[:B], k)
+    th = time.perf_counter()
+    for _ in range(6):
+        index.search_batch(Qall[:B], k)
+    host_qps_1024 = 6 * B / (time.perf_counter() - th)
+    host = dict(batch=int(Qh.shape[0]), value=round(host_qps, 1), unit="queries/s", one_batch_of_1024=round(host_qps_1024, 1),
+                note="hnsw_search_batch from pageable host memory, results back in host memory, one call at a time")
+    log("host buffers: %.0f QPS at B=%d, %.0f at B=%d" % (host_qps, Qh.shape[0], host_qps_1024, B))
+    pipe = index.pipeline_info()
 
     # ---- roofline of the dominant kernel (k_search) -------------------------------------
     # algorithmic bytes per launch = B x (n_dist*4*dim + n_ids*4 + 4*dim + 8*k)  (SURVEY 8d), the reference's counts
@@ -536,19 +651,30 @@ def main():
     # time (this rank's), which also pays for the gaps between launches: never above in_flight x per_launch
     overlapped = in_flight * per_launch
     achieved = min(overlapped, bytes_per_launch * args.steps / t_local / 1e9) if args.steps else overlapped
-    # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
-    # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, see profiles/); null for other workloads
-    traffic = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        want = dict(nodes=N, dim=dim, M=M, ef=ef, k=k, batch=B, graph=mode, streams=S)
-        for ent in tj["entries"]:
-            if all(ent["config"].get(kk) == vv for kk, vv in want.items()):
-                traffic = ent["k_search_hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError, TypeError):
-        pass
+    # HBM traffic per launch: measured IN THIS RUN when rocprofv3 is on PATH (two short re-runs of this command
+    # under --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 is the gfx950 correction of
+    # MI355X_MICROARCH.md, calibrated on this access pattern in profiles/*_pmc_hbm.txt), else the committed figure
+    traffic, traffic_source = None, None
+    if not args.no_traffic and world == 1 and args.steps:
+        traffic, traffic_source = measure_traffic(sys.argv[1:], log)
+    if traffic is None:
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            want = dict(nodes=N, dim=dim, M=M, ef=ef, k=k, batch=B, graph=mode, streams=S)
+            for ent in tj["entries"]:
+                if all(ent["config"].get(kk) == vv for kk, vv in want.items()):
+                    traffic = ent["k_search_hbm_bytes_per_launch"]
+                    traffic_source = "profiles/traffic.json@%s (not measured in this run)" % ent.get("commit", "?")
+        except (OSError, ValueError, KeyError, TypeError):
+            pass
     roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_source,
+                    peak_hbm_spec=HBM_PEAK_GBS, hbm_measured_copy=HBM_MEASURED_GBS,
+                    frac_of_measured_copy=round(achieved / HBM_MEASURED_GBS, 4),
+                    what="ALGORITHMIC bytes (the reference's n_dist x 4 dim + n_ids x 4 + query + results per query) over time, "
+                         "against the 8 TB/s HBM3E spec.  It is not a DRAM-level rate: the counters behind `traffic` sit at the "
+                         "L2's memory side and include Infinity-Cache hits (the 256 MB cache holds half of this 512 MB matrix), "
+                         "which is how the figure can exceed what a streaming copy sustains from DRAM (hbm_measured_copy)",
                     kernel="k_search", kernel_ms=round(kernel_ms, 4),
                     kernel_ms_median=None if kernel_ms_median is None else round(kernel_ms_median, 4),
                     kernel_ms_p90=None if kernel_ms_p90 is None else round(kernel_ms_p90, 4),
@@ -561,6 +687,7 @@ def main():
                     n_dist_per_query=round(n_dist_q, 1), n_ids_per_query=round(n_ids_q, 1),
                     n_expand_per_query=round(n_exp_q, 1),
                     re_evaluated_fraction=round(max(redo, 0.0), 5),
+                    lone_launch_1024=lone,
                     single_launch_4096=big)
 
     # ---- CPU baseline: the oracle (C restatement of the Rust path), bounded sample -------
@@ -640,13 +767,14 @@ def main():
                                % (cfg_name, N, dim, M, ef, k, B),
                    "nodes": N, "dim": dim, "M": M, "ef": ef, "k": k, "batch": B, "graph": mode, "graph_desc": graph_desc,
                    "steps_in_flight": S, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                   "launch_concurrency": args.launch_concurrency or "observed by the engine", "pipeline": pipe,
                    "prewarm_launches": PREWARM,
                    "parallelism": "replica x%d, query batch sharded%s" % (
                        world, " (ranks share one device, gloo: functional check only)" if one_device and world > 1 else "")},
         "gather_verified": gather_ok,
         "recall_at_%d" % k: None if recall is None else round(recall, 4),
         "build_seconds": None if t_build is None else round(t_build, 2),
-        "host_buffers_qps": round(host_qps, 1),
+        "host_buffers_qps": round(host_qps, 1), "host_buffers": host, "device_call": dev_calls,
         "gpu_fast_build": fast_build, "gpu_exact_build": exact_build,
         "clustered": clus,
         "bf16_storage_mode": bf16,

@@ -115,14 +115,33 @@ hnsw_status hnsw_search_batch(hnsw_index *h, const float *Q, uint32_t B, uint32_
 
 /* Same, with every buffer already resident in HBM; enqueues on `stream`
  * (a hipStream_t, NULL = the null stream) and returns without synchronising.
- * Throughput: keep three 1024-query calls in flight on three streams (a batch of 1024 fills half of
- * the chip's 2048 wave slots; the third is what the dispatcher backfills from) and export
- * GPU_MAX_HW_QUEUES=8 before the HIP runtime starts -- with the default of 4 hardware queues two of
- * the streams share one and serialise.  Inserts and deletes wait for every search
- * enqueued before them, whatever its stream.                                                       */
+ * Batches of "pipe_min_batch" (1536) queries or more are split into chunks of <= "pipe_chunk" (1024)
+ * that run on `stream` and two engine-owned streams and are joined back into `stream` before the call
+ * returns (hnsw_search_batch does the same with its copies overlapped): the chip holds 2048 queries,
+ * and a third chunk is what the dispatcher backfills from while the long queries of the first two
+ * drain.  Smaller calls are one launch; a caller that keeps several of those in flight
+ * on its own streams needs no tuning -- the engine sizes each launch's LDS share from the launches it
+ * sees in flight.  Inserts and deletes wait for every search enqueued before them, whatever its stream. */
 hnsw_status hnsw_search_batch_device(hnsw_index *h, const float *dQ, uint32_t B,
                                      uint32_t dim, uint32_t k, uint32_t *d_ids,
                                      float *d_sims, uint32_t *d_n_out, void *stream);
+
+/* The search pipeline's lanes need a hardware queue each.  The library asks the HIP runtime for 8
+ * (GPU_MAX_HW_QUEUES, set at load time unless the operator exported a value; effective when the library is
+ * loaded before the runtime starts) and measures, when the lanes are created, whether they really run
+ * concurrently: overlap = 1 yes, 0 they serialise (reported once on stderr; fatal with
+ * HNSW_REQUIRE_OVERLAP=1 in the environment), -1 not created yet.  probe_ratio = (a 200 us spin kernel on
+ * every lane at once) / (on one lane); priorities = 1 when the lanes had to be given distinct stream
+ * priorities to get queues of their own.  Creates the lanes if no batched search has done so yet.          */
+typedef struct {
+    uint32_t lanes;
+    int32_t overlap;
+    float probe_ratio;
+    uint32_t priorities;
+    uint32_t chunk, min_batch;
+    uint32_t hw_queues_env;    /* GPU_MAX_HW_QUEUES as this process sees it (0 = unset) */
+} hnsw_pipeline;
+hnsw_status hnsw_pipeline_info(hnsw_index *h, hnsw_pipeline *out);
 
 /* Replaces make_index (src/lib.rs:252-315): load a frozen graph straight into
  * HBM.  vectors [n][dim]; levels [n]; per layer l < n_layers a CSR
@@ -151,7 +170,9 @@ hnsw_status hnsw_deserialize(const void *buf, uint64_t bytes, uint64_t seed, int
                              hnsw_index **out);
 
 /* Engine knobs (not part of the reference surface).
- *   search    "launch_concurrency" (search launches the caller keeps in flight: sizes the LDS share),
+ *   search    "launch_concurrency" (search launches the caller keeps in flight: sizes the LDS share; 0 =
+ *             default: observed per launch), "pipe_chunk" / "pipe_min_batch" / "pipe_device" (the engine's
+ *             own pipelining of large batches, see hnsw_search_batch_device),
  *             "waves_per_cu" (residency the visited table is sized for, default 8), "visited_bounded"
  *             (1: a full LDS visited table stops recording -- exact results, distance evaluations may
  *             exceed the reference's; 0: the table continues in HBM -- counters equal the reference's),

@@ -20,6 +20,11 @@ class Info(C.Structure):
                 ("allocated_ids", C.c_uint32)]
 
 
+class Pipeline(C.Structure):
+    _fields_ = [("lanes", C.c_uint32), ("overlap", C.c_int32), ("probe_ratio", C.c_float), ("priorities", C.c_uint32),
+                ("chunk", C.c_uint32), ("min_batch", C.c_uint32), ("hw_queues_env", C.c_uint32)]
+
+
 fp = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)
 u64p = C.POINTER(C.c_uint64)
@@ -38,6 +43,7 @@ SIGNATURES = {
     "hnsw_search_batch": (C.c_int, [H, fp, C.c_uint32, C.c_uint32, C.c_uint32, u32p, fp, u32p]),
     "hnsw_search_batch_device": (C.c_int, [H, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hnsw_pipeline_info": (C.c_int, [H, C.POINTER(Pipeline)]),
     "hnsw_import": (C.c_int, [H, C.c_uint32, fp, u32p, C.c_int64, C.c_uint32, C.POINTER(u64p), C.POINTER(u32p)]),
     "hnsw_get_info": (C.c_int, [H, C.POINTER(Info)]),
     "hnsw_get_levels": (C.c_int, [H, u32p]),

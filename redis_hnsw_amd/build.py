@@ -1,4 +1,9 @@
-"""Build libhnsw_mi355x.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build libhnsw_mi355x.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+One translation unit per kernel family and metric variant (csrc/hnsw_host.hpp lists them), compiled in
+parallel into redis_hnsw_amd/build_obj/ and linked into one shared library; each object is rebuilt only when
+its own sources change."""
+import concurrent.futures
 import os
 import shutil
 import subprocess
@@ -6,14 +11,24 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
+OBJ_DIR = os.path.join(_HERE, "build_obj")
 LIB_PATH = os.path.join(LIB_DIR, "libhnsw_mi355x.so")
-SOURCES = ["hnsw_engine.hip"]
-DEPS = ["hnsw_engine.hip", "hnsw_device.hpp", "hnsw_kernels.hpp", "hnsw_insert.hpp", "hnsw_insert_host.inc", "hnsw_search_lean.hpp", "hnsw_occ.hpp",
-        os.path.join("..", "..", "include", "hnsw_mi355x.h")]
+_COMMON = ["hnsw_host.hpp", "hnsw_device.hpp", "hnsw_insert.hpp", "hnsw_occ.hpp",
+           os.path.join("..", "..", "include", "hnsw_mi355x.h")]
+# (source, variants, headers besides _COMMON)
+UNITS = [
+    ("hnsw_engine.hip", [None], ["hnsw_kernels.hpp", "hnsw_search_lean.hpp", "hnsw_insert_host.inc"]),
+    ("hnsw_tu_lean.hip", [0, 1], ["hnsw_search_lean.hpp"]),
+    ("hnsw_tu_search.hip", [0, 1, 2, 3], ["hnsw_kernels.hpp"]),
+    ("hnsw_tu_insert.hip", [0, 1, 2, 3], []),
+    ("hnsw_tu_occ.hip", [0, 1, 2, 3], []),
+]
+SOURCES = [u[0] for u in UNITS]
+DEPS = sorted(set(SOURCES + _COMMON + [d for u in UNITS for d in u[2]]))
 # -ffp-contract=off: the metric must round exactly where the reference's does
 # (explicit fma only, metrics.rs:57); never -ffast-math.
-FLAGS = ["--offload-arch=gfx950", "-Os", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-Os", "-std=c++17", "-ffp-contract=off", "-fPIC",
+         "-Wall", "-Wno-unused-function", "-Wno-undefined-func-template"]
 
 
 def hipcc():
@@ -23,22 +38,62 @@ def hipcc():
     raise RuntimeError("hipcc not found (need ROCm to build libhnsw_mi355x.so)")
 
 
-def needs_build():
-    if not os.path.exists(LIB_PATH):
+def _jobs(obj_dir, extra_flags=()):
+    """[(object path, command, dependency paths)] for every (source, variant)"""
+    out = []
+    for src, variants, deps in UNITS:
+        for v in variants:
+            stem = os.path.splitext(src)[0] + ("" if v is None else "_v%d" % v)
+            obj = os.path.join(obj_dir, stem + ".o")
+            cmd = [hipcc()] + FLAGS + list(extra_flags) + ([] if v is None else ["-DHNSW_VARIANT=%d" % v]) + \
+                  ["-c", os.path.join(CSRC, src), "-o", obj]
+            out.append((obj, cmd, [os.path.join(CSRC, d) for d in [src] + _COMMON + deps]))
+    return out
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB_PATH)
+    t = os.path.getmtime(target)
     if os.path.getmtime(os.path.abspath(__file__)) > t:  # the flags live here
         return True
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def needs_build():
+    jobs = _jobs(OBJ_DIR)
+    if _stale(LIB_PATH, [d for _, _, deps in jobs for d in deps]):
+        return True
+    return False
+
+
+def _compile_and_link(lib_path, obj_dir, force=False, extra_flags=(), workers=None):
+    os.makedirs(os.path.dirname(lib_path), exist_ok=True)
+    os.makedirs(obj_dir, exist_ok=True)
+    jobs = _jobs(obj_dir, extra_flags)
+    todo = [(obj, cmd) for obj, cmd, deps in jobs if force or _stale(obj, deps)]
+    workers = workers or max(1, min(len(todo), os.cpu_count() or 1, 8))
+    if todo:
+        def run(job):
+            obj, cmd = job
+            p = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+            if p.returncode != 0:
+                raise RuntimeError("%s\n%s%s" % (" ".join(cmd), p.stdout[-4000:], p.stderr[-8000:]))
+            return obj
+        # the heaviest units first (OCC, insert), so the pool drains evenly
+        todo.sort(key=lambda j: ("occ" not in j[0], "insert" not in j[0]))
+        with concurrent.futures.ThreadPoolExecutor(max_workers=workers) as ex:
+            list(ex.map(run, todo))
+    objs = [obj for obj, _, _ in jobs]
+    if todo or force or not os.path.exists(lib_path) or any(os.path.getmtime(o) > os.path.getmtime(lib_path) for o in objs):
+        subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs, cwd=CSRC)
+    return lib_path
 
 
 def build_library(force=False, extra_flags=()):
-    if not force and not needs_build():
+    if not force and not extra_flags and not needs_build():
         return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc()] + FLAGS + list(extra_flags) + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
-    subprocess.check_call(cmd, cwd=CSRC)
-    return LIB_PATH
+    return _compile_and_link(LIB_PATH, OBJ_DIR, force=force or bool(extra_flags), extra_flags=extra_flags)
 
 
 PROF_LIB_PATH = os.path.join(LIB_DIR, "libhnsw_mi355x_prof.so")
@@ -47,10 +102,7 @@ PROF_LIB_PATH = os.path.join(LIB_DIR, "libhnsw_mi355x_prof.so")
 def build_profiling_library():
     """Development aid: the same library with per-phase cycle counters compiled in
     (-DHNSW_PHASE_TIMERS); use it with HNSW_MI355X_LIB=<path> scripts/phase_profile.py."""
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc()] + FLAGS + ["-DHNSW_PHASE_TIMERS", "-o", PROF_LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
-    subprocess.check_call(cmd, cwd=CSRC)
-    return PROF_LIB_PATH
+    return _compile_and_link(PROF_LIB_PATH, OBJ_DIR + "_prof", extra_flags=["-DHNSW_PHASE_TIMERS"])
 
 
 if __name__ == "__main__":

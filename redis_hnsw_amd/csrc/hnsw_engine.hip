@@ -1,14 +1,16 @@
 // hnsw_engine.hip -- host side of libhnsw_mi355x.so: the C ABI of
 // include/hnsw_mi355x.h over the gfx950 kernels.  No CPU compute path exists
 // here: every search / insert is a kernel launch, and creation fails without
-// a device.
-#include "../../include/hnsw_mi355x.h"
-#include "hnsw_insert.hpp"
+// a device.  The heavy kernel templates are instantiated in their own
+// translation units (hnsw_tu_*.hip, see hnsw_host.hpp); this file holds the
+// handle's bookkeeping, the entry points and the small utility kernels.
+#define HNSW_UTILITY_KERNELS 1
+#include "hnsw_host.hpp"
 #include "hnsw_kernels.hpp"
 #include "hnsw_search_lean.hpp"
-#include "hnsw_occ.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -18,98 +20,7 @@
 
 using namespace hnsw;
 
-struct hnsw_index {
-    uint32_t dim = 0, m = 0, m_max = 0, m_max0 = 0, efc = 0;
-    double level_mult = 0;
-    int device = 0;
-    int mode = MODE_AVX, T = 0;
-    uint32_t cap = 0, n = 0, max_layer = 0;
-    int64_t enterpoint = -1;
-    uint32_t stride0 = 0, strideU = 0, upper_cap = 0, upper_used = 0;
-    uint32_t max_deg0 = 0, max_degU = 0;
-    float *d_vec = nullptr;
-    uint32_t *d_adj0 = nullptr, *d_adjU = nullptr, *d_upper_base = nullptr, *d_levels = nullptr;
-    DevHeader *d_hdr = nullptr;
-    std::vector<uint32_t> h_levels, h_upper_base;
-    std::vector<uint8_t> h_dead;   // tombstones (HNSW.NODE.DEL); ids are never reused
-    uint32_t n_dead = 0;
-    // search scratch
-    // HBM spill tables of the visited sets: kSpillRegions regions, handed out round-robin so that
-    // launches overlapping on different streams never share one (an event per region orders reuse)
-    uint32_t *d_spill = nullptr;
-    uint32_t *d_spill_one = nullptr;   // one table for the single-wave exact insert / delete kernels: holds every id of the index
-    uint32_t spill_one_gnb = 0;
-    uint32_t spill_gnb = 0, spill_slots = 0;
-    hipEvent_t spill_ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool spill_busy[4] = {false, false, false, false};
-    // the specialised search kernel uses no spill region: one "last search" event per caller stream instead
-    static constexpr uint32_t kSearchStreams = 16;
-    hipEvent_t search_ev[kSearchStreams] = {};
-    hipStream_t search_st[kSearchStreams] = {};
-    bool search_busy[kSearchStreams] = {};
-    uint32_t search_rr = 0;
-    uint32_t spill_rr = 0;
-    float *d_Q = nullptr;
-    uint32_t *d_res = nullptr;       // [ids B*k][sims B*k][n_out B] of the host-buffer entry points
-    size_t stage_q = 0, stage_r = 0;
-    uint32_t *h_pinned = nullptr;    // pinned mirror for batches <= kPinnedBatch
-    size_t pinned_words = 0;
-    // insert scratch
-    uint32_t *d_plan = nullptr;     // [plan_slots][kMaxLayers][1 + 64]
-    uint32_t plan_slots = 0;
-    uint32_t *d_touched = nullptr;  // exact insert touched list
-    uint32_t touched_cap = 0;
-    uint32_t *d_work = nullptr;     // fast build: shrink worklist
-    // exact-order parallel insert (hnsw_occ.hpp)
-    OccSlot *d_occ_slots = nullptr;
-    OccRead *d_occ_reads = nullptr;
-    OccShr *d_occ_shr = nullptr;
-    OccDelta *d_occ_ring = nullptr;
-    OccCtl *d_occ_ctl = nullptr;
-    uint32_t occ_window = 32;       // tuning: window slots (0 = the serial path only)
-    uint32_t occ_min_batch = 64;    // batches smaller than this take the serial path
-    uint32_t occ_log_cap = kOccMaxReads;   // tests: a tiny read log sends every node of the window to the serial kernels
-    uint32_t occ_slack_extra = 0;   // tests: demand this much more free room per row (exercises the restride stop)
-    uint32_t occ_ahead_x10 = 15;    // tuning: look-ahead = this/10 x running yield + 3
-    double occ_yield = 4.0;         // commits per round, running average (sizes the look-ahead)
-    uint64_t occ_rounds = 0;
-    OccCtl occ_last = {};           // counters of the last windowed build (hnsw_debug_occ)
-    uint32_t work_cap = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_sync = nullptr;
-    bool ev_valid = false;
-    bool time_launches = false;     // tuning: bracket every search launch with events (hnsw_last_search_kernel_ms)
-    int lds_buckets_override = -1;
-    bool tag_table = true;          // 16-bit tag visited table when the id range allows it
-    int tag_bb_override = -1;       // tests: force log2(buckets) of the tag table
-    int idbits_override = -1;       // tests: hash ids as an index of 2^idbits nodes would
-    bool asymmetric = false;        // links may be one-directional (the fast build prunes that way; imports are checked)
-    uint32_t lds_fill_x2 = 13;       // LDS visited table holds lnb * fill/2 ids (of 7 per bucket) before spilling
-    int grid_override = -1;
-    bool bf16 = false;               // vectors are stored as bf16 (compress_bf16): read-only, dim 128, specialised kernel only
-    bool select_shortcut = true;     // select_neighbors after search_level = the head of W (hnsw_insert.hpp); 0 = the full extension
-    bool lean = true;                // dim-128 searches use the specialised kernel (hnsw_search_lean.hpp) when its preconditions hold
-    size_t lds_reserve = 0;          // LDS a kernel needs besides the wave's own share (the OCC kernels' validation scratch)
-    bool grid_stride = false;        // specialised kernel: cap the grid at the resident waves and walk the batch grid-stride (tuning, for comparison)
-    bool visited_bounded = true;     // k_search: a full LDS visited table stops recording (exact results)
-    uint32_t max_waves_per_cu = 8;
-    uint32_t launch_concurrency = 1; // tuning: search launches the caller keeps in flight at once (sizes the LDS share)   // residency the LDS visited table is sized for (tuning: waves_per_cu)
-    uint32_t fast_seed = 512, fast_batch_max = 4096, fast_batch_div = 8;
-    uint64_t rng[4] = {0, 0, 0, 0};
-    uint64_t hbm_bytes = 0;
-    std::string err;
-};
-
-namespace {
-
-#define HIP_TRY(h, expr)                                                                       \
-    do {                                                                                       \
-        hipError_t e_ = (expr);                                                                \
-        if (e_ != hipSuccess) {                                                                \
-            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                      \
-            return HNSW_ERR_DEVICE;                                                            \
-        }                                                                                      \
-    } while (0)
+namespace hnsw_host {
 
 hnsw_status fail(hnsw_index *h, hnsw_status s, const std::string &msg)
 {
@@ -330,7 +241,7 @@ uint32_t pick_lnb(const hnsw_index *h, int R, int T, bool ins, uint32_t nwaves)
     // ... and so does the dim-768 search: its kernel holds the query and 24 loads in registers (> 256 VGPRs:
     // one wave per SIMD whatever the LDS share), so a smaller table would only forget more
     const uint32_t max_per_cu = (ins || T == 24) ? std::min(h->max_waves_per_cu, 4u) : h->max_waves_per_cu;
-    if (!ins) nwaves *= h->launch_concurrency;   // searches the caller overlaps on several streams share the CUs
+    if (!ins) nwaves *= std::max(h->cur_conc, 1u);   // search launches in flight at once share the CUs (search_concurrency)
     uint32_t per_cu = (nwaves + 255) / 256;
     per_cu = std::min(std::max(per_cu, 1u), max_per_cu);
     size_t budget = tiers[per_cu - 1];
@@ -341,14 +252,6 @@ uint32_t pick_lnb(const hnsw_index *h, int R, int T, bool ins, uint32_t nwaves)
     const uint32_t useful = (uint32_t)(0.8 * (double)h->efc * (double)h->m_max0 * 3.0 / 6.0) + 2;
     return std::max(std::min(fit, useful), 2u);
 }
-
-// LDS visited-set configuration of one launch
-struct VisCfg {
-    uint32_t lnb;      // 32-byte buckets (32-bit id mode); also sizes LDS in tag mode via `bytes`
-    uint32_t lcap;     // ids before the set moves to HBM
-    uint32_t tagcfg;   // 0, or log2(16-byte buckets) | idbits << 8
-    size_t bytes;      // LDS bytes of the table
-};
 
 VisCfg pick_vis(const hnsw_index *h, int R, int T, bool ins, uint32_t nwaves)
 {
@@ -474,85 +377,23 @@ hnsw_status ensure_spill_one(hnsw_index *h)
     return HNSW_OK;
 }
 
-template <int MODE, int T, int R>
-hnsw_status launch_search_t(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t *d_ids,
-                            float *d_sims, uint32_t *d_nout, hipStream_t st)
+// The specialised kernel's preconditions that do not depend on the launch (nullptr = all hold).  The bf16 serving
+// copy has no other kernel, so "compress_bf16" checks them before converting and the knobs below are refused
+// afterwards.
+const char *lean_blocker(const hnsw_index *h)
 {
-    const VisCfg vc = pick_vis(h, R, T, false, B);
-    const uint32_t lnb = vc.lnb;
-    const size_t lds = lds_fixed_bytes(R, T, h->dim, false) + vc.bytes;
-    GraphView gv = view(h);
-    gv.tagcfg = vc.tagcfg;
-    auto kern = k_search<MODE, T, R>;
-    {   // the attribute sticks to the function: set it once per size class, not once per launch
-        static size_t lds_set[16] = {0};
-        size_t &have = lds_set[h->device & 15];
-        if (lds > have) {
-            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            have = lds;
-        }
-    }
-    uint32_t grid = std::min(B, h->spill_slots);
-    if (h->grid_override > 0) grid = std::min<uint32_t>(grid, (uint32_t)h->grid_override);
-    uint32_t region, *spill;
-    hnsw_status ss = spill_acquire(h, st, &region, &spill);
-    if (ss != HNSW_OK) return ss;
-    if (h->time_launches) HIP_TRY(h, hipEventRecord(h->ev0, st));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, st, gv, dQ, B, k, h->efc, lnb, vc.lcap, spill,
-                       h->spill_gnb, d_ids, d_sims, d_nout, h->visited_bounded ? 1u : 0u);
-    HIP_TRY(h, hipGetLastError());
-    if (h->time_launches) {
-        HIP_TRY(h, hipEventRecord(h->ev1, st));
-        h->ev_valid = true;
-    }
-    if ((ss = spill_release(h, st, region)) != HNSW_OK) return ss;
-    return HNSW_OK;
-}
-
-template <int MODE, int T>
-hnsw_status launch_search_r(hnsw_index *h, int R, const float *dQ, uint32_t B, uint32_t k, uint32_t *d_ids,
-                            float *d_sims, uint32_t *d_nout, hipStream_t st)
-{
-    switch (R) {
-    case 1: return launch_search_t<MODE, T, 1>(h, dQ, B, k, d_ids, d_sims, d_nout, st);
-    case 4: return launch_search_t<MODE, T, 4>(h, dQ, B, k, d_ids, d_sims, d_nout, st);
-    case 8: return launch_search_t<MODE, T, 8>(h, dQ, B, k, d_ids, d_sims, d_nout, st);
-    case 16: return launch_search_t<MODE, T, 16>(h, dQ, B, k, d_ids, d_sims, d_nout, st);
-    }
-    return fail(h, HNSW_ERR_INVALID, "ef_construction > 1024 is not supported");
-}
-
-// The specialised kernel: no HBM spill table involved, so no region bookkeeping either.
-template <class VEC, int R, int BB, int DB>
-hnsw_status launch_lean_t(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t idbits, uint32_t per_cu,
-                          uint32_t *d_ids, float *d_sims, uint32_t *d_nout, hipStream_t st)
-{
-    const size_t lds = (size_t)R * 64 * 8 + ((size_t)16 << BB);
-    auto kern = k_search_lean<VEC, R, BB, DB>;
-    {
-        static size_t lds_set[16] = {0};
-        size_t &have = lds_set[h->device & 15];
-        if (lds > have) {
-            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            have = lds;
-        }
-    }
-    // as many blocks as the CUs hold at this table size; a larger batch is walked grid-stride
-    // one block per query: a batch larger than the chip holds queues in the dispatcher, which hands a new query to
-    // whichever slot frees first (queries differ in length by 2x; a grid-stride loop would fix the pairing up front)
-    uint32_t grid = h->grid_stride ? std::min(B, 256u * std::max(per_cu, 8u)) : B;
-    if (h->grid_override > 0) grid = std::min<uint32_t>(grid, (uint32_t)h->grid_override);
-    if (h->time_launches) HIP_TRY(h, hipEventRecord(h->ev0, st));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, st, view(h), dQ, B, k, h->efc, (1u << BB) * 6u, idbits, d_ids, d_sims,
-                       d_nout);
-    HIP_TRY(h, hipGetLastError());
-    if (h->time_launches) {
-        HIP_TRY(h, hipEventRecord(h->ev1, st));
-        h->ev_valid = true;
-    }
-    return note_search(h, st);                           // inserts wait for searches in flight
+    const int R = pick_R(h->efc);
+    if (!h->lean) return "tuning lean = 0";
+    if (h->mode != MODE_AVX || h->dim != 128) return "dim != 128";
+    if (!h->visited_bounded) return "tuning visited_bounded = 0";
+    if (!h->tag_table || h->tag_bb_override >= 0 || h->lds_buckets_override >= 0) return "visited-table test overrides (tag_table / tag_bb / lds_buckets)";
+    if (h->stride0 > 64 || h->strideU > 64) return "adjacency rows wider than 63 ids (M > 16, or widened by a restride)";
+    if (R != 1 && R != 4) return "ef_construction > 256";
+    // 16-bit entries: tag (idbits - bb bits) + >= 2 displacement bits; bb is 10 or 11 (9 with waves_per_cu > 8)
+    uint32_t idbits = std::max(ceil_log2(std::max(h->cap, 2u)), 11u);
+    if (h->idbits_override > (int)idbits && h->idbits_override <= 31) idbits = (uint32_t)h->idbits_override;
+    if (idbits - (h->max_waves_per_cu > 8 ? 9u : 10u) > 14) return "more than 2^24 node ids";
+    return nullptr;
 }
 
 // returns HNSW_OK and sets *done when the specialised kernel was launched
@@ -561,10 +402,8 @@ hnsw_status try_launch_lean(hnsw_index *h, const float *dQ, uint32_t B, uint32_t
 {
     *done = false;
     const int R = pick_R(h->efc);
-    if (!h->lean || h->mode != MODE_AVX || h->dim != 128 || !h->visited_bounded || !h->tag_table || h->tag_bb_override >= 0 ||
-        h->lds_buckets_override >= 0 || h->stride0 > 64 || h->strideU > 64 || (R != 1 && R != 4))
-        return HNSW_OK;
-    uint32_t per_cu = ((uint64_t)B * h->launch_concurrency + 255) / 256;
+    if (lean_blocker(h)) return HNSW_OK;
+    uint32_t per_cu = ((uint64_t)B * std::max(h->cur_conc, 1u) + 255) / 256;
     per_cu = std::min(std::max(per_cu, 1u), h->max_waves_per_cu);
     // 32 KB table at <= 4 waves per CU, 16 KB at <= 8, 8 KB beyond (tuning waves_per_cu > 8)
     uint32_t bb = per_cu >= 9 ? 9 : (per_cu >= 5 ? 10 : 11);
@@ -578,17 +417,24 @@ hnsw_status try_launch_lean(hnsw_index *h, const float *dQ, uint32_t B, uint32_t
         if (idbits - bb == 14) db = 2;
         else return HNSW_OK;
     }
-    *done = true;
-#define LEAN_CASE(RR, BBB, DDB)                                                                                  \
-    if (R == RR && bb == BBB && db == DDB)                                                                      \
-        return h->bf16 ? launch_lean_t<VecBF16<4>, RR, BBB, DDB>(h, dQ, B, k, idbits, per_cu, d_ids, d_sims, d_nout, st) \
-                       : launch_lean_t<VecF32<4>, RR, BBB, DDB>(h, dQ, B, k, idbits, per_cu, d_ids, d_sims, d_nout, st);
-    LEAN_CASE(1, 10, 3) LEAN_CASE(1, 11, 3) LEAN_CASE(4, 10, 3) LEAN_CASE(4, 11, 3)
-    LEAN_CASE(1, 10, 2) LEAN_CASE(1, 11, 2) LEAN_CASE(4, 10, 2) LEAN_CASE(4, 11, 2)
-    LEAN_CASE(1, 9, 3) LEAN_CASE(4, 9, 3)
-#undef LEAN_CASE
-    *done = false;
-    return HNSW_OK;
+    return h->bf16 ? launch_lean_v<VecBF16<4>>(h, R, bb, db, dQ, B, k, idbits, per_cu, d_ids, d_sims, d_nout, st, done)
+                   : launch_lean_v<VecF32<4>>(h, R, bb, db, dQ, B, k, idbits, per_cu, d_ids, d_sims, d_nout, st, done);
+}
+
+// How many search launches share the CUs with the one about to be enqueued on `st` (it sizes the LDS visited
+// table: 32 KB at <= 4 waves per CU, 16 KB at <= 8).  The engine's own pipeline knows (pipe_inflight); an
+// explicit "launch_concurrency" tuning is taken as the caller's promise; otherwise it is observed: this launch
+// plus every OTHER stream whose latest search has not finished yet (launches on one stream run one after the
+// other).  A wrong guess costs speed only, never exactness.
+uint32_t search_concurrency(hnsw_index *h, hipStream_t st)
+{
+    if (h->pipe_inflight > 1) return std::max(h->pipe_inflight, h->launch_concurrency);
+    if (h->launch_concurrency) return h->launch_concurrency;
+    uint32_t n = 1;
+    for (uint32_t i = 0; i < hnsw_index::kSearchStreams; ++i)
+        if (h->search_busy[i] && h->search_st[i] != st && hipEventQuery(h->search_ev[i]) == hipErrorNotReady) ++n;
+    (void)hipGetLastError();                           // hipErrorNotReady is an answer, not a failure
+    return std::min(n, 8u);
 }
 
 hnsw_status launch_search(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t *d_ids,
@@ -596,14 +442,227 @@ hnsw_status launch_search(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k
 {
     hnsw_status s = ensure_spill(h);
     if (s != HNSW_OK) return s;
+    h->cur_conc = search_concurrency(h, st);
     bool done = false;
-    if ((s = try_launch_lean(h, dQ, B, k, d_ids, d_sims, d_nout, st, &done)) != HNSW_OK || done) return s;
-    if (h->bf16) return fail(h, HNSW_ERR_INVALID, "bf16 storage is served by the specialised kernel only (dim 128, rows <= 63 ids, ef <= 256, default tuning)");
+    h->last_search_lean = false;
+    if ((s = try_launch_lean(h, dQ, B, k, d_ids, d_sims, d_nout, st, &done)) != HNSW_OK) return s;
+    if (done) { h->last_search_lean = true; return HNSW_OK; }
+    if (h->bf16) return fail(h, HNSW_ERR_INVALID, std::string("bf16 storage is served by the specialised kernel only: ") + (lean_blocker(h) ? lean_blocker(h) : "launch shape"));
     const int R = pick_R(h->efc);
-    if (h->mode == MODE_SCALAR) return launch_search_r<MODE_SCALAR, 0>(h, R, dQ, B, k, d_ids, d_sims, d_nout, st);
-    if (h->T == 4) return launch_search_r<MODE_AVX, 4>(h, R, dQ, B, k, d_ids, d_sims, d_nout, st);
-    if (h->T == 24) return launch_search_r<MODE_AVX, 24>(h, R, dQ, B, k, d_ids, d_sims, d_nout, st);
-    return launch_search_r<MODE_AVX, 0>(h, R, dQ, B, k, d_ids, d_sims, d_nout, st);
+    if (h->mode == MODE_SCALAR) s = launch_search_r<MODE_SCALAR, 0>(h, R, dQ, B, k, d_ids, d_sims, d_nout, st);
+    else if (h->T == 4) s = launch_search_r<MODE_AVX, 4>(h, R, dQ, B, k, d_ids, d_sims, d_nout, st);
+    else if (h->T == 24) s = launch_search_r<MODE_AVX, 24>(h, R, dQ, B, k, d_ids, d_sims, d_nout, st);
+    else s = launch_search_r<MODE_AVX, 0>(h, R, dQ, B, k, d_ids, d_sims, d_nout, st);
+    return s != HNSW_OK ? s : note_search(h, st);
+}
+
+// ---- the engine's own search pipeline --------------------------------------------------------------------
+// A batch larger than one chunk is split into chunks that run round-robin on kPipe lanes: lane 0 is the stream
+// the call is ordered on (the engine's for the host-buffer form, the caller's for the _device form), lanes
+// 1.. are engine-owned streams.  Several chunks in flight keep the chip's 2048 wave slots full while the long
+// queries of a chunk drain; in the host-buffer form a lane's H2D copy, kernel and D2H copy also
+// overlap the other lanes', and the host stages chunk i+1 into pinned memory while chunk i runs.
+// Lanes only overlap if each sits on a hardware queue of its own.  The HIP runtime hands new streams distinct
+// queues until GPU_MAX_HW_QUEUES (default 4) are in use and multiplexes after that; the library asks for 8 in
+// its load-time constructor (effective when it is loaded before the runtime starts), and -- because that cannot
+// be relied on -- MEASURES the overlap when the lanes are created: a spin kernel on one lane against the same
+// kernel on all lanes at once.  Lanes that serialise are re-created with distinct stream priorities (each
+// priority level has its own queue pool) and measured again; what was found is reported by
+// hnsw_pipeline_info(), printed once on stderr when the lanes still serialise, and fatal under
+// HNSW_REQUIRE_OVERLAP=1.
+__global__ void k_spin(unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+hnsw_status pipe_probe(hnsw_index *h, float *ratio)
+{
+    auto lane = [&](uint32_t l) { return l == 0 ? h->stream : h->pipe_st[l]; };
+    auto run = [&](uint32_t nl, double *secs) -> hnsw_status {
+        for (uint32_t l = 0; l < hnsw_index::kPipe; ++l) HIP_TRY(h, hipStreamSynchronize(lane(l)));
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t l = 0; l < nl; ++l) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, lane(l), 20000ull);   // 200 us at 100 MHz
+        HIP_TRY(h, hipGetLastError());
+        for (uint32_t l = 0; l < nl; ++l) HIP_TRY(h, hipStreamSynchronize(lane(l)));
+        *secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return HNSW_OK;
+    };
+    double t1 = 0, tn = 0, scratch = 0;
+    hnsw_status s;
+    if ((s = run(hnsw_index::kPipe, &scratch)) != HNSW_OK) return s;   // first launch loads the code object
+    if ((s = run(1, &t1)) != HNSW_OK || (s = run(hnsw_index::kPipe, &tn)) != HNSW_OK) return s;
+    *ratio = (float)(tn / std::max(t1, 1e-9));
+    return HNSW_OK;
+}
+
+hnsw_status ensure_pipe(hnsw_index *h)
+{
+    if (h->pipe_overlap >= 0) return HNSW_OK;
+    for (uint32_t l = 1; l < hnsw_index::kPipe; ++l) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->pipe_st[l], hipStreamNonBlocking));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_done[l], hipEventDisableTiming));
+    }
+    HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_done[0], hipEventDisableTiming));
+    HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_fork, hipEventDisableTiming));
+    float ratio = 0.f;
+    hnsw_status s = pipe_probe(h, &ratio);
+    if (s != HNSW_OK) return s;
+    if (ratio > 1.6f) {
+        // the lanes share a hardware queue: one stream per priority level instead
+        int least = 0, greatest = 0;
+        HIP_TRY(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        if (least != greatest) {
+            for (uint32_t l = 1; l < hnsw_index::kPipe; ++l) {
+                HIP_TRY(h, hipStreamDestroy(h->pipe_st[l]));
+                h->pipe_st[l] = nullptr;
+                HIP_TRY(h, hipStreamCreateWithPriority(&h->pipe_st[l], hipStreamNonBlocking, l == 1 ? greatest : least));
+            }
+            h->pipe_prio = true;
+            if ((s = pipe_probe(h, &ratio)) != HNSW_OK) return s;
+        }
+    }
+    h->pipe_probe_ratio = ratio;
+    h->pipe_overlap = ratio <= 1.6f ? 1 : 0;
+    if (!h->pipe_overlap) {
+        static bool warned = false;
+        if (!warned) {
+            warned = true;
+            fprintf(stderr, "libhnsw_mi355x: the search pipeline's %u streams do not overlap (probe ratio %.2f): hardware queues are "
+                            "shared -- export GPU_MAX_HW_QUEUES=8 before the HIP runtime starts; batched searches run at about "
+                            "2/3 of their throughput until then\n", hnsw_index::kPipe, (double)ratio);
+        }
+        if (std::getenv("HNSW_REQUIRE_OVERLAP"))
+            return fail(h, HNSW_ERR_DEVICE, "search pipeline streams share a hardware queue (HNSW_REQUIRE_OVERLAP is set)");
+    }
+    return HNSW_OK;
+}
+
+hnsw_status ensure_pipe_stage(hnsw_index *h, uint32_t chunk, uint32_t k)
+{
+    const size_t nq = (size_t)chunk * h->dim, nr = 2 * (size_t)chunk * k + chunk;
+    if (nq <= h->pipe_q_words && nr <= h->pipe_r_words) return HNSW_OK;
+    const size_t wq = std::max(nq, h->pipe_q_words), wr = std::max(nr, h->pipe_r_words);
+    for (uint32_t l = 0; l < hnsw_index::kPipe; ++l) {
+        hipStream_t st = l == 0 ? h->stream : h->pipe_st[l];
+        HIP_TRY(h, hipStreamSynchronize(st));
+        dev_free(h, h->pipe_dq[l], h->pipe_q_words);
+        dev_free(h, h->pipe_dres[l], h->pipe_r_words);
+        if (h->pipe_hq[l]) (void)hipHostFree(h->pipe_hq[l]);
+        if (h->pipe_hres[l]) (void)hipHostFree(h->pipe_hres[l]);
+        h->pipe_hq[l] = nullptr; h->pipe_hres[l] = nullptr;
+    }
+    h->pipe_q_words = h->pipe_r_words = 0;
+    hnsw_status s;
+    for (uint32_t l = 0; l < hnsw_index::kPipe; ++l) {
+        if ((s = dev_alloc(h, &h->pipe_dq[l], wq)) != HNSW_OK || (s = dev_alloc(h, &h->pipe_dres[l], wr)) != HNSW_OK) return s;
+        HIP_TRY(h, hipHostMalloc((void **)&h->pipe_hq[l], wq * 4, hipHostMallocDefault));
+        HIP_TRY(h, hipHostMalloc((void **)&h->pipe_hres[l], wr * 4, hipHostMallocDefault));
+    }
+    h->pipe_q_words = wq;
+    h->pipe_r_words = wr;
+    return HNSW_OK;
+}
+
+// chunk sizes: as few chunks of <= pipe_chunk queries as cover the batch, equal to within one query
+inline uint32_t pipe_chunks(const hnsw_index *h, uint32_t B, uint32_t *per)
+{
+    const uint32_t n = (B + h->pipe_chunk - 1) / h->pipe_chunk;
+    *per = (B + n - 1) / n;
+    return n;
+}
+
+// copy while checking: the host entry points refuse non-finite components (see all_finite)
+bool copy_finite(float *dst, const float *src, size_t n)
+{
+    uint32_t bad = 0;
+    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+    uint32_t *d32 = reinterpret_cast<uint32_t *>(dst);
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t u = s32[i];
+        d32[i] = u;
+        bad |= ((u & 0x7F800000u) == 0x7F800000u) ? 1u : 0u;
+    }
+    return bad == 0;
+}
+
+// hnsw_search_batch for B > kPinnedBatch: chunks through pinned staging on the lanes, copies and kernels overlapped
+hnsw_status search_batch_pipelined(hnsw_index *h, const float *Q, uint32_t B, uint32_t k, uint32_t *ids, float *sims,
+                                   uint32_t *n_out)
+{
+    hnsw_status s;
+    if ((s = ensure_pipe(h)) != HNSW_OK) return s;
+    uint32_t per = 0;
+    const uint32_t nch = pipe_chunks(h, B, &per);
+    if ((s = ensure_pipe_stage(h, per, k)) != HNSW_OK) return s;
+    const uint32_t lanes = std::min(nch, hnsw_index::kPipe);
+    auto lane_st = [&](uint32_t l) { return l == 0 ? h->stream : h->pipe_st[l]; };
+    // the graph was written on the engine's stream: the other lanes start after it
+    if (lanes > 1) {
+        HIP_TRY(h, hipEventRecord(h->ev_sync, h->stream));
+        for (uint32_t l = 1; l < lanes; ++l) HIP_TRY(h, hipStreamWaitEvent(h->pipe_st[l], h->ev_sync, 0));
+    }
+    h->pipe_inflight = lanes;
+    struct Restore { hnsw_index *h; ~Restore() { h->pipe_inflight = 1; } } restore{h};
+    bool overflow = false;
+    auto collect = [&](uint32_t c) -> hnsw_status {       // chunk c's results: pinned -> the caller's buffers
+        const uint32_t l = c % hnsw_index::kPipe, off = c * per, cb = std::min(per, B - off);
+        HIP_TRY(h, hipEventSynchronize(h->pipe_done[l]));
+        const uint32_t *r = h->pipe_hres[l];
+        const size_t nk = (size_t)cb * k;
+        std::memcpy(ids + (size_t)off * k, r, nk * 4);
+        std::memcpy(sims + (size_t)off * k, r + nk, nk * 4);
+        std::memcpy(n_out + off, r + 2 * nk, (size_t)cb * 4);
+        for (uint32_t b = 0; b < cb; ++b) overflow |= n_out[off + b] == kEmpty;
+        return HNSW_OK;
+    };
+    for (uint32_t c = 0; c < nch; ++c) {
+        const uint32_t l = c % hnsw_index::kPipe, off = c * per, cb = std::min(per, B - off);
+        if (c >= hnsw_index::kPipe && (s = collect(c - hnsw_index::kPipe)) != HNSW_OK) return s;   // frees lane l's staging
+        const size_t nq = (size_t)cb * h->dim, nk = (size_t)cb * k;
+        if (!copy_finite(h->pipe_hq[l], Q + (size_t)off * h->dim, nq)) {
+            for (uint32_t d = 0; d < lanes; ++d) (void)hipStreamSynchronize(lane_st(d));
+            return fail(h, HNSW_ERR_INVALID, "non-finite query component");
+        }
+        hipStream_t st = lane_st(l);
+        HIP_TRY(h, hipMemcpyAsync(h->pipe_dq[l], h->pipe_hq[l], nq * 4, hipMemcpyHostToDevice, st));
+        uint32_t *d_ids = h->pipe_dres[l], *d_nout = h->pipe_dres[l] + 2 * nk;
+        float *d_sims = reinterpret_cast<float *>(h->pipe_dres[l] + nk);
+        if ((s = launch_search(h, h->pipe_dq[l], cb, k, d_ids, d_sims, d_nout, st)) != HNSW_OK) return s;
+        HIP_TRY(h, hipMemcpyAsync(h->pipe_hres[l], h->pipe_dres[l], (2 * nk + cb) * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipEventRecord(h->pipe_done[l], st));
+    }
+    for (uint32_t c = nch > hnsw_index::kPipe ? nch - hnsw_index::kPipe : 0; c < nch; ++c)
+        if ((s = collect(c)) != HNSW_OK) return s;
+    if (overflow) return fail(h, HNSW_ERR_CAPACITY, "visited-set spill table overflow");
+    return HNSW_OK;
+}
+
+// hnsw_search_batch_device for large batches: chunks on the caller's stream (lane 0) and the engine's lanes,
+// joined back into the caller's stream before returning (nothing is synchronised)
+hnsw_status search_device_pipelined(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t *d_ids, float *d_sims,
+                                    uint32_t *d_nout, hipStream_t st)
+{
+    hnsw_status s;
+    if ((s = ensure_pipe(h)) != HNSW_OK) return s;
+    uint32_t per = 0;
+    const uint32_t nch = pipe_chunks(h, B, &per);
+    const uint32_t lanes = std::min(nch, hnsw_index::kPipe);
+    HIP_TRY(h, hipEventRecord(h->pipe_fork, st));        // inputs are ready in `st` order; so is the graph (ev_sync above)
+    for (uint32_t l = 1; l < lanes; ++l) HIP_TRY(h, hipStreamWaitEvent(h->pipe_st[l], h->pipe_fork, 0));
+    h->pipe_inflight = lanes;
+    struct Restore { hnsw_index *h; ~Restore() { h->pipe_inflight = 1; } } restore{h};
+    for (uint32_t c = 0; c < nch; ++c) {
+        const uint32_t l = c % hnsw_index::kPipe, off = c * per, cb = std::min(per, B - off);
+        if ((s = launch_search(h, dQ + (size_t)off * h->dim, cb, k, d_ids + (size_t)off * k, d_sims + (size_t)off * k,
+                               d_nout + off, l == 0 ? st : h->pipe_st[l])) != HNSW_OK)
+            return s;
+    }
+    for (uint32_t l = 1; l < lanes; ++l) {
+        HIP_TRY(h, hipEventRecord(h->pipe_done[l], h->pipe_st[l]));
+        HIP_TRY(h, hipStreamWaitEvent(st, h->pipe_done[l], 0));
+    }
+    return HNSW_OK;
 }
 
 // Staging of the host-buffer entry points: queries in, one result block [ids B*k][sims B*k][n_out B] out
@@ -624,7 +683,7 @@ hnsw_status ensure_stage(hnsw_index *h, uint32_t B, uint32_t k)
         h->stage_r = nr;
     }
     const size_t pin_words = nq + nr;
-    if (B <= kPinnedBatch && pin_words > h->pinned_words) {
+    if (pin_words > h->pinned_words) {
         if (h->h_pinned) (void)hipHostFree(h->h_pinned);
         h->h_pinned = nullptr;
         h->pinned_words = 0;
@@ -684,7 +743,9 @@ hnsw_status check_dev_status(hnsw_index *h, const DevHeader &hd)
 
 #include "hnsw_insert_host.inc"
 
-} // namespace
+} // namespace hnsw_host
+
+using namespace hnsw_host;
 
 // ===========================================================================
 // C ABI
@@ -747,6 +808,14 @@ void hnsw_destroy(hnsw_index *h)
     (void)hipFree(h->d_upper_base); (void)hipFree(h->d_levels); (void)hipFree(h->d_hdr);
     (void)hipFree(h->d_spill); (void)hipFree(h->d_spill_one); (void)hipFree(h->d_Q); (void)hipFree(h->d_res);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+    for (uint32_t l = 0; l < hnsw_index::kPipe; ++l) {
+        if (h->pipe_st[l]) { (void)hipStreamSynchronize(h->pipe_st[l]); (void)hipStreamDestroy(h->pipe_st[l]); }
+        if (h->pipe_done[l]) (void)hipEventDestroy(h->pipe_done[l]);
+        (void)hipFree(h->pipe_dq[l]); (void)hipFree(h->pipe_dres[l]);
+        if (h->pipe_hq[l]) (void)hipHostFree(h->pipe_hq[l]);
+        if (h->pipe_hres[l]) (void)hipHostFree(h->pipe_hres[l]);
+    }
+    if (h->pipe_fork) (void)hipEventDestroy(h->pipe_fork);
     (void)hipFree(h->d_plan); (void)hipFree(h->d_touched); (void)hipFree(h->d_work);
     (void)hipFree(h->d_occ_slots); (void)hipFree(h->d_occ_reads); (void)hipFree(h->d_occ_shr); (void)hipFree(h->d_occ_ring); (void)hipFree(h->d_occ_ctl);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -763,6 +832,15 @@ const char *hnsw_last_error(const hnsw_index *h) { return h ? h->err.c_str() : "
 hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
 {
     if (!h || !key) return HNSW_ERR_INVALID;
+    if (h->bf16) {
+        // a bf16 index is served by the specialised kernel only: knobs that would take it away are refused
+        const bool off = (!std::strcmp(key, "lean") && !value) || (!std::strcmp(key, "visited_bounded") && !value) ||
+                         (!std::strcmp(key, "tag_table") && !value) || (!std::strcmp(key, "tag_bb") && value >= 0) ||
+                         (!std::strcmp(key, "lds_buckets") && value >= 0) || !std::strcmp(key, "lds_hash_bits") ||
+                         (!std::strcmp(key, "idbits") && value > 24) || (!std::strcmp(key, "waves_per_cu") && value > 8) ||
+                         !std::strcmp(key, "force_restride") || !std::strcmp(key, "query_in_lds");
+        if (off) return fail(h, HNSW_ERR_INVALID, std::string("tuning ") + key + " is refused on a bf16 index (it would leave it without a search kernel)");
+    }
     if (!std::strcmp(key, "force_restride")) {   // tests: widen both adjacency tables by `value` words now
         HIP_TRY(h, hipSetDevice(h->device));
         return restride(h, h->stride0 + (uint32_t)value, h->strideU + (uint32_t)value);
@@ -775,14 +853,19 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
     if (!std::strcmp(key, "lds_hash_bits")) { h->lds_buckets_override = std::max<int>(2, (int)((1ll << value) / 8)); return HNSW_OK; }
     if (!std::strcmp(key, "grid")) { h->grid_override = (int)value; return HNSW_OK; }
     if (!std::strcmp(key, "time_launches")) { h->time_launches = value != 0; return HNSW_OK; }
-    if (!std::strcmp(key, "launch_concurrency")) { h->launch_concurrency = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 8); return HNSW_OK; }
+    if (!std::strcmp(key, "launch_concurrency")) { h->launch_concurrency = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 8); return HNSW_OK; }
+    if (!std::strcmp(key, "pipe_chunk")) { h->pipe_chunk = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 64), 1 << 20); return HNSW_OK; }
+    if (!std::strcmp(key, "pipe_min_batch")) { h->pipe_min_batch = (uint32_t)std::max<int64_t>(value, 2); return HNSW_OK; }
+    if (!std::strcmp(key, "pipe_device")) { h->pipe_device = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "compress_bf16")) {
         // One way: the f32 vector matrix becomes a bf16 one (round to nearest even) and the index read-only.
         // A separate, clearly-labelled serving mode: half the bytes of the gather; the
         // arithmetic stays the reference's f32 kernel on the stored values, so results are those of the
         // reference run on the bf16-rounded vectors (not on the original f32 ones).
         if (!value || h->bf16) return HNSW_OK;
-        if (h->mode != MODE_AVX || h->dim != 128) return fail(h, HNSW_ERR_INVALID, "compress_bf16 supports dim 128");
+        // only the specialised kernel reads bf16 rows: refuse, with the index untouched, unless it can serve this index
+        if (const char *why = lean_blocker(h))
+            return fail(h, HNSW_ERR_INVALID, std::string("compress_bf16 needs the specialised dim-128 search kernel, which this index cannot use: ") + why);
         HIP_TRY(h, hipSetDevice(h->device));
         HIP_TRY(h, hipDeviceSynchronize());
         unsigned short *d16 = nullptr;
@@ -991,6 +1074,7 @@ hnsw_status hnsw_search_batch_device(hnsw_index *h, const float *dQ, uint32_t B,
         HIP_TRY(h, hipGetLastError());
         return HNSW_OK;
     }
+    if (h->pipe_device && B >= h->pipe_min_batch) return search_device_pipelined(h, dQ, B, k, d_ids, d_sims, d_n_out, st);
     return launch_search(h, dQ, B, k, d_ids, d_sims, d_n_out, st);
 }
 
@@ -1005,35 +1089,29 @@ hnsw_status hnsw_search_batch(hnsw_index *h, const float *Q, uint32_t B, uint32_
     }
     if (B == 0) return HNSW_OK;
     if (k == 0) return fail(h, HNSW_ERR_INVALID, "k must be >= 1");
-    if (!all_finite(Q, (size_t)B * dim)) return fail(h, HNSW_ERR_INVALID, "non-finite query component");
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->n == h->n_dead || h->enterpoint < 0) {
+        if (!all_finite(Q, (size_t)B * dim)) return fail(h, HNSW_ERR_INVALID, "non-finite query component");
         for (uint32_t b = 0; b < B; ++b) n_out[b] = 0;
         return HNSW_OK;
     }
+    if (B > kPinnedBatch) return search_batch_pipelined(h, Q, B, k, ids, sims, n_out);   // checks finiteness while staging
+    // HNSW.SEARCH-sized calls: one launch on the engine's stream through one pinned block
+    if (!all_finite(Q, (size_t)B * dim)) return fail(h, HNSW_ERR_INVALID, "non-finite query component");
     hnsw_status s = ensure_stage(h, B, k);
     if (s != HNSW_OK) return s;
     const size_t nq = (size_t)B * dim, nk = (size_t)B * k;
     uint32_t *d_ids = h->d_res, *d_nout = h->d_res + 2 * nk;
     float *d_sims = reinterpret_cast<float *>(h->d_res + nk);
-    const bool pinned = B <= kPinnedBatch;
-    const void *src = Q;
-    if (pinned) { std::memcpy(h->h_pinned, Q, nq * 4); src = h->h_pinned; }
-    HIP_TRY(h, hipMemcpyAsync(h->d_Q, src, nq * 4, hipMemcpyHostToDevice, h->stream));
+    std::memcpy(h->h_pinned, Q, nq * 4);
+    HIP_TRY(h, hipMemcpyAsync(h->d_Q, h->h_pinned, nq * 4, hipMemcpyHostToDevice, h->stream));
     if ((s = launch_search(h, h->d_Q, B, k, d_ids, d_sims, d_nout, h->stream)) != HNSW_OK) return s;
-    if (pinned) {
-        uint32_t *back = h->h_pinned + nq;
-        HIP_TRY(h, hipMemcpyAsync(back, h->d_res, (2 * nk + B) * 4, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        std::memcpy(ids, back, nk * 4);
-        std::memcpy(sims, back + nk, nk * 4);
-        std::memcpy(n_out, back + 2 * nk, (size_t)B * 4);
-    } else {
-        HIP_TRY(h, hipMemcpyAsync(ids, d_ids, nk * 4, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(sims, d_sims, nk * 4, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(n_out, d_nout, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-    }
+    uint32_t *back = h->h_pinned + nq;
+    HIP_TRY(h, hipMemcpyAsync(back, h->d_res, (2 * nk + B) * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::memcpy(ids, back, nk * 4);
+    std::memcpy(sims, back + nk, nk * 4);
+    std::memcpy(n_out, back + 2 * nk, (size_t)B * 4);
     for (uint32_t b = 0; b < B; ++b)
         if (n_out[b] == kEmpty) return fail(h, HNSW_ERR_CAPACITY, "visited-set spill table overflow");
     return HNSW_OK;
@@ -1449,6 +1527,35 @@ hnsw_status hnsw_debug_phase_cycles(hnsw_index *h, uint64_t *out8)
     DevHeader hd;
     HIP_TRY(h, hipMemcpy(&hd, h->d_hdr, sizeof hd, hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; ++i) out8[i] = hd.prof[i];
+    return HNSW_OK;
+}
+
+// The search pipeline wants a hardware queue per lane; the HIP runtime reads GPU_MAX_HW_QUEUES once, when it
+// starts.  A process that loads this library before touching HIP (a Redis module does) gets 8 without exporting
+// anything; a value the operator set is left alone, and ensure_pipe() measures what the lanes really got.
+__attribute__((constructor)) static void hnsw_library_loaded() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
+hnsw_status hnsw_pipeline_info(hnsw_index *h, hnsw_pipeline *out)
+{
+    if (!h || !out) return HNSW_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hnsw_status s = ensure_pipe(h);
+    out->lanes = hnsw_index::kPipe;
+    out->overlap = h->pipe_overlap;
+    out->probe_ratio = h->pipe_probe_ratio;
+    out->priorities = h->pipe_prio ? 1u : 0u;
+    out->chunk = h->pipe_chunk;
+    out->min_batch = h->pipe_min_batch;
+    const char *e = std::getenv("GPU_MAX_HW_QUEUES");
+    out->hw_queues_env = e ? (uint32_t)std::atoi(e) : 0u;
+    return s;
+}
+
+// 1 when the latest search launch was the specialised dim-128 kernel's, 0 the general one's (not in the public header)
+hnsw_status hnsw_debug_last_search_path(hnsw_index *h, uint32_t *lean)
+{
+    if (!h || !lean) return HNSW_ERR_INVALID;
+    *lean = h->last_search_lean ? 1u : 0u;
     return HNSW_OK;
 }
 

@@ -1,0 +1,216 @@
+// hnsw_host.hpp -- what the translation units of libhnsw_mi355x.so share on the host side: the handle, the
+// helpers the kernel launchers need, and the launchers' declarations.  The library is built from one
+// translation unit per kernel family and metric variant (redis_hnsw_amd/build.py compiles them in parallel):
+//   hnsw_engine.hip      C ABI, capacity / staging / pipeline bookkeeping, the small utility kernels
+//   hnsw_tu_search.hip   k_search<MODE,T,R>                    (general search kernel)         x 4 variants
+//   hnsw_tu_lean.hip     k_search_lean<VEC,R,BB,DB>            (dim-128 specialisation)        x 2 variants
+//   hnsw_tu_insert.hip   k_insert_plan / k_insert_commit_exact / k_delete_exact / k_shrink_batch x 4 variants
+//   hnsw_tu_occ.hip      k_occ_validate / plan / shrinks / commit                              x 4 variants
+// A variant is one (metric order, query placement) pair, HNSW_VARIANT = 0..3:
+//   0 MODE_SCALAR,T=0   1 MODE_AVX,T=4 (dim 128)   2 MODE_AVX,T=24 (dim 768)   3 MODE_AVX,T=0 (any dim % 32 == 0)
+// Each launcher template is defined in its family's file and explicitly instantiated there for the variant
+// being compiled; the engine only sees the declarations below.
+#pragma once
+#include "../../include/hnsw_mi355x.h"
+#include "hnsw_occ.hpp"   // -> hnsw_insert.hpp -> hnsw_device.hpp (types and constants; kernels are templates)
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <vector>
+
+struct hnsw_index {
+    uint32_t dim = 0, m = 0, m_max = 0, m_max0 = 0, efc = 0;
+    double level_mult = 0;
+    int device = 0;
+    int mode = hnsw::MODE_AVX, T = 0;
+    uint32_t cap = 0, n = 0, max_layer = 0;
+    int64_t enterpoint = -1;
+    uint32_t stride0 = 0, strideU = 0, upper_cap = 0, upper_used = 0;
+    uint32_t max_deg0 = 0, max_degU = 0;
+    float *d_vec = nullptr;
+    uint32_t *d_adj0 = nullptr, *d_adjU = nullptr, *d_upper_base = nullptr, *d_levels = nullptr;
+    hnsw::DevHeader *d_hdr = nullptr;
+    std::vector<uint32_t> h_levels, h_upper_base;
+    std::vector<uint8_t> h_dead;   // tombstones (HNSW.NODE.DEL); ids are never reused
+    uint32_t n_dead = 0;
+    // search scratch
+    // HBM spill tables of the visited sets: kSpillRegions regions, handed out round-robin so that
+    // launches overlapping on different streams never share one (an event per region orders reuse)
+    uint32_t *d_spill = nullptr;
+    uint32_t *d_spill_one = nullptr;   // one table for the single-wave exact insert / delete kernels: holds every id of the index
+    uint32_t spill_one_gnb = 0;
+    uint32_t spill_gnb = 0, spill_slots = 0;
+    hipEvent_t spill_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool spill_busy[4] = {false, false, false, false};
+    // the specialised search kernel uses no spill region: one "last search" event per caller stream instead
+    static constexpr uint32_t kSearchStreams = 16;
+    hipEvent_t search_ev[kSearchStreams] = {};
+    hipStream_t search_st[kSearchStreams] = {};
+    bool search_busy[kSearchStreams] = {};
+    uint32_t search_rr = 0;
+    uint32_t spill_rr = 0;
+    // ---- the search pipeline (hnsw_search_batch / hnsw_search_batch_device): kPipe engine-owned streams,
+    // each with its own staging (device queries + results, pinned host mirrors) and fork / join events
+    static constexpr uint32_t kPipe = 3;
+    hipStream_t pipe_st[kPipe] = {};
+    hipEvent_t pipe_done[kPipe] = {};      // recorded after a lane's last operation of a call
+    hipEvent_t pipe_fork = nullptr;        // the caller's stream at entry (_device form)
+    float *pipe_dq[kPipe] = {};            // device queries of one chunk
+    uint32_t *pipe_dres[kPipe] = {};       // device [ids c*k][sims c*k][n_out c]
+    float *pipe_hq[kPipe] = {};            // pinned mirrors
+    uint32_t *pipe_hres[kPipe] = {};
+    size_t pipe_q_words = 0, pipe_r_words = 0;
+    uint32_t pipe_chunk = 1024;            // queries per chunk (tuning "pipe_chunk")
+    uint32_t pipe_min_batch = 1536;        // batches at least this large are pipelined (tuning "pipe_min_batch")
+    int pipe_overlap = -1;                 // measured at first use: 1 the lanes run concurrently, 0 they serialise (hardware queues alias)
+    float pipe_probe_ratio = 0.f;          // (all lanes together) / (one lane alone), spin-kernel probe
+    bool pipe_prio = false;                // lanes were re-created with distinct priorities to get queues of their own
+    float *d_Q = nullptr;
+    uint32_t *d_res = nullptr;       // [ids B*k][sims B*k][n_out B] of the host-buffer entry points
+    size_t stage_q = 0, stage_r = 0;
+    uint32_t *h_pinned = nullptr;    // pinned mirror for batches <= kPinnedBatch
+    size_t pinned_words = 0;
+    // insert scratch
+    uint32_t *d_plan = nullptr;     // [plan_slots][kMaxLayers][1 + 64]
+    uint32_t plan_slots = 0;
+    uint32_t *d_touched = nullptr;  // exact insert touched list
+    uint32_t touched_cap = 0;
+    uint32_t *d_work = nullptr;     // fast build: shrink worklist
+    // exact-order parallel insert (hnsw_occ.hpp)
+    hnsw::OccSlot *d_occ_slots = nullptr;
+    hnsw::OccRead *d_occ_reads = nullptr;
+    hnsw::OccShr *d_occ_shr = nullptr;
+    hnsw::OccDelta *d_occ_ring = nullptr;
+    hnsw::OccCtl *d_occ_ctl = nullptr;
+    uint32_t occ_window = 32;       // tuning: window slots (0 = the serial path only)
+    uint32_t occ_min_batch = 64;    // batches smaller than this take the serial path
+    uint32_t occ_log_cap = hnsw::kOccMaxReads;   // tests: a tiny read log sends every node of the window to the serial kernels
+    uint32_t occ_slack_extra = 0;   // tests: demand this much more free room per row (exercises the restride stop)
+    uint32_t occ_ahead_x10 = 15;    // tuning: look-ahead = this/10 x running yield + 3
+    double occ_yield = 4.0;         // commits per round, running average (sizes the look-ahead)
+    uint64_t occ_rounds = 0;
+    hnsw::OccCtl occ_last = {};     // counters of the last windowed build (hnsw_debug_occ)
+    uint32_t work_cap = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_sync = nullptr;
+    bool ev_valid = false;
+    bool time_launches = false;     // tuning: bracket every search launch with events (hnsw_last_search_kernel_ms)
+    int lds_buckets_override = -1;
+    bool tag_table = true;          // 16-bit tag visited table when the id range allows it
+    int tag_bb_override = -1;       // tests: force log2(buckets) of the tag table
+    int idbits_override = -1;       // tests: hash ids as an index of 2^idbits nodes would
+    bool asymmetric = false;        // links may be one-directional (the fast build prunes that way; imports are checked)
+    uint32_t lds_fill_x2 = 13;       // LDS visited table holds lnb * fill/2 ids (of 7 per bucket) before spilling
+    int grid_override = -1;
+    bool bf16 = false;               // vectors are stored as bf16 (compress_bf16): read-only, dim 128, specialised kernel only
+    bool select_shortcut = true;     // select_neighbors after search_level = the head of W (hnsw_insert.hpp); 0 = the full extension
+    bool lean = true;                // dim-128 searches use the specialised kernel (hnsw_search_lean.hpp) when its preconditions hold
+    size_t lds_reserve = 0;          // LDS a kernel needs besides the wave's own share (the OCC kernels' validation scratch)
+    bool grid_stride = false;        // specialised kernel: cap the grid at the resident waves and walk the batch grid-stride (tuning, for comparison)
+    bool visited_bounded = true;     // k_search: a full LDS visited table stops recording (exact results)
+    uint32_t max_waves_per_cu = 8;   // residency the LDS visited table is sized for (tuning: waves_per_cu)
+    uint32_t launch_concurrency = 0; // tuning: search launches the CALLER keeps in flight at once (0 = observed per launch, see search_concurrency)
+    uint32_t pipe_inflight = 1;      // ... and how many the engine's own pipeline has in flight right now
+    uint32_t cur_conc = 1;           // what the launch being enqueued sizes its LDS share for
+    bool last_search_lean = false;   // the latest search launch was the specialised kernel's (hnsw_debug_last_search_path)
+    bool pipe_device = true;         // tuning: the _device entry point splits large batches over the lanes too
+    uint32_t fast_seed = 512, fast_batch_max = 4096, fast_batch_div = 8;
+    uint64_t rng[4] = {0, 0, 0, 0};
+    uint64_t hbm_bytes = 0;
+    std::string err;
+};
+
+namespace hnsw_host {
+
+using namespace hnsw;
+
+#define HIP_TRY(h, expr)                                                                       \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                      \
+            return HNSW_ERR_DEVICE;                                                            \
+        }                                                                                      \
+    } while (0)
+
+// Variant of the translation unit being compiled (see the file header).
+#if defined(HNSW_VARIANT)
+#if HNSW_VARIANT == 0
+constexpr int kVarMode = MODE_SCALAR, kVarT = 0;
+#elif HNSW_VARIANT == 1
+constexpr int kVarMode = MODE_AVX, kVarT = 4;
+#elif HNSW_VARIANT == 2
+constexpr int kVarMode = MODE_AVX, kVarT = 24;
+#elif HNSW_VARIANT == 3
+constexpr int kVarMode = MODE_AVX, kVarT = 0;
+#else
+#error "HNSW_VARIANT must be 0..3"
+#endif
+#endif
+
+// LDS visited-set configuration of one launch
+struct VisCfg {
+    uint32_t lnb;      // 32-byte buckets (32-bit id mode); also sizes LDS in tag mode via `bytes`
+    uint32_t lcap;     // ids before the set moves to HBM
+    uint32_t tagcfg;   // 0, or log2(16-byte buckets) | idbits << 8
+    size_t bytes;      // LDS bytes of the table
+};
+
+struct InsertCfg {
+    int R;
+    uint32_t lnb, lcap, tagcfg;
+    size_t lds;
+};
+
+// ---- defined in hnsw_engine.hip ---------------------------------------------------------------------
+hnsw_status fail(hnsw_index *h, hnsw_status s, const std::string &msg);
+GraphView view(const hnsw_index *h);
+GraphView view_tag(const hnsw_index *h, uint32_t tagcfg);
+VisCfg pick_vis(const hnsw_index *h, int R, int T, bool ins, uint32_t nwaves);
+hnsw_status spill_acquire(hnsw_index *h, hipStream_t st, uint32_t *region, uint32_t **base);
+hnsw_status spill_release(hnsw_index *h, hipStream_t st, uint32_t region);
+hnsw_status note_search(hnsw_index *h, hipStream_t st);
+hnsw_status wait_inflight_searches(hnsw_index *h);
+
+// The dynamic-LDS attribute sticks to the kernel function (process-wide), so it is raised once per size class
+// instead of once per launch; `have` is the launcher's static high-water mark per device.  Handles on different
+// threads may launch the same kernel: the check-and-set is serialised.
+template <typename Kern>
+hnsw_status raise_lds_attr(hnsw_index *h, Kern kern, size_t lds, size_t (&have)[16])
+{
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &cur = have[h->device & 15];
+    if (lds > cur) {
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        cur = lds;
+    }
+    return HNSW_OK;
+}
+
+// ---- the launchers: defined + explicitly instantiated in the family files ----------------------------------
+// hnsw_tu_search.hip
+template <int MODE, int T>
+hnsw_status launch_search_r(hnsw_index *h, int R, const float *dQ, uint32_t B, uint32_t k, uint32_t *d_ids,
+                            float *d_sims, uint32_t *d_nout, hipStream_t st);
+// hnsw_tu_lean.hip: launches k_search_lean<VEC,R,BB,DB> if that instantiation exists (*done), else leaves *done false
+template <class VEC>
+hnsw_status launch_lean_v(hnsw_index *h, int R, uint32_t bb, uint32_t db, const float *dQ, uint32_t B, uint32_t k,
+                          uint32_t idbits, uint32_t per_cu, uint32_t *d_ids, float *d_sims, uint32_t *d_nout,
+                          hipStream_t st, bool *done);
+// hnsw_tu_insert.hip
+template <int MODE, int T>
+hnsw_status launch_insert_r(hnsw_index *h, const InsertCfg &c, bool plan, uint32_t first, uint32_t count);
+template <int MODE, int T>
+hnsw_status launch_shrink_t(hnsw_index *h, uint32_t *pending0, uint32_t *pendingU, uint32_t *work_n);
+template <int MODE, int T>
+hnsw_status launch_delete_r(hnsw_index *h, const InsertCfg &c, uint32_t id);
+// hnsw_tu_occ.hip
+template <int MODE, int T>
+hnsw_status occ_round_r(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t head, uint32_t count, uint32_t end_node);
+
+} // namespace hnsw_host

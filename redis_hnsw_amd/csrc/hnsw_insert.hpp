@@ -644,6 +644,7 @@ __global__ __launch_bounds__(64, 1) void k_delete_exact(GraphView g, uint32_t id
     if (vis.glob_dirty) visited_clear(vis, lane);
 }
 
+#ifdef HNSW_UTILITY_KERNELS   // plain (non-template) kernels: defined once, in hnsw_engine.hip
 // ---------------------------------------------------------------------------
 // fast build: commit a planned batch.  One wave per new node links it (both
 // directions, atomics on the row counters); rows pushed past m_max go to a
@@ -690,6 +691,8 @@ __global__ __launch_bounds__(64) void k_link_batch(GraphView g, uint32_t first_i
         }
     }
 }
+
+#endif // HNSW_UTILITY_KERNELS
 
 // prune row (e, lc) to its m_max nearest (by the engine's (dist, id) order)
 template <int MODE, int T>
@@ -747,6 +750,7 @@ __global__ __launch_bounds__(64) void k_shrink_batch(GraphView g, uint32_t mlink
     if (lane == 0 && ndist) atomicAdd(&g.hdr->ctr_insert[0], ndist);
 }
 
+#ifdef HNSW_UTILITY_KERNELS
 __global__ void k_batch_finish(DevHeader *hdr, uint32_t node_count, uint32_t max_layer, int32_t enterpoint,
                                uint32_t *work_n)
 {
@@ -755,5 +759,7 @@ __global__ void k_batch_finish(DevHeader *hdr, uint32_t node_count, uint32_t max
     hdr->enterpoint = enterpoint;
     *work_n = 0;
 }
+
+#endif // HNSW_UTILITY_KERNELS
 
 } // namespace hnsw

@@ -150,6 +150,7 @@ __global__ __launch_bounds__(64) void k_metric_pairs_reg(const float *__restrict
     }
 }
 
+#ifdef HNSW_UTILITY_KERNELS   // plain (non-template) kernels: defined once, in hnsw_engine.hip
 // ---------------------------------------------------------------------------
 // bulk import: CSR rows -> fixed-stride rows
 // ---------------------------------------------------------------------------
@@ -289,5 +290,7 @@ __global__ void k_export_rows(const uint32_t *__restrict__ adj, uint32_t stride,
     const uint32_t cnt = (uint32_t)(rp[wave + 1] - rp[wave]);
     for (uint32_t i = lane; i < cnt; i += 64) col[rp[wave] + i] = row[1 + i];
 }
+
+#endif // HNSW_UTILITY_KERNELS
 
 } // namespace hnsw

@@ -1,0 +1,54 @@
+// hnsw_tu_occ.hip -- the exact-order parallel insert (hnsw_occ.hpp) for one metric variant (HNSW_VARIANT, see
+// hnsw_host.hpp): k_occ_validate, k_occ_plan, k_occ_shrinks, k_occ_commit and the launcher of one round.
+#include "hnsw_host.hpp"
+
+namespace hnsw_host {
+
+template <int MODE, int T, int R>
+static hnsw_status occ_round_t(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t head, uint32_t count, uint32_t end_node)
+{
+    const size_t lds_val = kOccScratchBytes + 64 * 8 + (T == 0 ? (((size_t)h->dim * 4 + 15) & ~(size_t)15) : 0);
+    const size_t lds_commit = kOccScratchBytes + c.lds;
+    auto kv = k_occ_validate<MODE, T>;
+    auto kp = k_occ_plan<MODE, T, R>;
+    auto kc = k_occ_commit<MODE, T, R>;
+    auto ks = k_occ_shrinks<MODE, T, R>;
+    {
+        static std::mutex mu;
+        static bool attr_set[16] = {false};
+        std::lock_guard<std::mutex> lock(mu);
+        if (!attr_set[h->device & 15]) {
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+            attr_set[h->device & 15] = true;
+        }
+    }
+    const GraphView gv = view_tag(h, c.tagcfg);
+    hipLaunchKernelGGL(kv, dim3(count), dim3(64), lds_val, h->stream, gv, ob, head, count);
+    hipLaunchKernelGGL(kp, dim3(count), dim3(64), c.lds, h->stream, gv, ob, head, count, h->efc, h->m, c.lnb, c.lcap, h->d_spill,
+                       h->spill_gnb, h->d_plan, h->select_shortcut ? 1u : 0u, h->occ_log_cap);
+    hipLaunchKernelGGL(ks, dim3(count * kOccMaxShr), dim3(64), c.lds, h->stream, gv, ob, head, count, h->m, c.lnb, c.lcap, h->d_spill,
+                       h->spill_gnb);
+    hipLaunchKernelGGL(kc, dim3(1), dim3(64), lds_commit, h->stream, gv, ob, end_node, h->m, c.lnb, c.lcap, h->d_spill_one,
+                       h->spill_one_gnb, h->d_plan, h->m + 2 + h->occ_slack_extra);
+    HIP_TRY(h, hipGetLastError());
+    return HNSW_OK;
+}
+
+template <int MODE, int T>
+hnsw_status occ_round_r(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t head, uint32_t count, uint32_t end_node)
+{
+    switch (c.R) {
+    case 1: return occ_round_t<MODE, T, 1>(h, c, ob, head, count, end_node);
+    case 4: return occ_round_t<MODE, T, 4>(h, c, ob, head, count, end_node);
+    case 8: return occ_round_t<MODE, T, 8>(h, c, ob, head, count, end_node);
+    case 16: return occ_round_t<MODE, T, 16>(h, c, ob, head, count, end_node);
+    }
+    return fail(h, HNSW_ERR_INVALID, "bad R");
+}
+
+template hnsw_status occ_round_r<kVarMode, kVarT>(hnsw_index *, const InsertCfg &, const OccBufs &, uint32_t, uint32_t, uint32_t);
+
+} // namespace hnsw_host

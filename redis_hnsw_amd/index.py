@@ -194,6 +194,22 @@ class Index:
         self._check(self._lib.hnsw_search_batch_device(self._h, dQ_ptr, B, self.data_dim, k, d_ids_ptr, d_sims_ptr,
                                                        d_nout_ptr, stream))
 
+    def pipeline_info(self):
+        """lanes / measured overlap of the engine's search pipeline (hnsw_pipeline_info)"""
+        p = _capi.Pipeline()
+        self._check(self._lib.hnsw_pipeline_info(self._h, C.byref(p)))
+        return dict(lanes=int(p.lanes), overlap=int(p.overlap), probe_ratio=round(float(p.probe_ratio), 3),
+                    priorities=int(p.priorities), chunk=int(p.chunk), min_batch=int(p.min_batch),
+                    hw_queues_env=int(p.hw_queues_env))
+
+    def last_search_was_lean(self):
+        """development aid: did the latest search launch use the specialised dim-128 kernel"""
+        f = self._lib.hnsw_debug_last_search_path
+        f.restype, f.argtypes = C.c_int, [_capi.H, _capi.u32p]
+        v = C.c_uint32(0)
+        self._check(f(self._h, C.byref(v)))
+        return bool(v.value)
+
     def last_search_kernel_ms(self):
         ms = C.c_float(0)
         self._check(self._lib.hnsw_last_search_kernel_ms(self._h, C.byref(ms)))

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _run(extra):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--nodes", "20000", "--steps", "3", "--warmup", "1",
-           "--no-cpu-baseline", "--no-clustered"] + extra
+           "--no-cpu-baseline", "--no-clustered", "--no-traffic"] + extra
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -36,3 +36,10 @@ def test_bench_single_rank_line_has_the_contract_fields():
                 "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in out
     assert out["n_gpus"] == 1 and out["dtype"] == "f32" and "workload" in out["config"]
+    # what the roofline's denominator is, the literal one-launch-at-a-time shape, and the library's own pipelining
+    rl = out["roofline"]
+    assert rl["peak_hbm_spec"] == 8000.0 and rl["hbm_measured_copy"] < rl["peak_hbm_spec"]
+    assert rl["lone_launch_1024"]["launches_in_flight"] == 1 and rl["lone_launch_1024"]["kernel_ms"] > 0
+    assert out["host_buffers"]["batch"] == 8192 and out["host_buffers"]["value"] > 0
+    assert [c["batch"] for c in out["device_call"]] == [4096, 8192, 16384]
+    assert out["config"]["pipeline"]["lanes"] == 3

@@ -1,0 +1,155 @@
+"""Full-size evidence for the configurations BASELINE.json names, run by the driver with -m gpu:
+
+  * C3 (1M x 768, M=32, ef=400, k=100, B=4096) -- the only configuration served by the dim-768 kernel
+    (k_search<MODE_AVX,24,8>): size-independent properties on the whole batch + bit-exact sampled parity.
+  * the graph bench.py's headline is timed on -- the REFERENCE-ORDER fixture data/c2_ref_graph_1m.npz (the CPU
+    oracle's serial build, core.rs:489-599) -- in the bench's launch shape (three 1024-query calls in flight on
+    three streams, the bounded 16 KB visited table) and through the engine's own pipeline (host buffers,
+    B = 8192; one _device call of 4096): ids, similarity bits, n_ids and n_expand against the oracle.
+  * the reference-order GPU build checked row for row against a committed oracle-built fixture (50 k nodes),
+    the same check bench.py's gpu_exact_build leg makes.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import graphs_equal
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from redis_hnsw_amd import index as idxmod
+    return idxmod
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def test_full_size_c3_properties_and_sampled_parity(eng, oracle_mod):
+    from bench import draw_levels
+    N, dim, M, ef, k, B = 1_000_000, 768, 32, 400, 100, 4096
+    V = np.random.default_rng(1).random((N, dim), dtype=np.float32)
+    Q = np.random.default_rng(2).random((B, dim), dtype=np.float32)
+    gi = eng.Index("c3", dim, M, ef)
+    gi.add_batch(V, levels=draw_levels(N, M, 7), mode="fast")
+    assert gi.node_count == N
+    ids, sims, n_out = gi.search_batch(Q, k)                               # through the engine's pipeline (4 chunks)
+    assert np.all(n_out == k)                                              # min(k, ef, reachable) = k
+    assert np.all(ids < N)
+    assert np.all(sims[:, :-1] >= sims[:, 1:])                             # nearest first (core.rs:878-890)
+    assert np.all(sims <= 0)                                               # sim = -(squared L2)
+    assert all(len(set(r.tolist())) == k for r in ids[::16])               # no node twice
+    # the similarity reported for an id is the metric of that pair, recomputed independently in f64
+    d = ((Q[:16, None, :].astype(np.float64) - V[ids[:16].astype(np.int64)].astype(np.float64)) ** 2).sum(-1)
+    assert np.allclose(-d, sims[:16], rtol=1e-5, atol=0)
+    ids2, sims2, _ = gi.search_batch(Q, k)                                 # idempotent
+    assert np.array_equal(ids, ids2) and np.array_equal(_bits(sims), _bits(sims2))
+    part, _, _ = gi.search_batch(Q[:100], k)                               # batch composition does not matter
+    assert np.array_equal(part, ids[:100])
+    # sampled parity: the oracle searching the very same graph
+    g = gi.export_graph()
+    g["vectors"] = V
+    o = oracle_mod.OracleIndex.from_graph(dim, M, ef, g)
+    gi.set_tuning("visited_bounded", 0)                                    # the exact set: work counters equal the reference's
+    gi.reset_counters()
+    sids, ssims, sn = gi.search_batch(Q[:16], k)
+    oids, osims, on, oct = o.search_batch(Q[:16], k, threads=8)
+    assert np.array_equal(sids, oids) and np.array_equal(_bits(ssims), _bits(osims)) and np.array_equal(sn, on)
+    sc, _ = gi.counters()
+    assert (sc.n_dist, sc.n_ids, sc.n_expand) == (oct.n_dist, oct.n_ids, oct.n_expand)
+    assert np.array_equal(ids[:16], oids)                                  # and the bounded default agrees
+    gi.close(); o.close()
+
+
+FIXTURE_1M = os.path.join(ROOT, "data", "c2_ref_graph_1m.npz")
+
+
+@pytest.mark.skipif(not os.path.exists(FIXTURE_1M), reason="data/c2_ref_graph_1m.npz is missing")
+def test_reference_order_fixture_parity_in_the_bench_launch_shape(eng, oracle_mod):
+    import torch
+    from bench import load_graph_fixture
+    N, dim, M, ef, k, B = 1_000_000, 128, 16, 200, 10, 1024
+    V = np.random.default_rng(1).random((N, dim), dtype=np.float32)        # bench.py's vectors and queries
+    Qall = np.random.default_rng(2).random((8 * B, dim), dtype=np.float32)
+    graph, _ = load_graph_fixture(FIXTURE_1M, V)
+    gi = eng.Index("c2-ref", dim, M, ef)
+    gi.import_graph(graph)
+    o = oracle_mod.OracleIndex.from_graph(dim, M, ef, graph)
+    dev = torch.device("cuda", 0)
+    S = 3
+    streams = [torch.cuda.Stream() for _ in range(S)]
+    dQ = torch.from_numpy(Qall).to(dev)
+    outs = [(torch.empty((B, k), dtype=torch.int32, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev),
+             torch.empty((B,), dtype=torch.int32, device=dev)) for _ in range(6)]
+    torch.cuda.synchronize()
+    gi.reset_counters()
+    # bench.py's timed loop: consecutive 1024-query calls round-robin on three streams, nothing tuned
+    for i in range(6):
+        q = dQ[i * B:(i + 1) * B]
+        ids_t, sims_t, n_t = outs[i]
+        gi.search_batch_device(q.data_ptr(), B, k, ids_t.data_ptr(), sims_t.data_ptr(), n_t.data_ptr(), streams[i % S].cuda_stream)
+    torch.cuda.synchronize()
+    sc, _ = gi.counters()
+    # 16 queries of each of the six launches against the oracle
+    tot_ids = tot_exp = 0
+    for i in range(6):
+        sel = slice(i * B + 100, i * B + 116)
+        oids, osims, on, oct = o.search_batch(Qall[sel], k, threads=8)
+        got_ids = outs[i][0][100:116].cpu().numpy().view(np.uint32)
+        got_sims = outs[i][1][100:116].cpu().numpy()
+        assert np.array_equal(got_ids, oids) and np.array_equal(_bits(got_sims), _bits(osims))
+        assert np.array_equal(outs[i][2][100:116].cpu().numpy().view(np.uint32), on)
+    # counters of whole launches: n_ids and n_expand are the reference's even when the bounded table re-evaluates
+    oids, osims, on, oct = o.search_batch(Qall[:B], k, threads=8)
+    assert np.array_equal(outs[0][0].cpu().numpy().view(np.uint32), oids)
+    gi.reset_counters()
+    gi.search_batch_device(dQ[:B].data_ptr(), B, k, outs[0][0].data_ptr(), outs[0][1].data_ptr(), outs[0][2].data_ptr(),
+                           streams[0].cuda_stream)
+    torch.cuda.synchronize()
+    s1, _ = gi.counters()
+    assert (s1.n_ids, s1.n_expand) == (oct.n_ids, oct.n_expand)
+    assert oct.n_dist <= s1.n_dist <= 1.02 * oct.n_dist
+    assert gi.last_search_was_lean()
+
+    # the engine's own pipeline: host buffers, 8 chunks on 3 lanes ...
+    ids8, sims8, n8 = gi.search_batch(Qall, k)
+    assert np.all(n8 == k)
+    assert np.array_equal(ids8[:B], oids) and np.array_equal(_bits(sims8[:B]), _bits(osims))
+    sel = slice(7 * B + 500, 7 * B + 532)
+    o2 = o.search_batch(Qall[sel], k, threads=8)
+    assert np.array_equal(ids8[sel], o2[0]) and np.array_equal(_bits(sims8[sel]), _bits(o2[1]))
+    # ... and one _device call of 4096 queries (4 chunks, joined back into the caller's stream)
+    ids_t = torch.empty((4 * B, k), dtype=torch.int32, device=dev)
+    sims_t = torch.empty((4 * B, k), dtype=torch.float32, device=dev)
+    n_t = torch.empty((4 * B,), dtype=torch.int32, device=dev)
+    with torch.cuda.stream(streams[1]):
+        gi.search_batch_device(dQ.data_ptr(), 4 * B, k, ids_t.data_ptr(), sims_t.data_ptr(), n_t.data_ptr(), streams[1].cuda_stream)
+        got = ids_t.cpu().numpy().view(np.uint32)                          # ordered on the caller's stream: the join must hold
+        gots = sims_t.cpu().numpy()
+    assert np.array_equal(got, ids8[:4 * B]) and np.array_equal(_bits(gots), _bits(sims8[:4 * B]))
+    info = gi.pipeline_info()
+    assert info["overlap"] == 1, "the pipeline's streams serialise on this box: %r" % (info,)
+    gi.close(); o.close()
+
+
+FIXTURE_50K = os.path.join(ROOT, "data", "c2_ref_graph_50k.npz")
+
+
+@pytest.mark.skipif(not os.path.exists(FIXTURE_50K), reason="data/c2_ref_graph_50k.npz is missing")
+def test_exact_gpu_build_equals_the_committed_reference_order_fixture(eng):
+    """hnsw_add_batch mode 0 on the first 50 k nodes of the bench data == the oracle's serial build of the same
+    nodes (tests/fixtures/make_ref_graph.py --nodes 50000), row for row in stored order."""
+    from bench import draw_levels, load_graph_fixture
+    NE, dim, M, ef = 50_000, 128, 16, 200
+    V = np.random.default_rng(1).random((1_000_000, dim), dtype=np.float32)[:NE]
+    want, _ = load_graph_fixture(FIXTURE_50K, V)
+    gi = eng.Index("exact50k", dim, M, ef)
+    gi.add_batch(V, levels=draw_levels(1_000_000, M, 7)[:NE], mode="exact")
+    ok, why = graphs_equal(want, gi.export_graph())
+    assert ok, why
+    gi.close()

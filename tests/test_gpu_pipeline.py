@@ -1,0 +1,202 @@
+"""The engine's own search pipeline (hnsw_search_batch / hnsw_search_batch_device split large batches into
+chunks on engine-owned streams) and the round-2 advisor findings around the specialised kernel: results must be
+the oracle's whatever the chunking, the launch shape or the order of calls."""
+import numpy as np
+import pytest
+
+from tests.util import build_oracle, make_data
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from redis_hnsw_amd import index as idxmod
+    return idxmod
+
+
+@pytest.fixture(scope="module")
+def small(oracle_mod):
+    n, dim, m, ef = 6000, 128, 16, 200
+    V = make_data(n, dim, seed=1)
+    o, lv = build_oracle(oracle_mod, V, m, ef)
+    return V, o, lv, (n, dim, m, ef)
+
+
+@pytest.mark.parametrize("chunk,B", [(256, 3000), (1024, 2500), (100, 777), (64, 65)])
+def test_pipelined_host_search_equals_the_oracle(eng, small, chunk, B):
+    V, o, lv, (n, dim, m, ef) = small
+    g = o.export()
+    g["vectors"] = V
+    gi = eng.Index("pipe", dim, m, ef)
+    gi.import_graph(g)
+    gi.set_tuning("pipe_chunk", chunk)
+    Q = make_data(B, dim, seed=5)
+    k = 10
+    ids, sims, n_out = gi.search_batch(Q, k)                       # ceil(B / chunk) chunks over 3 lanes
+    oids, osims, on, _ = o.search_batch(Q, k, threads=8)
+    assert np.array_equal(n_out, on) and np.array_equal(ids, oids) and np.array_equal(_bits(sims), _bits(osims))
+    ids2, sims2, _ = gi.search_batch(Q, k)                         # staging buffers are reused: same again
+    assert np.array_equal(ids, ids2) and np.array_equal(_bits(sims), _bits(sims2))
+    # k larger than before: the staging grows
+    ids3, sims3, n3 = gi.search_batch(Q[:300], 40)
+    o3 = o.search_batch(Q[:300], 40, threads=8)
+    assert np.array_equal(ids3, o3[0]) and np.array_equal(_bits(sims3), _bits(o3[1])) and np.array_equal(n3, o3[2])
+    gi.close()
+
+
+def test_pipelined_search_refuses_a_non_finite_component_in_a_late_chunk(eng, small):
+    V, o, lv, (n, dim, m, ef) = small
+    g = o.export()
+    g["vectors"] = V
+    gi = eng.Index("pipe-nan", dim, m, ef)
+    gi.import_graph(g)
+    gi.set_tuning("pipe_chunk", 128)
+    Q = make_data(1000, dim, seed=6)
+    Q[900, 17] = np.inf
+    with pytest.raises(eng.HNSWError):
+        gi.search_batch(Q, 5)
+    Q[900, 17] = 0.5
+    ids, _, n_out = gi.search_batch(Q, 5)                          # and the handle keeps working
+    assert np.all(n_out == 5) and np.array_equal(ids, o.search_batch(Q, 5, threads=8)[0])
+    gi.close()
+
+
+def test_pipelined_device_call_joins_back_into_the_callers_stream(eng, small):
+    import torch
+    V, o, lv, (n, dim, m, ef) = small
+    g = o.export()
+    g["vectors"] = V
+    gi = eng.Index("pipe-dev", dim, m, ef)
+    gi.import_graph(g)
+    gi.set_tuning("pipe_chunk", 200)
+    gi.set_tuning("pipe_min_batch", 400)
+    dev = torch.device("cuda", 0)
+    B, k = 1500, 10
+    Q = make_data(B, dim, seed=7)
+    st = torch.cuda.Stream()
+    ids_t = torch.zeros((B, k), dtype=torch.int32, device=dev)
+    sims_t = torch.zeros((B, k), dtype=torch.float32, device=dev)
+    n_t = torch.zeros((B,), dtype=torch.int32, device=dev)
+    with torch.cuda.stream(st):
+        dQ = torch.from_numpy(Q).to(dev, non_blocking=True)        # the input is produced ON the caller's stream
+        for _ in range(3):                                         # back-to-back calls on one stream: fork after join
+            gi.search_batch_device(dQ.data_ptr(), B, k, ids_t.data_ptr(), sims_t.data_ptr(), n_t.data_ptr(), st.cuda_stream)
+        host_ids = torch.empty_like(ids_t, device="cpu").pin_memory()
+        host_ids.copy_(ids_t, non_blocking=True)                   # consumer ordered on the caller's stream only
+    st.synchronize()
+    oids, osims, on, _ = o.search_batch(Q, k, threads=8)
+    assert np.array_equal(host_ids.numpy().view(np.uint32), oids)
+    assert np.array_equal(_bits(sims_t.cpu().numpy()), _bits(osims))
+    assert np.array_equal(n_t.cpu().numpy().view(np.uint32), on)
+    # an exact insert right after waits for the lanes (searches in flight read the rows it rewrites)
+    with torch.cuda.stream(st):
+        gi.search_batch_device(dQ.data_ptr(), B, k, ids_t.data_ptr(), sims_t.data_ptr(), n_t.data_ptr(), st.cuda_stream)
+    gi.add_node("late", make_data(1, dim, seed=8)[0], level=0)
+    st.synchronize()
+    assert np.array_equal(ids_t.cpu().numpy().view(np.uint32), oids)
+    gi.close()
+
+
+def test_pipeline_lanes_overlap_and_report_it(eng, small):
+    V, o, lv, (n, dim, m, ef) = small
+    gi = eng.Index("pipe-info", dim, m, ef)
+    info = gi.pipeline_info()                                      # creates the lanes and measures them
+    assert info["lanes"] == 3 and info["chunk"] == 1024
+    assert info["overlap"] == 1, "the engine's streams share a hardware queue: %r" % (info,)
+    assert 0.5 < info["probe_ratio"] < 1.6
+    gi.close()
+
+
+def test_callers_own_streams_need_no_tuning(eng, small):
+    """three caller streams, nothing promised: each launch sizes its LDS share from the launches it sees in
+    flight; results are the oracle's whichever table size a launch got"""
+    import torch
+    V, o, lv, (n, dim, m, ef) = small
+    g = o.export()
+    g["vectors"] = V
+    gi = eng.Index("auto", dim, m, ef)
+    gi.import_graph(g)
+    dev = torch.device("cuda", 0)
+    B, k, S = 1024, 10, 3
+    Q = make_data(6 * B, dim, seed=9)
+    dQ = torch.from_numpy(Q).to(dev)
+    streams = [torch.cuda.Stream() for _ in range(S)]
+    outs = [(torch.empty((B, k), dtype=torch.int32, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev),
+             torch.empty((B,), dtype=torch.int32, device=dev)) for _ in range(6)]
+    torch.cuda.synchronize()
+    for i in range(6):
+        gi.search_batch_device(dQ[i * B:(i + 1) * B].data_ptr(), B, k, outs[i][0].data_ptr(), outs[i][1].data_ptr(),
+                               outs[i][2].data_ptr(), streams[i % S].cuda_stream)
+    torch.cuda.synchronize()
+    oids, osims, on, _ = o.search_batch(Q, k, threads=8)
+    for i in range(6):
+        assert np.array_equal(outs[i][0].cpu().numpy().view(np.uint32), oids[i * B:(i + 1) * B])
+        assert np.array_equal(_bits(outs[i][1].cpu().numpy()), _bits(osims[i * B:(i + 1) * B]))
+    gi.close()
+
+
+# ---- advisor findings, round 2 ---------------------------------------------------------------------
+def test_delete_keeps_an_m16_index_on_the_specialised_kernel(eng, oracle_mod):
+    """HNSW.NODE.DEL asks for row slack by the deleted node's own degree, not by the index's maximum: an M = 16
+    index (rows of 63 ids) is not restrided by its first delete and keeps the dim-128 kernel."""
+    n, dim, m, ef = 3000, 128, 16, 200
+    V = make_data(n, dim, seed=3)
+    o, lv = build_oracle(oracle_mod, V, m, ef)
+    gi = eng.Index("del16", dim, m, ef)
+    gi.add_batch(V, levels=lv, mode="exact")
+    Q = make_data(64, dim, seed=4)
+    gi.search_batch(Q, 10)
+    assert gi.last_search_was_lean()
+    inf0 = gi.info()
+    assert inf0.stride0 == 64 and inf0.max_degree0 >= 2 * m
+    for i in (5, 700, 1999, 2500):
+        gi.delete_node("node%d" % i)
+        o.delete(i)
+    inf1 = gi.info()
+    assert (inf1.stride0, inf1.stride_upper) == (inf0.stride0, inf0.stride_upper)
+    ids, sims, n_out = gi.search_batch(Q, 10)
+    assert gi.last_search_was_lean()
+    oids, osims, on, _ = o.search_batch(Q, 10)
+    assert np.array_equal(ids, oids) and np.array_equal(_bits(sims), _bits(osims)) and np.array_equal(n_out, on)
+    gi.close(); o.close()
+
+
+def test_compress_bf16_is_refused_when_no_kernel_could_serve_it(eng, oracle_mod):
+    dim = 128
+    Q = make_data(32, dim, seed=4)
+    # M = 32: rows of 112 words -- the specialised kernel does not apply; the index must stay as it was
+    V = make_data(1500, dim, seed=3)
+    a = eng.Index("bf-m32", dim, 32, 64)
+    a.add_batch(V, mode="fast")
+    before = a.search_batch(Q, 10)
+    with pytest.raises(eng.HNSWError) as e:
+        a.set_tuning("compress_bf16", 1)
+    assert "rows wider" in e.value.msg
+    after = a.search_batch(Q, 10)
+    assert np.array_equal(before[0], after[0]) and np.array_equal(_bits(before[1]), _bits(after[1]))
+    a.add_node("still-writable", V[0] * 0.5)
+    a.close()
+    # ef = 400 (R = 8): same
+    b = eng.Index("bf-ef400", dim, 16, 400)
+    b.add_batch(V, mode="fast")
+    with pytest.raises(eng.HNSWError):
+        b.set_tuning("compress_bf16", 1)
+    assert np.all(b.search_batch(Q, 10)[2] == 10)
+    b.close()
+    # an eligible index converts, and afterwards the knobs that would strand it are refused
+    c = eng.Index("bf-ok", dim, 16, 200)
+    c.add_batch(V, mode="fast")
+    c.set_tuning("compress_bf16", 1)
+    ok = c.search_batch(Q, 10)
+    for key, val in (("lean", 0), ("visited_bounded", 0), ("tag_table", 0), ("tag_bb", 5), ("lds_buckets", 64),
+                     ("force_restride", 16), ("waves_per_cu", 12)):
+        with pytest.raises(eng.HNSWError):
+            c.set_tuning(key, val)
+    again = c.search_batch(Q, 10)
+    assert np.array_equal(ok[0], again[0]) and np.array_equal(_bits(ok[1]), _bits(again[1]))
+    c.close()
