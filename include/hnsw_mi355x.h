@@ -115,13 +115,15 @@ hnsw_status hnsw_search_batch(hnsw_index *h, const float *Q, uint32_t B, uint32_
 
 /* Same, with every buffer already resident in HBM; enqueues on `stream`
  * (a hipStream_t, NULL = the null stream) and returns without synchronising.
- * Batches of "pipe_min_batch" (1536) queries or more are split into chunks of <= "pipe_chunk" (1024)
- * that run on `stream` and two engine-owned streams and are joined back into `stream` before the call
- * returns (hnsw_search_batch does the same with its copies overlapped): the chip holds 2048 queries,
- * and a third chunk is what the dispatcher backfills from while the long queries of the first two
- * drain.  Smaller calls are one launch; a caller that keeps several of those in flight
- * on its own streams needs no tuning -- the engine sizes each launch's LDS share from the launches it
- * sees in flight.  Inserts and deletes wait for every search enqueued before them, whatever its stream. */
+ * One call is one kernel launch with one workgroup per query: the dispatcher hands the next query to
+ * whichever of the chip's 2048 wave slots frees first, which is the best a single call can do (measured:
+ * splitting a call into chunks on several streams is slower -- a stream's next chunk waits for the last
+ * wave of its previous one; "pipe_device" = 1 keeps that form for comparison).  What one call cannot hide
+ * is its own drain: the last queries run on a nearly empty chip (0.76 of the steady rate at 4096 queries,
+ * 0.82 at 8192).  A caller with more than one batch hides it by keeping calls in flight on two or three
+ * streams of its own; nothing needs tuning for that -- the engine sizes each launch's LDS share from the
+ * launches it sees in flight.  hnsw_search_batch (host buffers) pipelines its copies and kernels on the
+ * engine's own lanes.  Inserts and deletes wait for every search enqueued before them, whatever its stream. */
 hnsw_status hnsw_search_batch_device(hnsw_index *h, const float *dQ, uint32_t B,
                                      uint32_t dim, uint32_t k, uint32_t *d_ids,
                                      float *d_sims, uint32_t *d_n_out, void *stream);

@@ -387,7 +387,7 @@ const char *lean_blocker(const hnsw_index *h)
     if (h->mode != MODE_AVX || h->dim != 128) return "dim != 128";
     if (!h->visited_bounded) return "tuning visited_bounded = 0";
     if (!h->tag_table || h->tag_bb_override >= 0 || h->lds_buckets_override >= 0) return "visited-table test overrides (tag_table / tag_bb / lds_buckets)";
-    if (h->stride0 > 64 || h->strideU > 64) return "adjacency rows wider than 63 ids (M > 16, or widened by a restride)";
+    if (h->stride0 > 128 || h->strideU > 128) return "adjacency rows wider than 127 ids";
     if (R != 1 && R != 4) return "ef_construction > 256";
     // 16-bit entries: tag (idbits - bb bits) + >= 2 displacement bits; bb is 10 or 11 (9 with waves_per_cu > 8)
     uint32_t idbits = std::max(ceil_log2(std::max(h->cap, 2u)), 11u);
@@ -417,8 +417,11 @@ hnsw_status try_launch_lean(hnsw_index *h, const float *dQ, uint32_t B, uint32_t
         if (idbits - bb == 14) db = 2;
         else return HNSW_OK;
     }
-    return h->bf16 ? launch_lean_v<VecBF16<4>>(h, R, bb, db, dQ, B, k, idbits, per_cu, d_ids, d_sims, d_nout, st, done)
-                   : launch_lean_v<VecF32<4>>(h, R, bb, db, dQ, B, k, idbits, per_cu, d_ids, d_sims, d_nout, st, done);
+    if (h->stride0 > 64 || h->strideU > 64)              // rows of 64..127 ids: two row words per lane
+        return h->bf16 ? launch_lean_v<VecBF16<4>, true>(h, R, bb, db, dQ, B, k, idbits, per_cu, d_ids, d_sims, d_nout, st, done)
+                       : launch_lean_v<VecF32<4>, true>(h, R, bb, db, dQ, B, k, idbits, per_cu, d_ids, d_sims, d_nout, st, done);
+    return h->bf16 ? launch_lean_v<VecBF16<4>, false>(h, R, bb, db, dQ, B, k, idbits, per_cu, d_ids, d_sims, d_nout, st, done)
+                   : launch_lean_v<VecF32<4>, false>(h, R, bb, db, dQ, B, k, idbits, per_cu, d_ids, d_sims, d_nout, st, done);
 }
 
 // How many search launches share the CUs with the one about to be enqueued on `st` (it sizes the LDS visited
@@ -561,6 +564,17 @@ hnsw_status ensure_pipe_stage(hnsw_index *h, uint32_t chunk, uint32_t k)
     }
     h->pipe_q_words = wq;
     h->pipe_r_words = wr;
+    // A stream's first copy in either direction sets up its copy path (measured: 5 ms per lane, in the middle
+    // of the first large batch otherwise): do one of each now.
+    if (!h->pipe_copy_warm) {
+        for (uint32_t l = 0; l < hnsw_index::kPipe; ++l) {
+            hipStream_t st = l == 0 ? h->stream : h->pipe_st[l];
+            HIP_TRY(h, hipMemcpyAsync(h->pipe_dq[l], h->pipe_hq[l], 256, hipMemcpyHostToDevice, st));
+            HIP_TRY(h, hipMemcpyAsync(h->pipe_hres[l], h->pipe_dres[l], 256, hipMemcpyDeviceToHost, st));
+        }
+        for (uint32_t l = 0; l < hnsw_index::kPipe; ++l) HIP_TRY(h, hipStreamSynchronize(l == 0 ? h->stream : h->pipe_st[l]));
+        h->pipe_copy_warm = true;
+    }
     return HNSW_OK;
 }
 
@@ -605,9 +619,16 @@ hnsw_status search_batch_pipelined(hnsw_index *h, const float *Q, uint32_t B, ui
     h->pipe_inflight = lanes;
     struct Restore { hnsw_index *h; ~Restore() { h->pipe_inflight = 1; } } restore{h};
     bool overflow = false;
+    const bool trace = std::getenv("HNSW_PIPE_TRACE") != nullptr;
+    const auto tr0 = std::chrono::steady_clock::now();
+    auto tr = [&](const char *what, uint32_t c) {
+        if (trace) fprintf(stderr, "[pipe %8.1f us] %s %u\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count(), what, c);
+    };
     auto collect = [&](uint32_t c) -> hnsw_status {       // chunk c's results: pinned -> the caller's buffers
         const uint32_t l = c % hnsw_index::kPipe, off = c * per, cb = std::min(per, B - off);
+        tr("wait", c);
         HIP_TRY(h, hipEventSynchronize(h->pipe_done[l]));
+        tr("done", c);
         const uint32_t *r = h->pipe_hres[l];
         const size_t nk = (size_t)cb * k;
         std::memcpy(ids + (size_t)off * k, r, nk * 4);
@@ -620,17 +641,23 @@ hnsw_status search_batch_pipelined(hnsw_index *h, const float *Q, uint32_t B, ui
         const uint32_t l = c % hnsw_index::kPipe, off = c * per, cb = std::min(per, B - off);
         if (c >= hnsw_index::kPipe && (s = collect(c - hnsw_index::kPipe)) != HNSW_OK) return s;   // frees lane l's staging
         const size_t nq = (size_t)cb * h->dim, nk = (size_t)cb * k;
+        tr("stage", c);
         if (!copy_finite(h->pipe_hq[l], Q + (size_t)off * h->dim, nq)) {
             for (uint32_t d = 0; d < lanes; ++d) (void)hipStreamSynchronize(lane_st(d));
             return fail(h, HNSW_ERR_INVALID, "non-finite query component");
         }
         hipStream_t st = lane_st(l);
+        tr("enqueue", c);
         HIP_TRY(h, hipMemcpyAsync(h->pipe_dq[l], h->pipe_hq[l], nq * 4, hipMemcpyHostToDevice, st));
+        tr("h2d", c);
         uint32_t *d_ids = h->pipe_dres[l], *d_nout = h->pipe_dres[l] + 2 * nk;
         float *d_sims = reinterpret_cast<float *>(h->pipe_dres[l] + nk);
         if ((s = launch_search(h, h->pipe_dq[l], cb, k, d_ids, d_sims, d_nout, st)) != HNSW_OK) return s;
+        tr("launched", c);
         HIP_TRY(h, hipMemcpyAsync(h->pipe_hres[l], h->pipe_dres[l], (2 * nk + cb) * 4, hipMemcpyDeviceToHost, st));
+        tr("d2h", c);
         HIP_TRY(h, hipEventRecord(h->pipe_done[l], st));
+        tr("enqueued", c);
     }
     for (uint32_t c = nch > hnsw_index::kPipe ? nch - hnsw_index::kPipe : 0; c < nch; ++c)
         if ((s = collect(c)) != HNSW_OK) return s;
@@ -1557,6 +1584,13 @@ hnsw_status hnsw_debug_last_search_path(hnsw_index *h, uint32_t *lean)
     if (!h || !lean) return HNSW_ERR_INVALID;
     *lean = h->last_search_lean ? 1u : 0u;
     return HNSW_OK;
+}
+
+// why the specialised kernel cannot serve this index ("" = it can); development aid, not in the public header
+const char *hnsw_debug_lean_blocker(hnsw_index *h)
+{
+    const char *why = h ? lean_blocker(h) : "null handle";
+    return why ? why : "";
 }
 
 hnsw_status hnsw_last_search_kernel_ms(hnsw_index *h, float *ms)

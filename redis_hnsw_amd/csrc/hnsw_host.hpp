@@ -3,7 +3,7 @@
 // translation unit per kernel family and metric variant (redis_hnsw_amd/build.py compiles them in parallel):
 //   hnsw_engine.hip      C ABI, capacity / staging / pipeline bookkeeping, the small utility kernels
 //   hnsw_tu_search.hip   k_search<MODE,T,R>                    (general search kernel)         x 4 variants
-//   hnsw_tu_lean.hip     k_search_lean<VEC,R,BB,DB>            (dim-128 specialisation)        x 2 variants
+//   hnsw_tu_lean.hip     k_search_lean<VEC,R,BB,DB,WIDE>       (dim-128 specialisation)        x 4 variants
 //   hnsw_tu_insert.hip   k_insert_plan / k_insert_commit_exact / k_delete_exact / k_shrink_batch x 4 variants
 //   hnsw_tu_occ.hip      k_occ_validate / plan / shrinks / commit                              x 4 variants
 // A variant is one (metric order, query placement) pair, HNSW_VARIANT = 0..3:
@@ -68,6 +68,7 @@ struct hnsw_index {
     uint32_t pipe_min_batch = 1536;        // batches at least this large are pipelined (tuning "pipe_min_batch")
     int pipe_overlap = -1;                 // measured at first use: 1 the lanes run concurrently, 0 they serialise (hardware queues alias)
     float pipe_probe_ratio = 0.f;          // (all lanes together) / (one lane alone), spin-kernel probe
+    bool pipe_copy_warm = false;           // each lane has done one copy in each direction
     bool pipe_prio = false;                // lanes were re-created with distinct priorities to get queues of their own
     float *d_Q = nullptr;
     uint32_t *d_res = nullptr;       // [ids B*k][sims B*k][n_out B] of the host-buffer entry points
@@ -117,7 +118,7 @@ struct hnsw_index {
     uint32_t pipe_inflight = 1;      // ... and how many the engine's own pipeline has in flight right now
     uint32_t cur_conc = 1;           // what the launch being enqueued sizes its LDS share for
     bool last_search_lean = false;   // the latest search launch was the specialised kernel's (hnsw_debug_last_search_path)
-    bool pipe_device = true;         // tuning: the _device entry point splits large batches over the lanes too
+    bool pipe_device = false;        // tuning: the _device entry point splits large batches over the lanes too (measured slower than one launch: a lane's next chunk waits for its previous chunk's last wave)
     uint32_t fast_seed = 512, fast_batch_max = 4096, fast_batch_div = 8;
     uint64_t rng[4] = {0, 0, 0, 0};
     uint64_t hbm_bytes = 0;
@@ -198,7 +199,7 @@ template <int MODE, int T>
 hnsw_status launch_search_r(hnsw_index *h, int R, const float *dQ, uint32_t B, uint32_t k, uint32_t *d_ids,
                             float *d_sims, uint32_t *d_nout, hipStream_t st);
 // hnsw_tu_lean.hip: launches k_search_lean<VEC,R,BB,DB> if that instantiation exists (*done), else leaves *done false
-template <class VEC>
+template <class VEC, bool WIDE>
 hnsw_status launch_lean_v(hnsw_index *h, int R, uint32_t bb, uint32_t db, const float *dQ, uint32_t B, uint32_t k,
                           uint32_t idbits, uint32_t per_cu, uint32_t *d_ids, float *d_sims, uint32_t *d_nout,
                           hipStream_t st, bool *done);

@@ -1,6 +1,6 @@
 // hnsw_search_lean.hpp -- the search kernel's inner loop, specialised for the shapes every BASELINE
 // configuration with dim 128 uses (C1, C2, C4): AVX2 summation order with the query in registers (T = dim/32),
-// adjacency rows of at most 63 ids (one 256-byte wave load), the 16-bit tag table as the visited set with a
+// adjacency rows of at most 63 ids (one 256-byte wave load; WIDE variant: 127 ids, two loads), the 16-bit tag table as the visited set with a
 // compile-time bucket count, in its BOUNDED form only (a full table stops recording; re-met members of W are
 // dropped by key equality -- see search_level_v2 and DESIGN.md 4.1).  Same algorithm, same results and the
 // same work counters as search_level_v2; what is gone is everything that made the general routine's
@@ -161,20 +161,26 @@ struct VecBF16 {
 };
 
 // search_level (core.rs:607-675) with W in registers; leaves w[] sorted (also copied to Wbuf) and returns |W|.
-template <class VEC, int R, int BB, int DB>
+// WIDE: adjacency rows of up to 128 words (127 ids) -- two row words per lane; the ids of a chunk are first
+// brought to lanes 0.. of one register (two ds_bpermute + a select per chunk), the rest is the narrow code with
+// base 0.  The reference does not bound degrees (core.rs:790-796), M = 32 rows are 112 words, and a restride can
+// widen an M = 16 index past 64: those stay on this kernel instead of falling back to the general one.
+template <class VEC, int R, int BB, int DB, bool WIDE>
 __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64_t *Wbuf, TagSet<BB, DB> &vis,
                                                       const typename VEC::Q &qr, uint32_t ep, uint32_t ef, uint32_t lc,
                                                       WorkCtr &ctr, int lane, unsigned long long *lossy_ctr)
 {
     constexpr int LPV = VEC::LPV, SPR = VEC::SPR, NR = VEC::NR;   // lanes per vector, vectors per round, rounds per chunk
     const int grp = lane / LPV, sub = lane % LPV;
-    const uint32_t stride = lc ? g.strideU : g.stride0;          // <= 64: a row is one wave load
+    const uint32_t stride = lc ? g.strideU : g.stride0;          // <= 64 (WIDE: <= 128): a row is one (two) wave load(s)
 
     tagset_clear<BB, DB>(vis, lane);                                  // core.rs:614
     (void)tagset_visit<BB, DB>(vis, lane == 0, ep);                   // core.rs:617
     vis.count = 1;
     const uint32_t *row = row_ptr(g, ep, lc);
     uint32_t word = (uint32_t)lane < stride ? row[lane] : 0u;     // requested before the distance is computed
+    uint32_t word2 = 0u;
+    if constexpr (WIDE) word2 = (uint32_t)lane + 64u < stride ? row[lane + 64] : 0u;
     uint64_t w[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) w[r] = ~0ull;
@@ -202,7 +208,7 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
         ctr.n_ids += cnt;
         bool have_next = false;
         uint64_t nkey = ~0ull;
-        uint32_t word_next = 0;
+        uint32_t word_next = 0, word2_next = 0;
 
         uint32_t c0 = 0;
         constexpr uint32_t CH = (uint32_t)(NR * SPR);             // ids per chunk
@@ -213,13 +219,23 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
             bool take = false;
             uint64_t rkey = ~0ull;                                // first unexpanded entry of W (last chunk only)
             if (nch) {
-                // slot s = r*SPR + grp of this chunk sits in lane c0 + 1 + s; empty slots re-read the first id
-                const uint32_t safe = (uint32_t)__builtin_amdgcn_readlane((int)word, (int)(c0 + 1));
+                // slot s = r*SPR + grp of this chunk sits in lane base + s of cw; empty slots re-read the first id
+                uint32_t cw, base;
+                if constexpr (WIDE) {
+                    const uint32_t idx = c0 + 1u + (uint32_t)lane;                  // row position this lane fetches
+                    const uint32_t lo = bperm(word, (int)(idx & 63u)), hi = bperm(word2, (int)(idx & 63u));
+                    cw = idx < 64u ? lo : hi;                                        // positions >= 128 are never valid (lane >= nch)
+                    base = 0u;
+                } else {
+                    cw = word;
+                    base = c0 + 1u;
+                }
+                const uint32_t safe = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)base);
                 uint32_t idr[NR];
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
                     const uint32_t s = (uint32_t)(r * SPR + grp);
-                    const uint32_t got = bperm(word, (int)((c0 + 1 + s) & 63u));
+                    const uint32_t got = bperm(cw, (int)((base + s) & 63u));
                     idr[r] = s < nch ? got : safe;
                 }
                 typename VEC::V v[NR];
@@ -231,9 +247,9 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
                     vis.lossy = true;
                     if (lane == 0) atomicAdd(lossy_ctr, 1ull);
                 }
-                const uint32_t li = (uint32_t)lane - (c0 + 1);
+                const uint32_t li = (uint32_t)lane - base;
                 const bool was_lossy = vis.lossy;
-                const uint64_t fm = __ballot(tagset_visit<BB, DB>(vis, li < nch, word));
+                const uint64_t fm = __ballot(tagset_visit<BB, DB>(vis, li < nch, cw));
                 if (vis.lossy && !was_lossy && lane == 0) atomicAdd(lossy_ctr, 1ull);
                 const uint32_t nf = (uint32_t)__popcll(fm);
                 vis.count += nf;
@@ -260,7 +276,7 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
                         idsel = (r == 0 || sub == r) ? idr[r] : idsel;
                     }
                 const uint32_t myslot = (uint32_t)(sub * SPR + grp);
-                const bool mine = sub < NR && myslot < nch && ((fm >> ((c0 + 1 + myslot) & 63u)) & 1ull);
+                const bool mine = sub < NR && myslot < nch && ((fm >> ((base + myslot) & 63u)) & 1ull);
                 key = pack_key(dsel, idsel);
                 take = mine && key < worst;                       // core.rs:657
                 if (vis.lossy) take = drop_members<R>(w, key, take, lane);
@@ -290,6 +306,7 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
                 if (have_next) {
                     row = row_ptr(g, key_id(nkey), lc);
                     word_next = (uint32_t)lane < stride ? row[lane] : 0u;
+                    if constexpr (WIDE) word2_next = (uint32_t)lane + 64u < stride ? row[lane + 64] : 0u;
                 }
                 pkey = key;
                 ptake = take;
@@ -305,6 +322,7 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
         if (__ballot(ptake)) merge_rank<R>(w, pkey, ptake, pup, ppos, lane);
         ckey = nkey;
         word = word_next;
+        word2 = word2_next;
     }
     if (__ballot(ptake)) nW = merge_regs<R>(w, Wbuf, nW, ef, pkey, ptake, lane, &worst);
 #pragma unroll
@@ -315,7 +333,7 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
 }
 
 // HNSW.SEARCH (core.rs:477-486 -> :865-892): one wave per query, grid-stride over the batch.
-template <class VEC, int R, int BB, int DB>
+template <class VEC, int R, int BB, int DB, bool WIDE>
 __global__ __launch_bounds__(64, VEC::MIN_WAVES) void k_search_lean(GraphView g, const float *__restrict__ Q, uint32_t B, uint32_t k,
                                                     uint32_t ef, uint32_t lcap, uint32_t idbits,
                                                     uint32_t *__restrict__ out_ids, float *__restrict__ out_sims,
@@ -338,11 +356,11 @@ __global__ __launch_bounds__(64, VEC::MIN_WAVES) void k_search_lean(GraphView g,
         VEC::load_q(Q + (size_t)qi * g.dim, qr, lane);
         uint32_t ep = (uint32_t)ep0;
         for (uint32_t lc = lmax; lc >= 1; --lc) {  // core.rs:870-874
-            search_level_lean<VEC, 1, BB, DB>(g, Wbuf, vis, qr, ep, 1, lc, ctr, lane, &g.hdr->ctr_search[3]);
+            search_level_lean<VEC, 1, BB, DB, WIDE>(g, Wbuf, vis, qr, ep, 1, lc, ctr, lane, &g.hdr->ctr_search[3]);
             ep = key_id(Wbuf[0]);                  // core.rs:872
             __builtin_amdgcn_wave_barrier();
         }
-        const uint32_t nW = search_level_lean<VEC, R, BB, DB>(g, Wbuf, vis, qr, ep, ef, 0, ctr, lane, &g.hdr->ctr_search[3]); // core.rs:876
+        const uint32_t nW = search_level_lean<VEC, R, BB, DB, WIDE>(g, Wbuf, vis, qr, ep, ef, 0, ctr, lane, &g.hdr->ctr_search[3]); // core.rs:876
         // core.rs:878-890: nearest first, min(k, |W|) results; sim = -dist (metrics.rs:75)
         const uint32_t nres = nW < k ? nW : k;
         for (uint32_t i = lane; i < k; i += 64) {

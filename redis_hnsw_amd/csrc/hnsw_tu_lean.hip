@@ -1,17 +1,18 @@
-// hnsw_tu_lean.hip -- the specialised dim-128 search kernel k_search_lean<VEC,R,BB,DB> for one vector format
-// (HNSW_VARIANT 0: f32 rows, the reference's data; 1: the bf16 serving copy) and its launcher.
+// hnsw_tu_lean.hip -- the specialised dim-128 search kernel k_search_lean<VEC,R,BB,DB,WIDE> for one vector format
+// and row width (HNSW_VARIANT 0: f32 rows, the reference's data; 1: the bf16 serving copy; 2 / 3: the same two
+// for adjacency rows of 64..127 ids) and its launcher.
 #include "hnsw_host.hpp"
 #include "hnsw_search_lean.hpp"
 
 namespace hnsw_host {
 
 // no HBM spill table involved, so no region bookkeeping either
-template <class VEC, int R, int BB, int DB>
+template <class VEC, int R, int BB, int DB, bool WIDE>
 static hnsw_status launch_lean_t(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t idbits, uint32_t per_cu,
                                  uint32_t *d_ids, float *d_sims, uint32_t *d_nout, hipStream_t st)
 {
     const size_t lds = (size_t)R * 64 * 8 + ((size_t)16 << BB);
-    auto kern = k_search_lean<VEC, R, BB, DB>;
+    auto kern = k_search_lean<VEC, R, BB, DB, WIDE>;
     static size_t lds_set[16] = {0};
     hnsw_status ss = raise_lds_attr(h, kern, lds, lds_set);
     if (ss != HNSW_OK) return ss;
@@ -30,7 +31,7 @@ static hnsw_status launch_lean_t(hnsw_index *h, const float *dQ, uint32_t B, uin
     return note_search(h, st);                           // inserts wait for searches in flight
 }
 
-template <class VEC>
+template <class VEC, bool WIDE>
 hnsw_status launch_lean_v(hnsw_index *h, int R, uint32_t bb, uint32_t db, const float *dQ, uint32_t B, uint32_t k,
                           uint32_t idbits, uint32_t per_cu, uint32_t *d_ids, float *d_sims, uint32_t *d_nout,
                           hipStream_t st, bool *done)
@@ -38,7 +39,7 @@ hnsw_status launch_lean_v(hnsw_index *h, int R, uint32_t bb, uint32_t db, const 
     *done = true;
 #define LEAN_CASE(RR, BBB, DDB)                                                                                  \
     if (R == RR && bb == BBB && db == DDB)                                                                      \
-        return launch_lean_t<VEC, RR, BBB, DDB>(h, dQ, B, k, idbits, per_cu, d_ids, d_sims, d_nout, st);
+        return launch_lean_t<VEC, RR, BBB, DDB, WIDE>(h, dQ, B, k, idbits, per_cu, d_ids, d_sims, d_nout, st);
     LEAN_CASE(1, 10, 3) LEAN_CASE(1, 11, 3) LEAN_CASE(4, 10, 3) LEAN_CASE(4, 11, 3)
     LEAN_CASE(1, 10, 2) LEAN_CASE(1, 11, 2) LEAN_CASE(4, 10, 2) LEAN_CASE(4, 11, 2)
     LEAN_CASE(1, 9, 3) LEAN_CASE(4, 9, 3)
@@ -47,12 +48,17 @@ hnsw_status launch_lean_v(hnsw_index *h, int R, uint32_t bb, uint32_t db, const 
     return HNSW_OK;
 }
 
+#define LEAN_INSTANCE(VEC, WIDE)                                                                                          \
+    template hnsw_status launch_lean_v<VEC, WIDE>(hnsw_index *, int, uint32_t, uint32_t, const float *, uint32_t, uint32_t, \
+                                                  uint32_t, uint32_t, uint32_t *, float *, uint32_t *, hipStream_t, bool *);
 #if HNSW_VARIANT == 0
-template hnsw_status launch_lean_v<VecF32<4>>(hnsw_index *, int, uint32_t, uint32_t, const float *, uint32_t, uint32_t, uint32_t,
-                                              uint32_t, uint32_t *, float *, uint32_t *, hipStream_t, bool *);
+LEAN_INSTANCE(VecF32<4>, false)
+#elif HNSW_VARIANT == 1
+LEAN_INSTANCE(VecBF16<4>, false)
+#elif HNSW_VARIANT == 2
+LEAN_INSTANCE(VecF32<4>, true)
 #else
-template hnsw_status launch_lean_v<VecBF16<4>>(hnsw_index *, int, uint32_t, uint32_t, const float *, uint32_t, uint32_t, uint32_t,
-                                               uint32_t, uint32_t *, float *, uint32_t *, hipStream_t, bool *);
+LEAN_INSTANCE(VecBF16<4>, true)
 #endif
 
 } // namespace hnsw_host

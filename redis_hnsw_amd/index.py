@@ -210,6 +210,12 @@ class Index:
         self._check(f(self._h, C.byref(v)))
         return bool(v.value)
 
+    def lean_blocker(self):
+        """development aid: why the specialised dim-128 kernel cannot serve this index ('' = it can)"""
+        f = self._lib.hnsw_debug_lean_blocker
+        f.restype, f.argtypes = C.c_char_p, [_capi.H]
+        return f(self._h).decode()
+
     def last_search_kernel_ms(self):
         ms = C.c_float(0)
         self._check(self._lib.hnsw_last_search_kernel_ms(self._h, C.byref(ms)))

@@ -4,8 +4,8 @@
     (k_search<MODE_AVX,24,8>): size-independent properties on the whole batch + bit-exact sampled parity.
   * the graph bench.py's headline is timed on -- the REFERENCE-ORDER fixture data/c2_ref_graph_1m.npz (the CPU
     oracle's serial build, core.rs:489-599) -- in the bench's launch shape (three 1024-query calls in flight on
-    three streams, the bounded 16 KB visited table) and through the engine's own pipeline (host buffers,
-    B = 8192; one _device call of 4096): ids, similarity bits, n_ids and n_expand against the oracle.
+    three streams, the bounded 16 KB visited table), through the engine's own pipeline (host buffers,
+    B = 8192) and as one _device call of 4096: ids, similarity bits, n_ids and n_expand against the oracle.
   * the reference-order GPU build checked row for row against a committed oracle-built fixture (50 k nodes),
     the same check bench.py's gpu_exact_build leg makes.
 """
@@ -123,7 +123,7 @@ def test_reference_order_fixture_parity_in_the_bench_launch_shape(eng, oracle_mo
     sel = slice(7 * B + 500, 7 * B + 532)
     o2 = o.search_batch(Qall[sel], k, threads=8)
     assert np.array_equal(ids8[sel], o2[0]) and np.array_equal(_bits(sims8[sel]), _bits(o2[1]))
-    # ... and one _device call of 4096 queries (4 chunks, joined back into the caller's stream)
+    # ... and one _device call of 4096 queries (one launch, one workgroup per query)
     ids_t = torch.empty((4 * B, k), dtype=torch.int32, device=dev)
     sims_t = torch.empty((4 * B, k), dtype=torch.float32, device=dev)
     n_t = torch.empty((4 * B,), dtype=torch.int32, device=dev)

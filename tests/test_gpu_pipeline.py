@@ -73,6 +73,7 @@ def test_pipelined_device_call_joins_back_into_the_callers_stream(eng, small):
     g["vectors"] = V
     gi = eng.Index("pipe-dev", dim, m, ef)
     gi.import_graph(g)
+    gi.set_tuning("pipe_device", 1)                                # off by default (one launch per call is faster)
     gi.set_tuning("pipe_chunk", 200)
     gi.set_tuning("pipe_min_batch", 400)
     dev = torch.device("cuda", 0)
@@ -142,18 +143,21 @@ def test_callers_own_streams_need_no_tuning(eng, small):
 
 # ---- advisor findings, round 2 ---------------------------------------------------------------------
 def test_delete_keeps_an_m16_index_on_the_specialised_kernel(eng, oracle_mod):
-    """HNSW.NODE.DEL asks for row slack by the deleted node's own degree, not by the index's maximum: an M = 16
-    index (rows of 63 ids) is not restrided by its first delete and keeps the dim-128 kernel."""
+    """HNSW.NODE.DEL asks for row slack by the deleted node's own degree, not by the index's maximum, so deletes
+    do not widen the rows of an M = 16 index; and rows of up to 127 ids (a hub of a small index, a restride) are
+    still served by the dim-128 kernel (its two-row-word form)."""
     n, dim, m, ef = 3000, 128, 16, 200
     V = make_data(n, dim, seed=3)
     o, lv = build_oracle(oracle_mod, V, m, ef)
     gi = eng.Index("del16", dim, m, ef)
     gi.add_batch(V, levels=lv, mode="exact")
     Q = make_data(64, dim, seed=4)
-    gi.search_batch(Q, 10)
-    assert gi.last_search_was_lean()
+    ids, sims, n_out = gi.search_batch(Q, 10)
     inf0 = gi.info()
-    assert inf0.stride0 == 64 and inf0.max_degree0 >= 2 * m
+    assert gi.last_search_was_lean(), (gi.lean_blocker(), inf0.stride0, inf0.stride_upper, inf0.max_degree0, inf0.max_degree_upper)
+    oids, osims, on, _ = o.search_batch(Q, 10)
+    assert np.array_equal(ids, oids) and np.array_equal(_bits(sims), _bits(osims)) and np.array_equal(n_out, on)
+    assert inf0.max_degree0 >= 2 * m
     for i in (5, 700, 1999, 2500):
         gi.delete_node("node%d" % i)
         o.delete(i)
@@ -166,28 +170,73 @@ def test_delete_keeps_an_m16_index_on_the_specialised_kernel(eng, oracle_mod):
     gi.close(); o.close()
 
 
+@pytest.mark.parametrize("m,widen", [(16, 0), (16, 32), (32, 0), (24, 0)])
+def test_wide_rows_stay_on_the_specialised_kernel(eng, oracle_mod, m, widen):
+    """rows of 64..127 ids (M > 16, or an M = 16 index after a restride): same answers and counters as the oracle,
+    through the two-row-word form of the dim-128 kernel, with the bounded table and with the exact one"""
+    n, dim, ef, k = 2500, 128, 200, 10
+    V = make_data(n, dim, seed=13)
+    o, lv = build_oracle(oracle_mod, V, m, ef)
+    g = o.export()
+    g["vectors"] = V
+    gi = eng.Index("wide", dim, m, ef)
+    gi.import_graph(g)
+    if widen:
+        gi.set_tuning("force_restride", widen)
+    inf = gi.info()
+    assert (inf.stride0 > 64) == (m > 16 or widen > 0)
+    Q = make_data(300, dim, seed=14)
+    gi.reset_counters()
+    ids, sims, n_out = gi.search_batch(Q, k)
+    assert gi.last_search_was_lean(), gi.lean_blocker()
+    oids, osims, on, oct = o.search_batch(Q, k, threads=8)
+    assert np.array_equal(ids, oids) and np.array_equal(_bits(sims), _bits(osims)) and np.array_equal(n_out, on)
+    sc, _ = gi.counters()
+    assert (sc.n_ids, sc.n_expand) == (oct.n_ids, oct.n_expand) and sc.n_dist >= oct.n_dist
+    gi.set_tuning("waves_per_cu", 4)                               # the 32 KB table: nothing is forgotten at this size
+    gi.reset_counters()
+    ids2, sims2, _ = gi.search_batch(Q, k)
+    sc, _ = gi.counters()
+    assert np.array_equal(ids2, oids) and (sc.n_dist, sc.n_ids, sc.n_expand) == (oct.n_dist, oct.n_ids, oct.n_expand)
+    gi.close(); o.close()
+
+
 def test_compress_bf16_is_refused_when_no_kernel_could_serve_it(eng, oracle_mod):
     dim = 128
     Q = make_data(32, dim, seed=4)
-    # M = 32: rows of 112 words -- the specialised kernel does not apply; the index must stay as it was
     V = make_data(1500, dim, seed=3)
-    a = eng.Index("bf-m32", dim, 32, 64)
+    # ef = 400 (W needs more than 256 register slots): the specialised kernel does not apply; the index must stay as it was
+    a = eng.Index("bf-ef400", dim, 16, 400)
     a.add_batch(V, mode="fast")
     before = a.search_batch(Q, 10)
     with pytest.raises(eng.HNSWError) as e:
         a.set_tuning("compress_bf16", 1)
-    assert "rows wider" in e.value.msg
+    assert "ef_construction" in e.value.msg
     after = a.search_batch(Q, 10)
     assert np.array_equal(before[0], after[0]) and np.array_equal(_bits(before[1]), _bits(after[1]))
     a.add_node("still-writable", V[0] * 0.5)
     a.close()
-    # ef = 400 (R = 8): same
-    b = eng.Index("bf-ef400", dim, 16, 400)
+    # rows wider than 127 ids: same
+    b = eng.Index("bf-wide", dim, 32, 64)
     b.add_batch(V, mode="fast")
-    with pytest.raises(eng.HNSWError):
+    b.set_tuning("force_restride", 32)
+    with pytest.raises(eng.HNSWError) as e:
         b.set_tuning("compress_bf16", 1)
+    assert "rows wider" in e.value.msg
     assert np.all(b.search_batch(Q, 10)[2] == 10)
     b.close()
+    # M = 32 (rows of 112 words) is served by the wide form: converts, answers like the oracle on the rounded vectors
+    c32 = eng.Index("bf-m32", dim, 32, 64)
+    c32.add_batch(V, mode="fast")
+    g = c32.export_graph()
+    c32.set_tuning("compress_bf16", 1)
+    got = c32.search_batch(Q, 10)
+    Vr = np.stack([c32._vector(i) for i in range(V.shape[0])])
+    g["vectors"] = Vr
+    o = oracle_mod.OracleIndex.from_graph(dim, 32, 64, g)
+    want = o.search_batch(Q, 10)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(_bits(got[1]), _bits(want[1]))
+    c32.close(); o.close()
     # an eligible index converts, and afterwards the knobs that would strand it are refused
     c = eng.Index("bf-ok", dim, 16, 200)
     c.add_batch(V, mode="fast")
