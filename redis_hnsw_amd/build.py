@@ -27,7 +27,10 @@ SOURCES = [u[0] for u in UNITS]
 DEPS = sorted(set(SOURCES + _COMMON + [d for u in UNITS for d in u[2]]))
 # -ffp-contract=off: the metric must round exactly where the reference's does
 # (explicit fma only, metrics.rs:57); never -ffast-math.
-FLAGS = ["--offload-arch=gfx950", "-Os", "-std=c++17", "-ffp-contract=off", "-fPIC",
+# -fno-slp-vectorize: the SLP vectoriser pairs the scalar adds of the metric's reduction tree into v_pk_add_f32 and
+# leaves their DPP operands behind as separate v_mov_dpp (6 instructions per exchange step instead of 4
+# v_add_f32_dpp); the packed arithmetic of the distance loop is written out by hand and does not need it.
+FLAGS = ["--offload-arch=gfx950", "-Os", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
          "-Wall", "-Wno-unused-function", "-Wno-undefined-func-template"]
 
 

@@ -160,6 +160,55 @@ struct VecBF16 {
     }
 };
 
+// ---- W's merge, straight-line form ---------------------------------------------------------------------
+// Same result as merge_apply / merge_regs of hnsw_device.hpp (the list ends as the top-`cap` of the union, the
+// reference's one-by-one pushes of core.rs:657-664), without a predicated LDS access: Wbuf carries 64 slots of
+// slack and one trash slot, so
+//   * every lane scatters all its R entries -- slots past nW hold ~0 with up[r] = (number of new keys), land at
+//     or beyond the merged length and so PAD the list with ~0;
+//   * entries pushed past `cap` land in [cap, R*64 + 64) and are masked when read back;
+//   * lanes without a new key write theirs to the trash slot.
+// The accept threshold of the next expansion (core.rs:651) is slot cap-1: a key once the list is full, padding
+// (~0 = "accept everything") before.
+template <int R>
+struct LeanW {
+    static constexpr uint32_t kSlots = R * 64 + 64 + 8;        // + slack for the scatter + trash (keeps 64-byte multiples)
+    static constexpr uint32_t kTrash = R * 64 + 64;
+    static constexpr size_t kBytes = (size_t)kSlots * 8;
+};
+
+template <int R>
+__device__ __forceinline__ uint32_t merge_apply_lean(uint64_t (&w)[R], uint64_t *Wbuf, uint32_t nW, uint32_t cap, uint64_t nk,
+                                                     bool take, const uint32_t (&up)[R], uint32_t mypos, uint32_t n_new,
+                                                     int lane, uint64_t &worst)
+{
+    uint32_t total = nW + n_new;
+    if (total > cap) total = cap;
+#pragma unroll
+    for (int r = 0; r < R; ++r) Wbuf[(uint32_t)(r * 64 + lane) + up[r]] = w[r];
+    Wbuf[take ? mypos : LeanW<R>::kTrash] = nk;
+    __builtin_amdgcn_wave_barrier();                    // one wave owns Wbuf; the LDS serves it in issue order
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint64_t v = Wbuf[r * 64 + lane];
+        w[r] = (uint32_t)(r * 64 + lane) < cap ? v : ~0ull;
+    }
+    worst = Wbuf[cap - 1];
+    __builtin_amdgcn_wave_barrier();
+    return total;
+}
+
+template <int R>
+__device__ __forceinline__ uint32_t merge_regs_lean(uint64_t (&w)[R], uint64_t *Wbuf, uint32_t nW, uint32_t cap, uint64_t nk,
+                                                    bool take, int lane, uint64_t &worst)
+{
+    const uint64_t mm = __ballot(take);
+    if (mm == 0) return nW;
+    uint32_t up[R], mypos;
+    merge_rank<R>(w, nk, take, up, mypos, lane);
+    return merge_apply_lean<R>(w, Wbuf, nW, cap, nk, take, up, mypos, (uint32_t)__popcll(mm), lane, worst);
+}
+
 // search_level (core.rs:607-675) with W in registers; leaves w[] sorted (also copied to Wbuf) and returns |W|.
 // WIDE: adjacency rows of up to 128 words (127 ids) -- two row words per lane; the ids of a chunk are first
 // brought to lanes 0.. of one register (two ds_bpermute + a select per chunk), the rest is the narrow code with
@@ -197,7 +246,7 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
     uint64_t worst = ef == 1 ? ckey : ~0ull;                      // W's ef-th key once it is full (core.rs:651)
     uint64_t pkey = ~0ull;                                        // keys of the last chunk, merged one expansion later
     bool ptake = false;
-    uint32_t pup[R], ppos = 0;
+    uint32_t pup[R], ppos = 0, pn = 0;                            // ranks of the pending keys and their count
 #pragma unroll
     for (int r = 0; r < R; ++r) pup[r] = 0;
 
@@ -238,10 +287,12 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
                     const uint32_t got = bperm(cw, (int)((base + s) & 63u));
                     idr[r] = s < nch ? got : safe;
                 }
+                // all NR rounds are requested: the slots a short chunk does not use re-read its first vector (one
+                // line per group, already on its way), which is cheaper than predicating the loads -- the registers
+                // of a skipped load would have to be given a value on the other path
                 typename VEC::V v[NR];
 #pragma unroll
-                for (int r = 0; r < NR; ++r)
-                    if (r == 0 || nch > (uint32_t)(r * SPR)) VEC::load_v(g, idr[r], lane, v[r]);   // uniform: skipped rounds cost nothing
+                for (int r = 0; r < NR; ++r) VEC::load_v(g, idr[r], lane, v[r]);
                 // ---- under those loads: visited filter (core.rs:648-649) and the deferred merge ----
                 if (!vis.lossy && vis.count + CH > vis.lcap) {
                     vis.lossy = true;
@@ -254,9 +305,10 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
                 const uint32_t nf = (uint32_t)__popcll(fm);
                 vis.count += nf;
                 ctr.n_dist += nf;                                 // the reference evaluates the fresh ones (core.rs:652)
-                if (__ballot(ptake)) {
-                    nW = merge_apply<R>(w, Wbuf, nW, ef, pkey, ptake, pup, ppos, lane, &worst);
+                if (pn) {
+                    nW = merge_apply_lean<R>(w, Wbuf, nW, ef, pkey, ptake, pup, ppos, pn, lane, worst);
                     ptake = false;
+                    pn = 0;
                 }
                 if (last) {
                     // W is complete: its first unexpanded entry is the next candidate unless one of this chunk's
@@ -281,15 +333,16 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
                 take = mine && key < worst;                       // core.rs:657
                 if (vis.lossy) take = drop_members<R>(w, key, take, lane);
             } else {
-                if (__ballot(ptake)) {
-                    nW = merge_apply<R>(w, Wbuf, nW, ef, pkey, ptake, pup, ppos, lane, &worst);
+                if (pn) {
+                    nW = merge_apply_lean<R>(w, Wbuf, nW, ef, pkey, ptake, pup, ppos, pn, lane, worst);
                     ptake = false;
+                    pn = 0;
                 }
                 int r2, l2;
                 if (!first_unexpanded<R>(w, rkey, r2, l2)) rkey = ~0ull;
             }
             if (!last) {
-                nW = merge_regs<R>(w, Wbuf, nW, ef, key, take, lane, &worst);   // core.rs:659-664
+                nW = merge_regs_lean<R>(w, Wbuf, nW, ef, key, take, lane, worst);   // core.rs:659-664
             } else {
                 // The next candidate is known before these keys are merged: the nearest accepted new key if
                 // it beats the first unexpanded entry of W, else that entry.  Its row is requested now; the
@@ -319,12 +372,13 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
 #pragma unroll
         for (int r = 0; r < R; ++r) w[r] |= (w[r] == nkey) ? 1ull : 0ull;
         if (ptake && pkey == nkey) pkey |= 1ull;
-        if (__ballot(ptake)) merge_rank<R>(w, pkey, ptake, pup, ppos, lane);
+        pn = (uint32_t)__popcll(__ballot(ptake));
+        if (pn) merge_rank<R>(w, pkey, ptake, pup, ppos, lane);
         ckey = nkey;
         word = word_next;
         word2 = word2_next;
     }
-    if (__ballot(ptake)) nW = merge_regs<R>(w, Wbuf, nW, ef, pkey, ptake, lane, &worst);
+    nW = merge_regs_lean<R>(w, Wbuf, nW, ef, pkey, ptake, lane, worst);
 #pragma unroll
     for (int r = 0; r < R; ++r) Wbuf[r * 64 + lane] = w[r];
     __builtin_amdgcn_wave_barrier();
@@ -341,9 +395,9 @@ __global__ __launch_bounds__(64, VEC::MIN_WAVES) void k_search_lean(GraphView g,
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
-    uint64_t *Wbuf = reinterpret_cast<uint64_t *>(smem);                       // [R*64]
+    uint64_t *Wbuf = reinterpret_cast<uint64_t *>(smem);                       // [LeanW<R>::kSlots]
     TagSet<BB, DB> vis;
-    vis.tab = reinterpret_cast<uint32_t *>(smem + (size_t)R * 64 * 8);
+    vis.tab = reinterpret_cast<uint32_t *>(smem + LeanW<R>::kBytes);
     vis.idbits = idbits;
     vis.lcap = lcap;
     vis.count = 0;

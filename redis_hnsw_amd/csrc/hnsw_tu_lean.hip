@@ -11,7 +11,7 @@ template <class VEC, int R, int BB, int DB, bool WIDE>
 static hnsw_status launch_lean_t(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t idbits, uint32_t per_cu,
                                  uint32_t *d_ids, float *d_sims, uint32_t *d_nout, hipStream_t st)
 {
-    const size_t lds = (size_t)R * 64 * 8 + ((size_t)16 << BB);
+    const size_t lds = LeanW<R>::kBytes + ((size_t)16 << BB);
     auto kern = k_search_lean<VEC, R, BB, DB, WIDE>;
     static size_t lds_set[16] = {0};
     hnsw_status ss = raise_lds_attr(h, kern, lds, lds_set);
