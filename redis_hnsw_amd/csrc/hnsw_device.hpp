@@ -826,7 +826,8 @@ __device__ __forceinline__ void merge_rank(const uint64_t (&w)[R], uint64_t nk, 
             rank += __popcll(__ballot(below));
             stay[r] += below ? 1u : 0u;
         }
-        mypos = lane == j ? rank : mypos;
+        // lane j's position: rank and j are wave-uniform SALU results (no VALU-written SGPR feeds the lane select)
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(mypos) : "s"(rank), "s"(j));
     }
     const uint32_t n = (uint32_t)__popcll(mm0);
 #pragma unroll

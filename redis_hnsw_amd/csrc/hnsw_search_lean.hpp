@@ -368,10 +368,14 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
         } while (c0 < cnt);
 
         if (!have_next) break;                                    // core.rs:630,635
-        // mark the chosen entry expanded (core.rs:631 pop)
+        // mark the chosen entry expanded (core.rs:631 pop).  Ids are unique in W and among the pending keys, and the
+        // chosen key is unexpanded: its low word (id << 1) identifies it, and adding the match sets bit 0
+        {
+            const uint32_t nlo = (uint32_t)nkey;
 #pragma unroll
-        for (int r = 0; r < R; ++r) w[r] |= (w[r] == nkey) ? 1ull : 0ull;
-        if (ptake && pkey == nkey) pkey |= 1ull;
+            for (int r = 0; r < R; ++r) w[r] += ((uint32_t)w[r] == nlo) ? 1ull : 0ull;
+            pkey += (ptake && (uint32_t)pkey == nlo) ? 1ull : 0ull;
+        }
         pn = (uint32_t)__popcll(__ballot(ptake));
         if (pn) merge_rank<R>(w, pkey, ptake, pup, ppos, lane);
         ckey = nkey;

@@ -24,9 +24,12 @@ Q = np.random.default_rng(2).random((8 * B, dim), dtype=np.float32)
 g, _ = load_graph_fixture(FIXTURES[(N, dim, M, ef)], V)
 ix = Index("ab", dim, M, ef)
 ix.import_graph(g)
+for kv in os.environ.get("HNSW_TUNING", "").split(","):
+    if kv:
+        ix.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
 dev = torch.device("cuda", 0)
 dQ = torch.from_numpy(Q).to(dev)
-S = 3
+S = int(os.environ.get("HNSW_STREAMS", "3"))
 streams = [torch.cuda.Stream() for _ in range(S)]
 outs = [(torch.empty((4 * B, k), dtype=torch.int32, device=dev), torch.empty((4 * B, k), dtype=torch.float32, device=dev),
          torch.empty((4 * B,), dtype=torch.int32, device=dev)) for _ in range(S)]
@@ -83,3 +86,9 @@ for q in Q[:400]:
     g1.search_knn(q, k)
 c1 = (time.perf_counter() - t0) / 400
 print("c1     %.1f us / query, identical: %s" % (1e6 * c1, same))
+g1.set_tuning("time_launches", 1)
+ks = []
+for q in Q[:100]:
+    g1.search_knn(q, k)
+    ks.append(g1.last_search_kernel_ms())
+print("c1     kernel alone %.1f us (median of 100, HIP events around the launch)" % (1e3 * float(np.median(ks))))
