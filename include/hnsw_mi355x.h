@@ -152,6 +152,37 @@ hnsw_status hnsw_import(hnsw_index *h, uint32_t n, const float *vectors,
                         const uint32_t *levels, int64_t enterpoint, uint32_t n_layers,
                         const uint64_t *const *row_ptr, const uint32_t *const *col);
 
+/* One-time index distribution to replicas (search_knn takes &self, core.rs:477, so every GPU may
+ * hold a copy), without a host hop: the tables are handed out as DEVICE pointers, so that a collective
+ * (RCCL broadcast over xGMI) or a peer copy moves them HBM to HBM.
+ *   source       hnsw_replica_view(src, &r)          r = sizes + pointers into src's HBM (valid until the next
+ *                                                     call that grows, restrides, inserts into or destroys src)
+ *   destination  copy r's scalar fields from the source's, then
+ *                hnsw_replica_prepare(dst, &r)       allocates for them on dst's device, fills in dst's pointers
+ *                <move vec_bytes / adj0_bytes / adj_upper_bytes / 4n / 4n bytes into vec, adj0, adj_upper,
+ *                 upper_base, levels -- in the source's row layout: stride0 / stride_upper words per row>
+ *                hnsw_replica_commit(dst, &r, dead)  adopts the tables; dead = n tombstone bytes (0/1, host
+ *                                                     memory) or NULL when n_dead = 0
+ * dst must be an empty index created with the source's dim, M and ef_construction.  The replica is an exact copy
+ * (same rows in the same stored order, same enterpoint): it answers every search bit for bit like the source,
+ * and continues like it under exact inserts and deletes (its level generator keeps its own seed).            */
+typedef struct {
+    uint32_t n;                /* ids handed out (rows of vec / adj0 / levels / upper_base)                   */
+    uint32_t dim;
+    uint32_t upper_used;       /* rows of adj_upper                                                            */
+    uint32_t stride0, stride_upper;
+    uint32_t max_layer, max_degree0, max_degree_upper;
+    uint32_t n_dead, asymmetric, bf16;
+    uint32_t reserved;
+    int64_t enterpoint;
+    uint64_t vec_bytes, adj0_bytes, adj_upper_bytes;
+    void *vec, *adj0, *adj_upper, *upper_base, *levels;    /* device memory                                    */
+} hnsw_replica;
+hnsw_status hnsw_replica_view(hnsw_index *h, hnsw_replica *out);
+hnsw_status hnsw_replica_prepare(hnsw_index *h, hnsw_replica *inout);
+hnsw_status hnsw_replica_commit(hnsw_index *h, const hnsw_replica *r, const uint8_t *dead);
+hnsw_status hnsw_get_tombstones(hnsw_index *h, uint8_t *dead /*[allocated_ids]*/);
+
 /* Export for IndexRedis/NodeRedis write-through (src/types.rs:62-91,292-309). */
 hnsw_status hnsw_get_info(hnsw_index *h, hnsw_info *info);
 hnsw_status hnsw_get_levels(hnsw_index *h, uint32_t *levels /*[node_count]*/);

@@ -20,6 +20,18 @@ class Info(C.Structure):
                 ("allocated_ids", C.c_uint32)]
 
 
+class Replica(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("dim", C.c_uint32), ("upper_used", C.c_uint32), ("stride0", C.c_uint32),
+                ("stride_upper", C.c_uint32), ("max_layer", C.c_uint32), ("max_degree0", C.c_uint32),
+                ("max_degree_upper", C.c_uint32), ("n_dead", C.c_uint32), ("asymmetric", C.c_uint32), ("bf16", C.c_uint32),
+                ("reserved", C.c_uint32), ("enterpoint", C.c_int64), ("vec_bytes", C.c_uint64), ("adj0_bytes", C.c_uint64),
+                ("adj_upper_bytes", C.c_uint64), ("vec", C.c_void_p), ("adj0", C.c_void_p), ("adj_upper", C.c_void_p),
+                ("upper_base", C.c_void_p), ("levels", C.c_void_p)]
+
+    SCALARS = ("n", "dim", "upper_used", "stride0", "stride_upper", "max_layer", "max_degree0", "max_degree_upper", "n_dead",
+               "asymmetric", "bf16", "enterpoint")
+
+
 class Pipeline(C.Structure):
     _fields_ = [("lanes", C.c_uint32), ("overlap", C.c_int32), ("probe_ratio", C.c_float), ("priorities", C.c_uint32),
                 ("chunk", C.c_uint32), ("min_batch", C.c_uint32), ("hw_queues_env", C.c_uint32)]
@@ -44,6 +56,10 @@ SIGNATURES = {
     "hnsw_search_batch_device": (C.c_int, [H, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p]),
     "hnsw_pipeline_info": (C.c_int, [H, C.POINTER(Pipeline)]),
+    "hnsw_replica_view": (C.c_int, [H, C.POINTER(Replica)]),
+    "hnsw_replica_prepare": (C.c_int, [H, C.POINTER(Replica)]),
+    "hnsw_replica_commit": (C.c_int, [H, C.POINTER(Replica), C.POINTER(C.c_uint8)]),
+    "hnsw_get_tombstones": (C.c_int, [H, C.POINTER(C.c_uint8)]),
     "hnsw_import": (C.c_int, [H, C.c_uint32, fp, u32p, C.c_int64, C.c_uint32, C.POINTER(u64p), C.POINTER(u32p)]),
     "hnsw_get_info": (C.c_int, [H, C.POINTER(Info)]),
     "hnsw_get_levels": (C.c_int, [H, u32p]),

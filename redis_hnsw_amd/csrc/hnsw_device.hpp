@@ -826,8 +826,7 @@ __device__ __forceinline__ void merge_rank(const uint64_t (&w)[R], uint64_t nk, 
             rank += __popcll(__ballot(below));
             stay[r] += below ? 1u : 0u;
         }
-        // lane j's position: rank and j are wave-uniform SALU results (no VALU-written SGPR feeds the lane select)
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(mypos) : "s"(rank), "s"(j));
+        mypos = lane == j ? rank : mypos;
     }
     const uint32_t n = (uint32_t)__popcll(mm0);
 #pragma unroll

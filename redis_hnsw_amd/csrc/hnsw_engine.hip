@@ -1257,6 +1257,103 @@ hnsw_status hnsw_import(hnsw_index *h, uint32_t n, const float *vectors, const u
     return push_header(h);
 }
 
+// ---- replicas: the index tables as device pointers (one-time distribution over RCCL / peer copies) ----------
+hnsw_status hnsw_replica_view(hnsw_index *h, hnsw_replica *out)
+{
+    if (!h || !out) return HNSW_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));          // everything the engine enqueued has landed
+    std::memset(out, 0, sizeof *out);
+    out->n = h->n; out->dim = h->dim; out->upper_used = h->upper_used;
+    out->stride0 = h->stride0; out->stride_upper = h->strideU;
+    out->max_layer = h->max_layer; out->max_degree0 = h->max_deg0; out->max_degree_upper = h->max_degU;
+    out->n_dead = h->n_dead; out->asymmetric = h->asymmetric ? 1u : 0u; out->bf16 = h->bf16 ? 1u : 0u;
+    out->enterpoint = h->enterpoint;
+    out->vec_bytes = (uint64_t)h->n * h->dim * (h->bf16 ? 2 : 4);
+    out->adj0_bytes = (uint64_t)h->n * h->stride0 * 4;
+    out->adj_upper_bytes = (uint64_t)h->upper_used * h->strideU * 4;
+    out->vec = h->d_vec; out->adj0 = h->d_adj0; out->adj_upper = h->d_adjU;
+    out->upper_base = h->d_upper_base; out->levels = h->d_levels;
+    return HNSW_OK;
+}
+
+hnsw_status hnsw_replica_prepare(hnsw_index *h, hnsw_replica *r)
+{
+    if (!h || !r) return HNSW_ERR_INVALID;
+    if (h->n != 0 || h->bf16) return fail(h, HNSW_ERR_INVALID, "hnsw_replica_prepare needs an empty index");
+    if (r->dim != h->dim) return fail(h, HNSW_ERR_DIM_MISMATCH, "replica: data dimension does not match Index");
+    if (r->n == 0 || r->enterpoint >= (int64_t)r->n || r->max_layer >= kMaxLayers || r->n_dead > r->n ||
+        r->stride0 < h->stride0 || r->stride_upper < h->strideU || r->stride0 > kAuxWords || r->stride_upper > kAuxWords ||
+        (r->stride0 & 15) || (r->stride_upper & 15) || r->max_degree0 >= r->stride0 || r->max_degree_upper >= r->stride_upper)
+        return fail(h, HNSW_ERR_INVALID, "replica: inconsistent header (the source must have the same M)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hnsw_status s;
+    if ((s = restride(h, r->stride0, r->stride_upper)) != HNSW_OK) return s;      // the source's row layout
+    if ((s = ensure_node_cap(h, r->n)) != HNSW_OK) return s;
+    if ((s = ensure_upper_cap(h, std::max(r->upper_used, 1u))) != HNSW_OK) return s;
+    if (r->bf16 && lean_blocker(h)) return fail(h, HNSW_ERR_INVALID, "replica: a bf16 source needs an index the specialised kernel can serve");
+    if (r->bf16) {
+        // the vector matrix of a bf16 replica is half the size: swap the f32 allocation for a bf16 one now
+        unsigned short *d16 = nullptr;
+        const size_t nel = (size_t)h->cap * h->dim;
+        HIP_TRY(h, hipMalloc((void **)&d16, std::max<size_t>(nel, 1) * 2));
+        HIP_TRY(h, hipDeviceSynchronize());
+        (void)hipFree(h->d_vec);
+        h->hbm_bytes -= std::min<uint64_t>(h->hbm_bytes, nel * 2);
+        h->d_vec = reinterpret_cast<float *>(d16);
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));          // the allocations' fills are done before anyone writes
+    r->vec_bytes = (uint64_t)r->n * h->dim * (r->bf16 ? 2 : 4);
+    r->adj0_bytes = (uint64_t)r->n * h->stride0 * 4;
+    r->adj_upper_bytes = (uint64_t)r->upper_used * h->strideU * 4;
+    r->vec = h->d_vec; r->adj0 = h->d_adj0; r->adj_upper = h->d_adjU;
+    r->upper_base = h->d_upper_base; r->levels = h->d_levels;
+    h->bf16 = r->bf16 != 0;                               // the tables are being filled: not searchable until commit (n == 0)
+    return HNSW_OK;
+}
+
+hnsw_status hnsw_replica_commit(hnsw_index *h, const hnsw_replica *r, const uint8_t *dead)
+{
+    if (!h || !r) return HNSW_ERR_INVALID;
+    if (h->n != 0) return fail(h, HNSW_ERR_INVALID, "hnsw_replica_commit: the index is not empty");
+    if (r->vec != h->d_vec || r->adj0 != h->d_adj0 || r->levels != h->d_levels || r->stride0 != h->stride0 ||
+        r->stride_upper != h->strideU || r->n == 0 || r->n > h->cap || r->upper_used > h->upper_cap)
+        return fail(h, HNSW_ERR_INVALID, "hnsw_replica_commit: not the block hnsw_replica_prepare returned");
+    if (r->n_dead && !dead) return fail(h, HNSW_ERR_INVALID, "hnsw_replica_commit: tombstones missing");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());                   // whoever filled the tables (a collective's stream) is done
+    // the host mirrors the engine keeps: levels, upper slots, tombstones
+    h->h_levels.assign(h->cap, 0);
+    h->h_upper_base.assign(h->cap, kNoUpper);
+    h->h_dead.assign(h->cap, 0);
+    HIP_TRY(h, hipMemcpy(h->h_levels.data(), h->d_levels, (size_t)r->n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(h->h_upper_base.data(), h->d_upper_base, (size_t)r->n * 4, hipMemcpyDeviceToHost));
+    uint32_t used = 0, nd = 0;
+    for (uint32_t i = 0; i < r->n; ++i) {
+        if (h->h_levels[i] >= kMaxLayers) return fail(h, HNSW_ERR_INVALID, "replica: level too large");
+        if (h->h_levels[i] > 0) {
+            if (h->h_upper_base[i] != used) return fail(h, HNSW_ERR_INVALID, "replica: upper slots are not in id order");
+            used += h->h_levels[i];
+        }
+        if (dead) { h->h_dead[i] = dead[i] ? 1 : 0; nd += h->h_dead[i]; }
+    }
+    if (used != r->upper_used || nd != r->n_dead) return fail(h, HNSW_ERR_INVALID, "replica: slot / tombstone counts do not match the header");
+    if (r->enterpoint >= 0 && (h->h_dead[r->enterpoint] || h->h_levels[r->enterpoint] != r->max_layer))
+        return fail(h, HNSW_ERR_INVALID, "replica: the enterpoint must be a live node of the top layer");
+    h->n = r->n; h->n_dead = r->n_dead; h->upper_used = r->upper_used;
+    h->enterpoint = r->enterpoint; h->max_layer = r->max_layer;
+    h->max_deg0 = r->max_degree0; h->max_degU = r->max_degree_upper;
+    h->asymmetric = r->asymmetric != 0;
+    return push_header(h);
+}
+
+hnsw_status hnsw_get_tombstones(hnsw_index *h, uint8_t *dead)
+{
+    if (!h || !dead) return HNSW_ERR_INVALID;
+    std::copy(h->h_dead.begin(), h->h_dead.begin() + h->n, dead);
+    return HNSW_OK;
+}
+
 hnsw_status hnsw_get_info(hnsw_index *h, hnsw_info *info)
 {
     if (!h || !info) return HNSW_ERR_INVALID;

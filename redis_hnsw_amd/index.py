@@ -310,6 +310,37 @@ class Index:
         self._check(self._lib.hnsw_get_neighbors(self._h, int(i), int(layer), _u32p(out), cap, C.byref(n)))
         return out[: n.value].copy()
 
+    # -- replicas (one-time index distribution) ------------------------------------------
+    def replica_view(self):
+        """sizes + DEVICE pointers of this index's tables (hnsw_replica_view)"""
+        r = _capi.Replica()
+        self._check(self._lib.hnsw_replica_view(self._h, C.byref(r)))
+        return r
+
+    def replica_prepare(self, scalars):
+        """allocate for a source's tables (dict of _capi.Replica.SCALARS) on this empty index -> Replica with pointers"""
+        r = _capi.Replica()
+        for key in _capi.Replica.SCALARS:
+            setattr(r, key, int(scalars[key]))
+        self._check(self._lib.hnsw_replica_prepare(self._h, C.byref(r)))
+        return r
+
+    def replica_commit(self, r, dead=None, names=None):
+        d = None
+        if dead is not None:
+            d = np.ascontiguousarray(dead, dtype=np.uint8)
+        self._check(self._lib.hnsw_replica_commit(self._h, C.byref(r), d.ctypes.data_as(C.POINTER(C.c_uint8)) if d is not None else None))
+        n = int(r.n)
+        self._names = list(names) if names is not None else ["node%d" % i for i in range(n)]
+        self._ids = {nm: i for i, nm in enumerate(self._names) if nm is not None}
+
+    def tombstones(self):
+        n = int(self.info().allocated_ids)
+        d = np.zeros(max(n, 1), dtype=np.uint8)
+        if n:
+            self._check(self._lib.hnsw_get_tombstones(self._h, d.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return d[:n]
+
     # -- counters / knobs -----------------------------------------------------------
     def counters(self):
         s, i = _capi.Counters(), _capi.Counters()
