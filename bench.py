@@ -286,16 +286,20 @@ def main():
         index.set_tuning(key, int(val))
     graph = None
     t_build = None
+    replication = None
     graph_desc = {"reference": "reference-order (serial core.rs:489-599 order; fixture built by the CPU oracle, imported with hnsw_import)",
                   "exact": "reference-order, built on the GPU (hnsw_add_batch mode 0)",
                   "fast": "batched GPU build (hnsw_add_batch mode 1; NOT the reference's graph)"}[mode]
+    replicate = world > 1 and os.environ.get("HNSW_BENCH_REPLICATE", "1") != "0"
     if mode == "reference":
-        # every rank reads the fixture itself: the one-time index distribution of a deployment
-        graph, oracle_build_s = load_graph_fixture(fixture, V)
-        tb = time.time()
-        index.import_graph(graph)
-        torch.cuda.synchronize()
-        log("imported the reference-order graph (%d nodes) in %.2f s" % (N, time.time() - tb))
+        # rank 0 imports the fixture; the replicas receive the index over RCCL (HNSW_BENCH_REPLICATE=0: every rank
+        # reads the fixture itself instead)
+        if rank == 0 or not replicate:
+            graph, oracle_build_s = load_graph_fixture(fixture, V)
+            tb = time.time()
+            index.import_graph(graph)
+            torch.cuda.synchronize()
+            log("imported the reference-order graph (%d nodes) in %.2f s" % (N, time.time() - tb))
     else:
         if rank == 0:
             tb = time.time()
@@ -303,15 +307,21 @@ def main():
             torch.cuda.synchronize()
             t_build = time.time() - tb
             log("built %d nodes in %.2f s (%s)" % (N, t_build, mode))
-            if world > 1 or not args.no_cpu_baseline:
+            if world == 1 and not args.no_cpu_baseline:
                 graph = index.export_graph(with_vectors=False)
-        if world > 1:
-            # one-time index distribution: rank 0's graph to every replica over RCCL
-            g = shard.broadcast_graph(dist, graph, N, src=0, device=coll_dev)
-            if rank != 0:
-                g["vectors"] = V
-                index.import_graph(g)
-            dist.barrier()
+    if replicate or (world > 1 and mode != "reference"):
+        # one-time index distribution: rank 0's tables straight out of its HBM into every replica's
+        # -- vectors included -- as device-pointer broadcasts over RCCL (host-staged when the ranks share one
+        # device in the gloo functional mode)
+        tb = time.time()
+        moved = shard.replicate_index(dist, index, src=0, device=torch.device("cuda", local_rank),
+                                      via="device" if backend == "nccl" else "host")
+        dist.barrier()
+        t_repl = time.time() - tb
+        log("replicated the index to %d ranks: %.2f GB per replica in %.2f s (%s)" % (
+            world, moved / 1e9, t_repl, "RCCL, HBM to HBM" if backend == "nccl" else "host-staged, gloo"))
+        replication = dict(bytes_per_replica=int(moved), seconds=round(t_repl, 3),
+                           transport="rccl broadcast of device pointers" if backend == "nccl" else "gloo, host-staged")
 
     # ---- device-resident inputs/outputs ---------------------------------------------
     dev = torch.device("cuda", local_rank)
@@ -385,6 +395,41 @@ def main():
         tt = torch.tensor([t_wall], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_wall = float(tt.item())
+    per_rank = None
+    gather_cmp = None
+    if world > 1:
+        # what every rank saw (the driver computes efficiency from `value`; these show the spread behind it)
+        objs = [None] * world
+        dist.all_gather_object(objs, dict(rank=rank, seconds=t_local, qps=B * args.steps / t_local))
+        per_rank = dict(qps=[round(o_["qps"], 1) for o_ in objs],
+                        ms_per_step_min=round(1e3 * min(o_["seconds"] for o_ in objs) / args.steps, 4),
+                        ms_per_step_max=round(1e3 * max(o_["seconds"] for o_ in objs) / args.steps, 4))
+        # the per-step exchange as an RCCL all-gather of the packed [2,B,k] block vs the alternative
+        # without a collective -- every rank copies its own block to pinned host memory (hipMemcpyAsync D2H)
+        reps_g = 50
+        hostbuf = torch.empty((2, B, k), dtype=torch.int32).pin_memory()
+        gsrc = bufs[0] if backend == "nccl" else bufs[0].cpu()
+        for _ in range(5):
+            shard.gather_packed(dist, gsrc, world, gouts[0])
+            hostbuf.copy_(bufs[0], non_blocking=True)
+        torch.cuda.synchronize()
+        dist.barrier()
+        tg = time.perf_counter()
+        for _ in range(reps_g):
+            shard.gather_packed(dist, gsrc, world, gouts[0])
+        torch.cuda.synchronize()
+        t_ag = (time.perf_counter() - tg) / reps_g
+        td = time.perf_counter()
+        for _ in range(reps_g):
+            hostbuf.copy_(bufs[0], non_blocking=True)
+        torch.cuda.synchronize()
+        t_d2h = (time.perf_counter() - td) / reps_g
+        tt2 = torch.tensor([t_ag, t_d2h], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
+        gather_cmp = dict(bytes_per_rank=int(2 * B * k * 4), allgather_us=round(1e6 * float(tt2[0]), 1),
+                          d2h_to_pinned_us=round(1e6 * float(tt2[1]), 1), transport=backend,
+                          note="back to back, nothing overlapped; in the timed loop the gather of step i runs on its own "
+                               "stream under the search of step i+1")
     # average duration of ONE k_search launch: launches on a stream run back to back, so the stream's
     # elapsed time / its launches (what rocprofv3 --kernel-trace reports as the kernel's average)
     kernel_ms = float(np.mean([ev0[s_].elapsed_time(ev1[s_]) / per_stream[s_] for s_ in range(S) if per_stream[s_]]))
@@ -772,6 +817,9 @@ def main():
                    "parallelism": "replica x%d, query batch sharded%s" % (
                        world, " (ranks share one device, gloo: functional check only)" if one_device and world > 1 else "")},
         "gather_verified": gather_ok,
+        "rccl_world": world if (world > 1 and backend == "nccl") else None,
+        "collective_backend": backend if world > 1 else None,
+        "per_rank": per_rank, "index_replication": replication, "topk_exchange": gather_cmp,
         "recall_at_%d" % k: None if recall is None else round(recall, 4),
         "build_seconds": None if t_build is None else round(t_build, 2),
         "host_buffers_qps": round(host_qps, 1), "host_buffers": host, "device_call": dev_calls,

@@ -23,9 +23,17 @@ def _run(extra):
 
 
 def test_bench_spawns_two_ranks_and_gather_matches_unsharded():
+    import torch
     out = _run(["--gpus", "2", "--verify-gather"])
     assert out["n_gpus"] == 2
     assert out["gather_verified"] is True
+    # two visible devices: one rank per GPU over RCCL; one device (this tier's box): the ranks share it over gloo --
+    # the line says which, and either way rank 1's index arrived through shard.replicate_index (engine per rank)
+    want = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    assert out["collective_backend"] == want and (out["rccl_world"] == 2) == (want == "nccl")
+    assert out["index_replication"]["bytes_per_replica"] > 20000 * 128 * 4
+    assert len(out["per_rank"]["qps"]) == 2 and out["per_rank"]["ms_per_step_max"] >= out["per_rank"]["ms_per_step_min"]
+    assert out["topk_exchange"]["allgather_us"] > 0 and out["topk_exchange"]["d2h_to_pinned_us"] > 0
     assert out["scaling"] == "weak" and out["value"] > 0
     assert out["roofline"]["bound"] == "hbm"
 

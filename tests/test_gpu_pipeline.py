@@ -249,3 +249,55 @@ def test_compress_bf16_is_refused_when_no_kernel_could_serve_it(eng, oracle_mod)
     again = c.search_batch(Q, 10)
     assert np.array_equal(ok[0], again[0]) and np.array_equal(_bits(ok[1]), _bits(again[1]))
     c.close()
+
+
+# ---- one-time index distribution through device pointers --------------------------------
+@pytest.mark.parametrize("with_deletes,bf16", [(False, False), (True, False), (False, True)])
+def test_replica_through_device_pointers_is_an_exact_copy(eng, oracle_mod, with_deletes, bf16):
+    """hnsw_replica_view -> hnsw_replica_prepare -> HBM-to-HBM copies -> hnsw_replica_commit (what
+    shard.replicate_index does with RCCL broadcasts): same rows in stored order, same answers, and the replica
+    continues like the oracle under exact inserts."""
+    import torch
+    from redis_hnsw_amd import _capi, shard
+    from tests.util import graphs_equal
+    n, dim, m, ef, k = 2500, 128, 16, 200, 10
+    V = make_data(n + 40, dim, seed=21)
+    o, lv = build_oracle(oracle_mod, V[:n], m, ef)
+    src = eng.Index("src", dim, m, ef)
+    src.add_batch(V[:n], levels=lv, mode="exact")
+    if with_deletes:
+        for i in (3, 77, src.enterpoint_id, 1200):
+            src.delete_node("node%d" % i)
+            o.delete(i)
+    if bf16:
+        src.set_tuning("compress_bf16", 1)
+    r = src.replica_view()
+    dst = eng.Index("dst", dim, m, ef)
+    rd = dst.replica_prepare({key: int(getattr(r, key)) for key in _capi.Replica.SCALARS})
+    dev = torch.device("cuda", 0)
+    for sp, dp, nbytes in ((r.vec, rd.vec, rd.vec_bytes), (r.adj0, rd.adj0, rd.adj0_bytes),
+                           (r.adj_upper, rd.adj_upper, rd.adj_upper_bytes), (r.upper_base, rd.upper_base, 4 * int(r.n)),
+                           (r.levels, rd.levels, 4 * int(r.n))):
+        if int(nbytes):
+            shard.device_bytes(dp, int(nbytes), dev).copy_(shard.device_bytes(sp, int(nbytes), dev))
+    torch.cuda.synchronize()
+    dst.replica_commit(rd, src.tombstones() if with_deletes else None, names=list(src._names))
+    assert dst.node_count == src.node_count and dst.enterpoint_id == src.enterpoint_id and dst.max_layer == src.max_layer
+    ok, why = graphs_equal(src.export_graph(), dst.export_graph())
+    assert ok, why
+    Q = make_data(200, dim, seed=22)
+    a, b = src.search_batch(Q, k), dst.search_batch(Q, k)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(_bits(a[1]), _bits(b[1])) and np.array_equal(a[2], b[2])
+    if not bf16:
+        want = o.search_batch(Q, k, threads=8)
+        assert np.array_equal(b[0], want[0]) and np.array_equal(_bits(b[1]), _bits(want[1]))
+        for i in range(n, n + 40):                                 # the replica is writable and continues exactly
+            lvl = int(oracle_mod.draw_levels(n + 40, m, 9)[i])
+            dst.add_node("late%d" % i, V[i], level=lvl)
+            o.add(V[i], lvl)
+        ok, why = graphs_equal(o.export(), dst.export_graph())
+        assert ok, why
+    # a second prepare on a non-empty index, and a commit of a foreign block, are refused
+    with pytest.raises(eng.HNSWError):
+        dst.replica_prepare({key: int(getattr(r, key)) for key in _capi.Replica.SCALARS})
+    src.close(); dst.close(); o.close()

@@ -40,11 +40,13 @@ def _worker(rank, world, port, tmpdir):
         o = oracle.OracleIndex(dim, m, ef)
         o.add_batch(V, oracle.draw_levels(n, m, 7))
         graph = o.export()
-    g = shard.broadcast_graph(dist, graph, n, src=0)
+    # vectors travel with the graph (rank 1 never sees V otherwise); arrays keep their native width
+    g = shard.broadcast_graph(dist, graph, n, src=0, vectors=V if rank == 0 else None)
     if rank == 0:
         ok, why = graphs_equal({k_: graph[k_] for k_ in ("levels", "enterpoint", "max_layer", "row_ptr", "col")}, g)
         assert ok, why
-    g["vectors"] = V
+    assert g["levels"].dtype == np.uint32 and g["row_ptr"][0].dtype == np.uint64 and g["col"][0].dtype == np.uint32
+    assert np.array_equal(g["vectors"].view(np.uint32), V.view(np.uint32))
     replica = oracle.OracleIndex.from_graph(dim, m, ef, g)
     lo, hi = shard.shard_bounds(B, world, rank)
     ids, sims, n_out, _ = replica.search_batch(Q[lo:hi], k)
