@@ -1,0 +1,270 @@
+//! GpuIndex -- the methods src/lib.rs calls on Index<f32,f32> (src/hnsw/core.rs:322-486), executed by the
+//! MI355X engine.  The struct keeps what the reference keeps in `Index.nodes` (core.rs:316): the node names;
+//! the engine speaks dense ids.  Error strings are the reference's (core.rs:390, 408, 421, 479), rendered by
+//! error_string() exactly as clients see them today (core.rs:42-46).
+use super::ffi;
+use std::collections::HashMap;
+use std::ffi::CStr;
+
+#[derive(Debug)]
+pub enum HNSWError {
+    Str(&'static str),
+    String(String),
+}
+impl HNSWError {
+    pub fn error_string(&self) -> String {
+        format!("{:?}", self) // core.rs:42-46
+    }
+}
+impl From<String> for HNSWError {
+    fn from(s: String) -> Self {
+        HNSWError::String(s)
+    }
+}
+
+pub struct SearchResult {
+    pub sim: f32,     // -(squared L2), metrics.rs:75
+    pub name: String, // last '.'-separated segment of the node key, core.rs:885-887
+    pub id: u32,
+}
+
+/// what the `update_fn` closure of add_node / delete_node receives instead of a Node<f32>:
+/// enough to rebuild the node's NodeRedis (src/types.rs:292-309) from the engine
+pub struct NodeView<'a> {
+    pub index: &'a GpuIndex,
+    pub id: u32,
+}
+impl<'a> NodeView<'a> {
+    pub fn data(&self) -> Vec<f32> {
+        let mut v = vec![0f32; self.index.data_dim];
+        unsafe { ffi::hnsw_get_vector(self.index.h, self.id, v.as_mut_ptr()) };
+        v
+    }
+    /// neighbour NAMES per layer, in stored order (what NodeRedis.neighbors holds)
+    pub fn neighbors(&self) -> Vec<Vec<String>> {
+        let mut info = ffi::hnsw_info::default();
+        unsafe { ffi::hnsw_get_info(self.index.h, &mut info) };
+        let cap = info.stride0.max(info.stride_upper) as usize;
+        let mut out = Vec::new();
+        let mut buf = vec![0u32; cap];
+        for layer in 0..=self.index.levels[self.id as usize] {
+            let mut n = 0u32;
+            unsafe { ffi::hnsw_get_neighbors(self.index.h, self.id, layer, buf.as_mut_ptr(), cap as u32, &mut n) };
+            out.push(buf[..n as usize].iter().map(|&j| self.index.names[j as usize].clone().unwrap()).collect());
+        }
+        out
+    }
+}
+
+pub struct GpuIndex {
+    pub name: String,
+    pub data_dim: usize,
+    pub m: usize,
+    pub m_max: usize,
+    pub m_max_0: usize,
+    pub ef_construction: usize,
+    pub level_mult: f64,
+    h: *mut ffi::hnsw_index,
+    names: Vec<Option<String>>, // id -> "hnsw.{idx}.{node}"; None = deleted (ids are never reused)
+    ids: HashMap<String, u32>,  // name -> id
+    levels: Vec<u32>,           // id -> top layer (the layer sets of IndexRedis.layers)
+}
+unsafe impl Send for GpuIndex {}
+unsafe impl Sync for GpuIndex {} // search_knn takes &self (core.rs:477); the module serialises writers with try_write
+
+impl GpuIndex {
+    fn last_error(&self) -> HNSWError {
+        let p = unsafe { ffi::hnsw_last_error(self.h) };
+        HNSWError::String(unsafe { CStr::from_ptr(p) }.to_string_lossy().into_owned())
+    }
+
+    /// Index::new(name, mfunc, data_dim, m, ef_construction)  core.rs:322-347 (the metric is Euclidean, :332)
+    pub fn new(name: &str, data_dim: usize, m: usize, ef_construction: usize) -> Result<Self, HNSWError> {
+        let mut h = std::ptr::null_mut();
+        let seed: u64 = rand::random(); // core.rs:344 seeds from entropy
+        let st = unsafe { ffi::hnsw_create(data_dim as u32, m as u32, ef_construction as u32, seed, 0, &mut h) };
+        let idx = GpuIndex {
+            name: name.to_owned(),
+            data_dim,
+            m,
+            m_max: m,
+            m_max_0: 2 * m,
+            ef_construction,
+            level_mult: 1.0 / (m as f64).ln(),
+            h,
+            names: Vec::new(),
+            ids: HashMap::new(),
+            levels: Vec::new(),
+        };
+        if st != ffi::HNSW_OK {
+            return Err(idx.last_error());
+        }
+        Ok(idx)
+    }
+
+    pub fn node_count(&self) -> usize {
+        self.ids.len()
+    }
+    pub fn node_names(&self) -> impl Iterator<Item = &String> {
+        self.ids.keys()
+    }
+    pub fn contains(&self, name: &str) -> bool {
+        self.ids.contains_key(name)
+    }
+    pub fn node(&self, name: &str) -> Option<NodeView> {
+        self.ids.get(name).map(|&id| NodeView { index: self, id })
+    }
+    pub fn info(&self) -> ffi::hnsw_info {
+        let mut info = ffi::hnsw_info::default();
+        unsafe { ffi::hnsw_get_info(self.h, &mut info) };
+        info
+    }
+    pub fn enterpoint(&self) -> Option<String> {
+        let e = self.info().enterpoint;
+        if e < 0 { None } else { self.names[e as usize].clone() }
+    }
+    /// IndexRedis.layers: the names of the nodes whose top layer is l  (src/types.rs:73-82)
+    pub fn layers(&self) -> Vec<Vec<String>> {
+        let top = self.info().max_layer as usize;
+        let mut out = vec![Vec::new(); if self.ids.is_empty() { 0 } else { top + 1 }];
+        for (id, name) in self.names.iter().enumerate() {
+            if let Some(n) = name {
+                let l = self.levels[id] as usize;
+                for layer in out.iter_mut().take(l + 1) {
+                    layer.push(n.clone());
+                }
+            }
+        }
+        out
+    }
+
+    /// add_node(&mut self, name, data, update_fn)  core.rs:383-412
+    pub fn add_node(&mut self, name: &str, data: &[f32], update_fn: impl Fn(String, NodeView)) -> Result<(), HNSWError> {
+        if data.len() != self.data_dim {
+            return Err(format!("data dimension: {} does not match Index", data.len()).into()); // core.rs:389-391
+        }
+        if !self.ids.is_empty() && self.ids.contains_key(name) {
+            return Err(format!("Node: {:?} already exists", name).into()); // core.rs:407-409 (after the first-node branch)
+        }
+        let (mut id, mut nt) = (0u32, 0u32);
+        let mut touched = vec![0u32; 8192];
+        let st = unsafe {
+            ffi::hnsw_add(self.h, data.as_ptr(), data.len() as u32, -1, &mut id, touched.as_mut_ptr(),
+                          touched.len() as u32, &mut nt)
+        };
+        if st != ffi::HNSW_OK {
+            return Err(self.last_error());
+        }
+        debug_assert_eq!(id as usize, self.names.len());
+        self.names.push(Some(name.to_owned()));
+        self.ids.insert(name.to_owned(), id);
+        let mut lv = vec![0u32; self.names.len()];
+        unsafe { ffi::hnsw_get_levels(self.h, lv.as_mut_ptr()) };
+        self.levels = lv;
+        for &t in &touched[..(nt as usize).min(touched.len())] {
+            // core.rs:580-584: every node whose links changed is written through (write_node, src/lib.rs:351-353)
+            update_fn(self.names[t as usize].clone().unwrap(), NodeView { index: self, id: t });
+        }
+        Ok(())
+    }
+
+    /// delete_node(&mut self, name, update_fn)  core.rs:414-475
+    pub fn delete_node(&mut self, name: &str, update_fn: impl Fn(String, NodeView)) -> Result<(), HNSWError> {
+        let id = match self.ids.get(name) {
+            Some(&id) => id,
+            None => return Err(format!("Node: {:?} does not exist", name).into()), // core.rs:419-422
+        };
+        let (mut nt, mut touched) = (0u32, vec![0u32; 8192]);
+        let st = unsafe { ffi::hnsw_delete(self.h, id, touched.as_mut_ptr(), touched.len() as u32, &mut nt) };
+        if st != ffi::HNSW_OK {
+            return Err(self.last_error());
+        }
+        self.ids.remove(name);
+        self.names[id as usize] = None;
+        for &t in &touched[..(nt as usize).min(touched.len())] {
+            if let Some(n) = self.names[t as usize].clone() {
+                update_fn(n, NodeView { index: self, id: t }); // core.rs:441-446
+            }
+        }
+        Ok(())
+    }
+
+    /// search_knn(&self, data, k)  core.rs:477-486 -> :865-892
+    pub fn search_knn(&self, data: &[f32], k: usize) -> Result<Vec<SearchResult>, HNSWError> {
+        if data.len() != self.data_dim {
+            return Err(format!("data dimension: {} does not match Index", data.len()).into()); // core.rs:478-480
+        }
+        if self.ids.is_empty() || k == 0 {
+            return Ok(Vec::new()); // core.rs:481-483
+        }
+        let (mut ids, mut sims, mut n) = (vec![0u32; k], vec![0f32; k], 0u32);
+        let st = unsafe {
+            ffi::hnsw_search(self.h, data.as_ptr(), data.len() as u32, k as u32, ids.as_mut_ptr(), sims.as_mut_ptr(), &mut n)
+        };
+        if st != ffi::HNSW_OK {
+            return Err(self.last_error());
+        }
+        Ok((0..n as usize)
+            .map(|i| SearchResult {
+                sim: sims[i],
+                name: self.names[ids[i] as usize].as_ref().unwrap().rsplit('.').next().unwrap().to_owned(),
+                id: ids[i],
+            })
+            .collect())
+    }
+
+    /// make_index (src/lib.rs:252-315): rebuild from the per-node keys with ONE upload.
+    /// nodes[i] = (key, data, neighbour keys per layer) in the order of IndexRedis.nodes; ids follow that order.
+    pub fn from_keys(name: &str, data_dim: usize, m: usize, ef_construction: usize,
+                     nodes: Vec<(String, Vec<f32>, Vec<Vec<String>>)>, enterpoint: Option<String>)
+                     -> Result<Self, HNSWError> {
+        let mut idx = GpuIndex::new(name, data_dim, m, ef_construction)?;
+        let n = nodes.len();
+        if n == 0 {
+            return Ok(idx);
+        }
+        for (i, (key, _, _)) in nodes.iter().enumerate() {
+            idx.ids.insert(key.clone(), i as u32);
+        }
+        let n_layers = nodes.iter().map(|x| x.2.len()).max().unwrap_or(1).max(1);
+        let mut vectors = Vec::with_capacity(n * data_dim);
+        let mut levels = vec![0u32; n];
+        let mut row_ptr = vec![vec![0u64; n + 1]; n_layers];
+        let mut col: Vec<Vec<u32>> = vec![Vec::new(); n_layers];
+        for (i, (_, data, nbrs)) in nodes.iter().enumerate() {
+            vectors.extend_from_slice(data);
+            levels[i] = nbrs.len().max(1) as u32 - 1;
+            for l in 0..n_layers {
+                if let Some(layer) = nbrs.get(l) {
+                    for nb in layer {
+                        // src/lib.rs:277-281: an unknown neighbour key is an error, not a skip
+                        let j = *idx.ids.get(nb).ok_or_else(|| format!("Node: {} does not exist", nb))?;
+                        col[l].push(j);
+                    }
+                }
+                row_ptr[l][i + 1] = col[l].len() as u64;
+            }
+        }
+        let ep = match &enterpoint {
+            Some(key) => *idx.ids.get(key).ok_or_else(|| format!("Node: {} does not exist", key))? as i64,
+            None => return Ok(idx),
+        };
+        let rp: Vec<*const u64> = row_ptr.iter().map(|r| r.as_ptr()).collect();
+        let cl: Vec<*const u32> = col.iter().map(|c| c.as_ptr()).collect();
+        let st = unsafe {
+            ffi::hnsw_import(idx.h, n as u32, vectors.as_ptr(), levels.as_ptr(), ep, n_layers as u32, rp.as_ptr(), cl.as_ptr())
+        };
+        if st != ffi::HNSW_OK {
+            return Err(idx.last_error());
+        }
+        idx.names = nodes.into_iter().map(|x| Some(x.0)).collect();
+        idx.levels = levels;
+        Ok(idx)
+    }
+}
+
+impl Drop for GpuIndex {
+    fn drop(&mut self) {
+        unsafe { ffi::hnsw_destroy(self.h) }
+    }
+}

@@ -8,7 +8,9 @@
  * HNSW.SEARCH exactly that way -- names and the key-value copies live here, the engine sees dense ids -- and
  * then checks the property the write-through exists for: the keyspace copy of every live node equals what
  * the engine holds (so make_index, src/lib.rs:252-315, would rebuild the same graph), and the graph rebuilt
- * from the keyspace through hnsw_import answers HNSW.SEARCH identically.
+ * from the keyspace through hnsw_import answers HNSW.SEARCH identically -- and, when the golden file is given
+ * (argv[1] = tests/golden/shim_sequence.txt, written by the CPU oracle playing the same commands), that every
+ * answer is the reference algorithm's: names in reply form (last '.' segment, core.rs:885-887) and similarity bits.
  * Exit code 0 = all assertions hold.                                                                    */
 #include <math.h>
 #include <stdio.h>
@@ -106,8 +108,11 @@ static int delete_node(const char *key)
 
 static float frand(unsigned *s) { *s = *s * 1664525u + 1013904223u; return (float)(*s >> 8) / 16777216.0f; }
 
-int main(void)
+int main(int argc, char **argv)
 {
+    FILE *golden = argc > 1 ? fopen(argv[1], "r") : NULL;
+    if (argc > 1 && !golden) { fprintf(stderr, "cannot open %s\n", argv[1]); return 1; }
+    unsigned n_golden = 0;
     OK(hnsw_create(DIM, M, EFC, 12345, 0, &H));                    /* HNSW.NEW, src/lib.rs:131-171 */
     unsigned seed = 7;
     static float V[MAXN][DIM];
@@ -189,6 +194,21 @@ int main(void)
             CHECK(memcmp(&a_sims[i], &b_sims[i], 4) == 0);
             CHECK(a_sims[i] <= 0.0f);                              /* sim = -(squared L2), metrics.rs:75 */
         }
+        if (golden) {                                              /* the oracle's answer to the same command */
+            unsigned gn = 0;
+            CHECK(fscanf(golden, "%u", &gn) == 1 && gn == na);
+            for (uint32_t i = 0; i < na; i++) {
+                char gname[48]; unsigned gbits = 0, bits;
+                CHECK(fscanf(golden, " %47[^:]:%x", gname, &gbits) == 2);
+                const char *dot = strrchr(names[a_ids[i]], '.');   /* reply name = last '.' segment */
+                memcpy(&bits, &a_sims[i], 4);
+                if (strcmp(dot ? dot + 1 : names[a_ids[i]], gname) != 0 || bits != gbits) {
+                    fprintf(stderr, "query %d rank %u: engine %s:%08x, oracle %s:%08x\n", q, i, dot ? dot + 1 : "?", bits, gname, gbits);
+                    return 1;
+                }
+            }
+            n_golden++;
+        }
     }
     /* dimension mismatch surfaces the reference's message (core.rs:478-480) */
     {
@@ -200,6 +220,7 @@ int main(void)
     }
     hnsw_destroy(H1);
     hnsw_destroy(H2);
-    printf("shim_sequence ok: %u adds, %u live, %lu node writes\n", n_names, live, n_writes);
+    if (golden) fclose(golden);
+    printf("shim_sequence ok: %u adds, %u live, %lu node writes, %u answers equal to the oracle's golden file\n", n_names, live, n_writes, n_golden);
     return 0;
 }

@@ -186,9 +186,12 @@ def test_rust_shim_call_sequence_in_c(eng):
     import subprocess
     from redis_hnsw_amd import build
     exe = build.build_shim_test()
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    import os
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "shim_sequence.txt")
+    r = subprocess.run([exe, golden], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "shim_sequence ok" in r.stdout
+    # every HNSW.SEARCH answer through the shim's sequence equals the CPU oracle's (names + similarity bits)
+    assert "shim_sequence ok" in r.stdout and "60 answers equal to the oracle's golden file" in r.stdout
 
 
 def test_reference_rdb_layout_round_trip_through_the_engine(eng, oracle_mod):

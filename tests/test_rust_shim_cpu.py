@@ -1,0 +1,114 @@
+"""The Rust shim is committed as files (integration/rust/) but cannot be compiled in this image (no cargo):
+what can be checked without a compiler is checked here -- every `extern "C"` declaration of ffi.rs against
+include/hnsw_mi355x.h (name, arity, argument and return types), the #[repr(C)] hnsw_info against the header's
+struct, the status constants, and that the lib.rs patch is well formed.  The shim's call sequence itself runs in C
+under -m gpu (tests/cpp/shim_sequence.c, against the oracle's golden answers)."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RUST = os.path.join(ROOT, "integration", "rust")
+
+C2RUST = {"uint32_t": "u32", "int32_t": "i32", "uint64_t": "u64", "int64_t": "i64", "int": "c_int", "float": "f32",
+          "uint8_t": "u8", "void": "c_void", "char": "c_char", "hnsw_status": "c_int"}
+
+
+def _strip_comments(text):
+    return re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+
+
+def _c_type_to_rust(ctype):
+    """'const uint64_t *const *' -> '*const *const u64'"""
+    t = ctype.strip()
+    stars = []
+    while t.endswith("*") or t.endswith("*const"):
+        if t.endswith("*const"):
+            t = t[: -len("*const")].strip()
+            stars.append("const_ptr_level")     # a const pointer: constness of what it points to is decided below
+        else:
+            t = t[:-1].strip()
+            stars.append("ptr")
+    const_base = t.startswith("const ")
+    base = t.replace("const ", "").strip()
+    rust = C2RUST.get(base, base)
+    # innermost pointer takes the base's constness; outer levels are '*const' iff that level was declared '*const'
+    out = rust
+    for i, lvl in enumerate(stars[::-1]):
+        if i == 0:
+            out = ("*const " if const_base else "*mut ") + out
+        else:
+            inner_is_const_ptr = stars[::-1][i - 1] == "const_ptr_level"
+            out = ("*const " if inner_is_const_ptr else "*mut ") + out
+    return out
+
+
+def _header_functions():
+    text = _strip_comments(open(os.path.join(ROOT, "include", "hnsw_mi355x.h")).read())
+    fns = {}
+    for m in re.finditer(r"\b(hnsw_status|void|const char \*)\s*(hnsw_[a-z_0-9]+)\s*\(([^)]*)\)\s*;", text):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        params = []
+        for a in [x.strip() for x in args.split(",") if x.strip()]:
+            mm = re.match(r"(.*?)([A-Za-z_][A-Za-z_0-9]*)$", a)          # type, then the parameter name
+            params.append(_c_type_to_rust(mm.group(1)))
+        fns[name] = (params, {"hnsw_status": "c_int", "void": None, "const char *": "*const c_char"}[ret])
+    return fns
+
+
+def _rust_functions():
+    text = re.sub(r"//.*", "", open(os.path.join(RUST, "src", "hnsw", "ffi.rs")).read())
+    fns = {}
+    for m in re.finditer(r"pub fn (hnsw_[a-z_0-9]+)\s*\(([^)]*)\)\s*(?:->\s*([^;]+))?;", text, flags=re.S):
+        params = [re.sub(r"\s+", " ", a.split(":", 1)[1].strip()) for a in m.group(2).split(",") if a.strip()]
+        fns[m.group(1)] = (params, m.group(3).strip() if m.group(3) else None)
+    return fns
+
+
+def test_every_rust_extern_matches_the_header():
+    c, r = _header_functions(), _rust_functions()
+    assert len(r) >= 15
+    for name, (rparams, rret) in r.items():
+        assert name in c, "ffi.rs declares %s, which include/hnsw_mi355x.h does not" % name
+        cparams, cret = c[name]
+        assert rparams == cparams, "%s: ffi.rs %r vs header %r" % (name, rparams, cparams)
+        assert rret == cret, "%s: return type %r vs %r" % (name, rret, cret)
+    # everything the module's call sites need is there
+    for need in ("hnsw_create", "hnsw_destroy", "hnsw_last_error", "hnsw_add", "hnsw_delete", "hnsw_search",
+                 "hnsw_search_batch", "hnsw_import", "hnsw_get_info", "hnsw_get_levels", "hnsw_get_vector", "hnsw_get_neighbors"):
+        assert need in r
+
+
+def test_repr_c_info_struct_and_status_codes_match_the_header():
+    htext = _strip_comments(open(os.path.join(ROOT, "include", "hnsw_mi355x.h")).read())
+    body = re.search(r"typedef struct \{([^}]*)\} hnsw_info;", htext, flags=re.S).group(1)
+    cfields = []
+    for decl in [d.strip() for d in body.split(";") if d.strip()]:
+        ctype, names = decl.split(None, 1)
+        cfields += [(n.strip(), C2RUST[ctype]) for n in names.split(",")]
+    rtext = open(os.path.join(RUST, "src", "hnsw", "ffi.rs")).read()
+    rbody = re.search(r"pub struct hnsw_info \{([^}]*)\}", rtext, flags=re.S).group(1)
+    rfields = [(m.group(1), m.group(2)) for m in re.finditer(r"pub ([a-z_0-9]+): ([a-z0-9]+),", rbody)]
+    assert rfields == cfields
+    enum = re.search(r"typedef enum \{([^}]*)\} hnsw_status;", htext, flags=re.S).group(1)
+    for m in re.finditer(r"(HNSW_[A-Z_]+)\s*=\s*(\d+)", enum):
+        assert re.search(r"pub const %s: c_int = %s;" % (m.group(1), m.group(2)), rtext), m.group(1)
+
+
+def test_the_shim_uses_only_declared_entry_points_and_the_patch_is_well_formed():
+    r = _rust_functions()
+    gpu = open(os.path.join(RUST, "src", "hnsw", "gpu_index.rs")).read()
+    used = set(re.findall(r"ffi::(hnsw_[a-z_0-9]+)\s*\(", gpu))
+    assert used and used <= set(r), used - set(r)
+    # the reference's three error strings, verbatim (core.rs:390, 408, 421, 479)
+    for msg in ('"data dimension: {} does not match Index"', '"Node: {:?} already exists"', '"Node: {:?} does not exist"'):
+        assert msg in gpu
+    diff = open(os.path.join(RUST, "lib_rs.diff")).read().split("\n")
+    assert diff[0] == "--- a/src/lib.rs" and diff[1] == "+++ b/src/lib.rs"
+    hunks = [l for l in diff if l.startswith("@@")]
+    assert len(hunks) >= 8
+    starts = [int(re.match(r"@@ -(\d+)", h).group(1)) for h in hunks]
+    assert starts == sorted(starts)                                   # applies top to bottom
+    for fn in ("GpuIndex::new(", "GpuIndex::from_keys(", "index_redis_of(", "node_redis_of("):
+        assert any(l.startswith("+") and fn in l for l in diff), fn
+    for f in ("build.rs", "Cargo.toml.diff", "README.md"):
+        assert os.path.exists(os.path.join(RUST, f))
