@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 using namespace hnsw;
@@ -1058,11 +1059,15 @@ hnsw_status hnsw_delete(hnsw_index *h, uint32_t id, uint32_t *touched, uint32_t 
     uint32_t nt = 0;
     hnsw_status s = delete_exact(h, id, &nt);
     if (s != HNSW_OK) return s;
-    if (touched && nt) {
+    if (touched && (nt || !h->purged_owners.empty())) {
         uint32_t have = std::min(nt, h->touched_cap);
         std::vector<uint32_t> tmp(have);
-        HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->d_touched, (size_t)have * 4, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (have) {
+            HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->d_touched, (size_t)have * 4, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+        }
+        for (uint32_t o : h->purged_owners)
+            if (o != id) tmp.push_back(o);                   // rows the inbound sweep edited (one-directional graphs)
         std::sort(tmp.begin(), tmp.end());
         tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
         nt = (uint32_t)tmp.size();

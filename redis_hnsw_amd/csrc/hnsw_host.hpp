@@ -37,6 +37,7 @@ struct hnsw_index {
     std::vector<uint32_t> h_levels, h_upper_base;
     std::vector<uint8_t> h_dead;   // tombstones (HNSW.NODE.DEL); ids are never reused
     uint32_t n_dead = 0;
+    std::vector<uint32_t> purged_owners;   // HNSW.NODE.DEL on a one-directional graph: owners of the rows the inbound sweep edited
     // search scratch
     // HBM spill tables of the visited sets: kSpillRegions regions, handed out round-robin so that
     // launches overlapping on different streams never share one (an event per region orders reuse)

@@ -189,7 +189,10 @@ __global__ void k_restride(const uint32_t *__restrict__ src, uint32_t sstride, u
 // node's own rows, which finds every neighbour only if links are symmetric (core.rs:770-772 keeps the
 // reference's so).  This pass removes what is left of `id` from every row of a table, keeping the stored
 // order.  One wave per row.
-__global__ void k_purge_inbound(uint32_t *adj, uint32_t stride, uint64_t rows, uint32_t id, uint32_t *n_removed)
+// The rows it edits are reported (row index | table flag) so that the host can hand their owners to the caller's
+// update_fn like every other touched node (the integration writes hnswnodet values through for touched ids only).
+__global__ void k_purge_inbound(uint32_t *adj, uint32_t stride, uint64_t rows, uint32_t id, uint32_t *n_removed,
+                                uint32_t *edited, uint32_t edited_cap, uint32_t flag)
 {
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
@@ -208,7 +211,12 @@ __global__ void k_purge_inbound(uint32_t *adj, uint32_t stride, uint64_t rows, u
         if (keep && removed) row[1 + kept + __popcll(kb & ((1ull << lane) - 1ull))] = x;
         kept += (uint32_t)__popcll(kb);
     }
-    if (removed && lane == 0) { row[0] = kept; atomicAdd(n_removed, removed); }
+    if (removed && lane == 0) {
+        row[0] = kept;
+        atomicAdd(n_removed, removed);
+        const uint32_t slot = atomicAdd(&edited[0], 1u);             // edited[0] = count, entries follow
+        if (slot < edited_cap) edited[1 + slot] = (uint32_t)wave | flag;
+    }
 }
 
 // number of links i -> j whose reverse j -> i is missing (0 for every graph the reference can produce)

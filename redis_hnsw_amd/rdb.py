@@ -9,9 +9,10 @@ hnsw_import call, so an existing dataset goes straight into HBM.
 Byte container.  Redis wraps every Save* call of a module value in an opcode (rdb.h, "module value
 format 2": RDB_MODULE_OPCODE_EOF=0, SINT=1, UINT=2, FLOAT=3, DOUBLE=4, STRING=5), integers and lengths in
 the RDB length encoding, floats/doubles as little-endian IEEE bytes, the value closed by an EOF opcode.
-ModuleIO below writes and reads that container (strings always as raw length + bytes: a reader accepts
-that form; redis-server may pick an integer or LZF encoding when it WRITES, which a full RDB parser would
-have to undo first).  redis-server and the redis-module crate are absent from this image, so the container
+ModuleIO below writes and reads that container.  It WRITES strings as raw length + bytes (always accepted);
+it READS the special encodings redis-server may choose when it writes a string -- 8/16/32-bit integers
+(0xC0..0xC2) and LZF-compressed bytes (0xC3) -- as well.  redis-server and the redis-module crate are absent
+from this image, so the container
 is restated from Redis's published format and is not byte-pinned against a real dump; what the parity
 tests pin is the FIELD ORDER and the graph semantics, which is all the engine depends on.
 """
@@ -38,6 +39,51 @@ def _len_encode(n):
     if n <= 0xFFFFFFFF:
         return b"\x80" + struct.pack(">I", n)
     return b"\x81" + struct.pack(">Q", n)
+
+
+def lzf_decompress(data, out_len):
+    """liblzf's format, as rdbLoadLzfStringObject feeds it: literal runs (ctrl < 32: ctrl + 1 bytes follow) and
+    back references (length ctrl >> 5, +next byte when 7, then +2; offset ((ctrl & 0x1f) << 8 | next) + 1)"""
+    out = bytearray()
+    i, n = 0, len(data)
+    while i < n:
+        ctrl = data[i]
+        i += 1
+        if ctrl < 32:
+            run = ctrl + 1
+            if i + run > n:
+                raise RdbFormatError("truncated LZF literal run")
+            out += data[i:i + run]
+            i += run
+        else:
+            length = ctrl >> 5
+            if length == 7:
+                if i >= n:
+                    raise RdbFormatError("truncated LZF back reference")
+                length += data[i]
+                i += 1
+            if i >= n:
+                raise RdbFormatError("truncated LZF back reference")
+            ref = len(out) - (((ctrl & 0x1F) << 8) | data[i]) - 1
+            i += 1
+            if ref < 0:
+                raise RdbFormatError("LZF back reference before the start of the output")
+            for _ in range(length + 2):
+                out.append(out[ref])
+                ref += 1
+    if len(out) != out_len:
+        raise RdbFormatError("LZF stream decodes to %d bytes, header says %d" % (len(out), out_len))
+    return bytes(out)
+
+
+def index_key(name):
+    """the Redis key of an index: 'hnsw.{idx}' (src/lib.rs:27, 137); full keys pass through"""
+    return name if name.startswith(PREFIX + ".") else "%s.%s" % (PREFIX, name)
+
+
+def node_key(index_name, node):
+    """the Redis key of a node: 'hnsw.{idx}.{node}' (src/lib.rs:342-343); full keys pass through"""
+    return node if node.startswith(PREFIX + ".") else "%s.%s" % (index_key(index_name), node)
 
 
 class ModuleIO:
@@ -98,7 +144,23 @@ class ModuleIO:
         return self._load_len()
 
     def load_string(self):
+        """rdbLoadStringObject: a raw length + bytes, or one of the special encodings (first byte 0b11xxxxxx)"""
         self._expect(OP_STRING)
+        b0 = self._in[self._pos] if self._pos < len(self._in) else None
+        if b0 is not None and (b0 >> 6) == 3:
+            self._pos += 1
+            enc = b0 & 0x3F
+            if enc == 0:                                         # RDB_ENC_INT8
+                return str(struct.unpack("<b", self._take(1))[0])
+            if enc == 1:                                         # RDB_ENC_INT16
+                return str(struct.unpack("<h", self._take(2))[0])
+            if enc == 2:                                         # RDB_ENC_INT32
+                return str(struct.unpack("<i", self._take(4))[0])
+            if enc == 3:                                         # RDB_ENC_LZF: compressed length, original length, bytes
+                clen = self._load_len()
+                ulen = self._load_len()
+                return lzf_decompress(bytes(self._take(clen)), ulen).decode("utf-8")
+            raise RdbFormatError("unknown string encoding 0x%02x" % b0)
         n = self._load_len()
         return bytes(self._take(n)).decode("utf-8")
 
@@ -299,13 +361,16 @@ def redis_to_graph(ir, get_node):
     return graph, names
 
 
-def dump_index(index):
+def dump_index(index, qualify=True):
     """An engine Index -> (hnswindex value bytes, {node key: hnswnodet value bytes}): what the module's
-    RDB save callbacks stream for this index and each of its nodes."""
+    RDB save callbacks stream for this index and each of its nodes.  The reference stores FULL keys -- the index
+    as 'hnsw.{idx}', nodes as 'hnsw.{idx}.{node}' -- and its make_index opens the stored names as keys
+    (src/lib.rs:256-258), so names that are not full keys yet are qualified (qualify=False keeps them verbatim)."""
     g = index.export_graph(with_vectors=True)
     dead = [nm is None for nm in index._names]
-    names = [nm if nm is not None else "" for nm in index._names]
-    ir, nodes = graph_to_redis(index.name, index.data_dim, index.m, index.ef_construction, g, names, dead)
+    iname = index_key(index.name) if qualify else index.name
+    names = [(node_key(index.name, nm) if qualify else nm) if nm is not None else "" for nm in index._names]
+    ir, nodes = graph_to_redis(iname, index.data_dim, index.m, index.ef_construction, g, names, dead)
     return save_index(ir), {k: save_node(v) for k, v in nodes.items()}
 
 

@@ -301,3 +301,33 @@ def test_replica_through_device_pointers_is_an_exact_copy(eng, oracle_mod, with_
     with pytest.raises(eng.HNSWError):
         dst.replica_prepare({key: int(getattr(r, key)) for key in _capi.Replica.SCALARS})
     src.close(); dst.close(); o.close()
+
+
+def test_delete_on_a_one_directional_graph_reports_every_row_it_edited(eng):
+    """fast-built graphs have links without a reverse: HNSW.NODE.DEL sweeps them away (k_purge_inbound), and the
+    owners of the swept rows are part of the touched set the caller writes through (the persisted hnswnodet
+    values would keep the deleted key otherwise)."""
+    n, dim, m, ef = 5000, 32, 8, 64
+    V = make_data(n, dim, seed=31)
+    gi = eng.Index("purge", dim, m, ef)
+    gi.set_tuning("fast_seed", 128)
+    gi.add_batch(V, mode="fast")
+    Q = make_data(100, dim, seed=2)
+    ids0, _, _ = gi.search_batch(Q, 10)
+    uniq, cnt = np.unique(ids0.ravel(), return_counts=True)
+    checked = 0
+    for victim in [int(x) for x in uniq[np.argsort(-cnt)][:12]]:
+        g = gi.export_graph()
+        inbound = set()
+        for rp, col in zip(g["row_ptr"], g["col"]):
+            rows = np.searchsorted(rp, np.nonzero(col == victim)[0], side="right") - 1
+            inbound |= set(int(r) for r in rows)
+        touched = set()
+        gi.delete_node("node%d" % victim, update_fn=lambda name, i: touched.add(int(i)))
+        assert inbound - {victim} <= touched, sorted(inbound - touched)[:5]
+        own = set(int(x) for l in range(len(g["col"])) for x in g["col"][l][int(g["row_ptr"][l][victim]):int(g["row_ptr"][l][victim + 1])])
+        checked += len(inbound - own - {victim})                       # rows only the sweep could have found
+        g2 = gi.export_graph()
+        assert not any((c == victim).any() for c in g2["col"])
+    assert checked > 0, "no one-directional inbound link was exercised"
+    gi.close()

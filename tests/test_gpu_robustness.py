@@ -239,6 +239,17 @@ def test_reference_rdb_layout_round_trip_through_the_engine(eng, oracle_mod):
     assert set(na) == set(nb)
     assert all(rdb.load_node(na[k]) == rdb.load_node(nb[k]) for k in na)
     a.close(); b.close()
+    # names that are not full keys are stored the way the reference stores them: hnsw.{idx} / hnsw.{idx}.{node}
+    # (src/lib.rs:137, 342-343); replies keep the last '.' segment (core.rs:885-887)
+    c = eng.Index("plain", dim, m, ef)
+    for i in range(60):
+        c.add_node("n%d" % i, V[i], level=int(lv[i]))
+    iv, nv = rdb.dump_index(c)
+    assert rdb.load_index(iv).name == "hnsw.plain" and set(nv) == {"hnsw.plain.n%d" % i for i in range(60)}
+    d = rdb.restore_index(iv, nv)
+    assert [r.name for r in d.search_knn(Q[0], 5)] == [r.name for r in c.search_knn(Q[0], 5)]
+    assert all(r.name.startswith("n") and "." not in r.name for r in d.search_knn(Q[0], 5))
+    c.close(); d.close()
 
 
 def _bf16_round(V):

@@ -91,3 +91,37 @@ def test_unknown_neighbour_is_the_references_error():
     del broken[victim]
     with pytest.raises(KeyError, match="does not exist"):                     # src/lib.rs:262
         rdb.redis_to_graph(ir, lambda nm: rdb.load_node(broken[nm]) if nm in broken else None)
+
+
+def test_reader_accepts_the_string_encodings_redis_may_write():
+    """redis-server integer-encodes short numeric strings (0xC0..0xC2) and LZF-compresses long repetitive ones
+    (0xC3) when it WRITES an RDB; load_string undoes both"""
+    import struct
+    from redis_hnsw_amd import rdb
+
+    def value(payload):
+        return bytes([rdb.OP_STRING]) + payload + bytes([rdb.OP_EOF])
+
+    for raw, want in ((b"\xc0" + struct.pack("<b", -7), "-7"), (b"\xc1" + struct.pack("<h", 12345), "12345"),
+                      (b"\xc2" + struct.pack("<i", -2000000000), "-2000000000")):
+        io = rdb.ModuleIO(value(raw))
+        assert io.load_string() == want
+        io.expect_eof()
+    # LZF: "hnsw.idx." + "ab" * 20: a literal run, then one back reference of 38 bytes at offset 2
+    text = b"hnsw.idx.ab" + b"ab" * 19
+    comp = bytes([10]) + b"hnsw.idx.ab" + bytes([(7 << 5) | 0, 38 - 2 - 7, 1])
+    assert rdb.lzf_decompress(comp, len(text)) == text
+    io = rdb.ModuleIO(value(b"\xc3" + bytes([len(comp)]) + bytes([len(text)]) + comp))
+    assert io.load_string() == text.decode()
+    io.expect_eof()
+    with pytest.raises(rdb.RdbFormatError):
+        rdb.lzf_decompress(bytes([(1 << 5) | 0, 5]), 3)             # reference before the start
+    with pytest.raises(rdb.RdbFormatError):
+        rdb.lzf_decompress(comp, len(text) + 1)                      # wrong declared length
+
+
+def test_keys_are_the_reference_s_full_keys():
+    from redis_hnsw_amd import rdb
+    assert rdb.index_key("foo") == "hnsw.foo" and rdb.index_key("hnsw.foo") == "hnsw.foo"          # src/lib.rs:137
+    assert rdb.node_key("foo", "n1") == "hnsw.foo.n1" and rdb.node_key("hnsw.foo", "n1") == "hnsw.foo.n1"
+    assert rdb.node_key("foo", "hnsw.foo.n1") == "hnsw.foo.n1"                                        # src/lib.rs:342-343
