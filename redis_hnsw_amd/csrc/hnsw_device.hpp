@@ -158,7 +158,7 @@ __device__ __forceinline__ float avx_reduce(float4 a)
 // per-wave LDS slices
 struct WaveMem {
     uint64_t *W;     // [R*64] sorted keys
-    uint64_t *S;     // [64]   select_neighbors result list (insert kernels)
+    uint64_t *S;     // [128]  select_neighbors result list (insert kernels): up to m_max0 = 2M ids, M <= 64
     uint32_t *fresh; // [64]
     float *dsc;      // [64]
     float *qlds;     // [dim]  query copy (generic / scalar modes; also float4 view)
@@ -582,13 +582,14 @@ __device__ __forceinline__ int find_unexpanded(const uint64_t *W, uint32_t nW, i
 }
 
 constexpr uint32_t kAuxWords = 512; // insert scratch: one adjacency row (degree <= 511)
+constexpr uint32_t kSelMax = 128;   // select_neighbors result: m_max0 = 2M ids at most (M <= 64)
 
 // LDS carve-up.  Search: [W: R*64*8][fresh: 64*4][dsc: 64*4][qlds (T==0)][hash: nb*32].
 // The insert kernels add [S: 64*8][aux: kAuxWords*4] after dsc.
 __host__ __device__ inline size_t lds_fixed_bytes(int R, int T, uint32_t dim, bool ins)
 {
     size_t b = (size_t)R * 64 * 8 + 64 * 4 + 64 * 4;
-    if (ins) b += 64 * 8 + kAuxWords * 4;
+    if (ins) b += kSelMax * 8 + kAuxWords * 4;
     if (T == 0) b += ((size_t)dim * 4 + 15) & ~(size_t)15;
     return b;
 }
@@ -608,7 +609,7 @@ __device__ __forceinline__ void carve(unsigned char *smem, uint32_t dim, uint32_
     m.S = nullptr;
     m.aux = nullptr;
     if (INS) {
-        m.S = reinterpret_cast<uint64_t *>(p); p += 64 * 8;
+        m.S = reinterpret_cast<uint64_t *>(p); p += kSelMax * 8;
         m.aux = reinterpret_cast<uint32_t *>(p); p += kAuxWords * 4;
     }
     m.qlds = reinterpret_cast<float *>(p);

@@ -565,13 +565,14 @@ hnsw_status ensure_pipe_stage(hnsw_index *h, uint32_t chunk, uint32_t k)
     }
     h->pipe_q_words = wq;
     h->pipe_r_words = wr;
-    // A stream's first copy in either direction sets up its copy path (measured: 5 ms per lane, in the middle
-    // of the first large batch otherwise): do one of each now.
+    // A stream's first LARGE copy sets up its copy path (measured: 5-6 ms per lane at the first 512 KB H2D copy, in
+    // the middle of the first large batch otherwise; a 256-byte copy does not trigger it): one full-size copy in
+    // each direction per lane now, once per handle.
     if (!h->pipe_copy_warm) {
         for (uint32_t l = 0; l < hnsw_index::kPipe; ++l) {
             hipStream_t st = l == 0 ? h->stream : h->pipe_st[l];
-            HIP_TRY(h, hipMemcpyAsync(h->pipe_dq[l], h->pipe_hq[l], 256, hipMemcpyHostToDevice, st));
-            HIP_TRY(h, hipMemcpyAsync(h->pipe_hres[l], h->pipe_dres[l], 256, hipMemcpyDeviceToHost, st));
+            HIP_TRY(h, hipMemcpyAsync(h->pipe_dq[l], h->pipe_hq[l], wq * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(h, hipMemcpyAsync(h->pipe_hres[l], h->pipe_dres[l], wr * 4, hipMemcpyDeviceToHost, st));
         }
         for (uint32_t l = 0; l < hnsw_index::kPipe; ++l) HIP_TRY(h, hipStreamSynchronize(l == 0 ? h->stream : h->pipe_st[l]));
         h->pipe_copy_warm = true;
@@ -787,8 +788,8 @@ hnsw_status hnsw_create(uint32_t dim, uint32_t m, uint32_t ef_construction, uint
     *out = nullptr;
     hnsw_index *h = new hnsw_index();
     *out = h; // returned even on failure so the caller can read hnsw_last_error()
-    if (dim == 0 || m < 2 || m > 32 || ef_construction == 0 || ef_construction > 1024)
-        return fail(h, HNSW_ERR_INVALID, "supported: dim >= 1, 2 <= M <= 32, 1 <= EFCON <= 1024");
+    if (dim == 0 || m < 2 || m > 64 || ef_construction == 0 || ef_construction > 1024)
+        return fail(h, HNSW_ERR_INVALID, "supported: dim >= 1, 2 <= M <= 64, 1 <= EFCON <= 1024");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(h, HNSW_ERR_DEVICE, "no HIP device: this engine has no CPU path");

@@ -29,6 +29,12 @@ constexpr uint32_t kPlanStride = 1 + 64;  // per (slot, layer): count + up to 64
 // candidate is merged in.  cand[0..ncand) is sorted nearest first and is left
 // untouched.  Result in m.S[0..n), sorted; returns n.
 // ---------------------------------------------------------------------------
+// S holds up to kSelMax = 128 keys (m_max0 = 2M, M <= 64): one register slice per 64
+__device__ __forceinline__ uint32_t merge_S(uint64_t *S, uint32_t nS, uint32_t mcap, uint64_t key, bool take, int lane)
+{
+    return mcap > 64 ? merge_sorted<2>(S, nS, mcap, key, take, lane) : merge_sorted<1>(S, nS, mcap, key, take, lane);
+}
+
 template <int MODE, int T>
 __device__ __forceinline__ uint32_t select_topm(const GraphView &g, const WaveMem &m, Visited &vis, const QReg<T> &qr,
                                 const uint64_t *cand, uint32_t ncand, uint32_t qid, uint32_t mcap,
@@ -92,7 +98,7 @@ __device__ __forceinline__ uint32_t select_topm(const GraphView &g, const WaveMe
                 for (int r = 0; r < 8; ++r)
                     if (sub == r && live[r]) { key = pack_key(dd[r], idr[r]); have = true; }
                 const uint64_t worst = nS == mcap ? m.S[mcap - 1] : ~0ull;
-                nS = merge_sorted<1>(m.S, nS, mcap, key, have && key < worst, lane);   // core.rs:717
+                nS = merge_S(m.S, nS, mcap, key, have && key < worst, lane);   // core.rs:717
                 return;
             }
             for (uint32_t pass = 0; pass * 32 < count; ++pass) {
@@ -116,7 +122,7 @@ __device__ __forceinline__ uint32_t select_topm(const GraphView &g, const WaveMe
                         if (sub == r0 + rr && live[rr]) { key = pack_key(dd[rr], idr[rr]); have = true; }
                 }
                 const uint64_t worst = nS == mcap ? m.S[mcap - 1] : ~0ull;
-                nS = merge_sorted<1>(m.S, nS, mcap, key, have && key < worst, lane);   // core.rs:717
+                nS = merge_S(m.S, nS, mcap, key, have && key < worst, lane);   // core.rs:717
             }
         };
         auto drain = [&](uint32_t keep_below) {             // evaluate blocks of 64 until fewer than keep_below wait
@@ -208,7 +214,7 @@ __device__ __forceinline__ uint32_t select_topm(const GraphView &g, const WaveMe
             const bool have = (uint32_t)lane < nf;
             const uint64_t key = have ? pack_key(m.dsc[lane], m.fresh[lane]) : ~0ull;
             const uint64_t worst = nS == mcap ? m.S[mcap - 1] : ~0ull;
-            nS = merge_sorted<1>(m.S, nS, mcap, key, have && key < worst, lane); // core.rs:717
+            nS = merge_S(m.S, nS, mcap, key, have && key < worst, lane); // core.rs:717
         }
     }
     __syncthreads();
@@ -234,7 +240,7 @@ __device__ __forceinline__ bool select_is_head_of_W(uint32_t ef, uint32_t mcap, 
 __device__ __forceinline__ uint32_t select_head_of_W(const WaveMem &m, uint32_t nW, uint32_t mcap, int lane)
 {
     const uint32_t nS = nW < mcap ? nW : mcap;
-    if ((uint32_t)lane < nS) m.S[lane] = m.W[lane] & ~1ull;
+    for (uint32_t i = lane; i < nS; i += 64) m.S[i] = m.W[i] & ~1ull;
     __syncthreads();
     return nS;
 }
@@ -405,10 +411,11 @@ __device__ __forceinline__ void update_connections(const GraphView &g, const Wav
         journal_push(jr, drop, e, lc, x, false, lane);
         journal_push(jr, drop, x, lc, e, false, lane);
     }
-    // new neighbours that were not adjacent before (:790-796)
-    {
-        const uint32_t x = (uint32_t)lane < nS ? key_id(m.S[lane]) : kEmpty;
-        bool isNew = (uint32_t)lane < nS;
+    // new neighbours that were not adjacent before (:790-796), nearest first (64 of S at a time: nS <= 2M <= 128)
+    for (uint32_t sb = 0; sb < nS; sb += 64) {
+        const bool inSel = sb + (uint32_t)lane < nS;
+        const uint32_t x = inSel ? key_id(m.S[sb + lane]) : kEmpty;
+        bool isNew = inSel;
         if (isNew)
             for (uint32_t i = 0; i < cnt; ++i) isNew &= m.aux[i] != x;
         const uint64_t nb = __ballot(isNew);
@@ -444,7 +451,7 @@ __device__ __forceinline__ void update_connections(const GraphView &g, const Wav
         kept += __popcll(nb);
         journal_push(jr, isNew, e, lc, x, true, lane);
         journal_push(jr, isNew, x, lc, e, true, lane);
-        touch_push(touched, touched_cap, nt, x, (uint32_t)lane < nS, lane); // :796
+        touch_push(touched, touched_cap, nt, x, inSel, lane); // :796
     }
     if (lane == 0) erow[0] = kept;
     touch_push(touched, touched_cap, nt, e, lane == 0, lane);               // :787

@@ -36,7 +36,7 @@ constexpr uint32_t kOccMaxHits = 1024;      // (reader, z) pairs whose distance 
 struct OccShr {
     uint32_t lc, e, nS, bound;              // bound = distance bits of the last selected; nS = 0: not computed yet
     uint32_t log0, cnt, pad0, pad1;         // its read-log range starts at log0: 1 + cnt + 1 entries (row e, its members, this node)
-    uint32_t S[64];                         // selected ids, nearest first
+    uint32_t S[kSelMax];                    // selected ids, nearest first (up to m_max0 = 2M)
 };
 struct OccSlot {
     uint32_t node, planned, snap, epoch;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_shrinks(GraphView g, OccBufs ob, 
     if (vis.glob_dirty) visited_clear(vis, lane);
     if (fail || nS == 0) { if (lane == 0) sl->fail = 1; return; }
     const uint32_t bound = (uint32_t)(m.S[nS - 1] >> 32);
-    if ((uint32_t)lane < nS) sp->S[lane] = key_id(m.S[lane]);
+    for (uint32_t i = lane; i < nS; i += 64) sp->S[i] = key_id(m.S[i]);
     // reads: row e itself, and the rows of econn's members
     if (lane == 0 && log0 < kOccMaxReads) reads[log0] = OccRead{e, occ_meta(lc, OCC_SHRINK_ROW, k, true), 0u};
     for (uint32_t i = lane; i < tot; i += 64)
@@ -568,9 +568,10 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
                 __syncthreads();
                 uint32_t nS;
                 if (k >= 0 && !sc.flags[2 + k]) {
-                    const uint32_t sv = shr[k].S[lane];          // S[64]: loaded alongside nS, not after it
+                    const uint32_t sv = shr[k].S[lane], sv2 = shr[k].S[64 + lane];   // loaded alongside nS, not after it
                     nS = shr[k].nS;
                     if ((uint32_t)lane < nS) m.S[lane] = (uint64_t)sv << 1;
+                    if (64u + (uint32_t)lane < nS) m.S[64 + lane] = (uint64_t)sv2 << 1;
                     __syncthreads();
                     n_spec += 1;
                 } else {

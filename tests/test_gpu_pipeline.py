@@ -331,3 +331,53 @@ def test_delete_on_a_one_directional_graph_reports_every_row_it_edited(eng):
         assert not any((c == victim).any() for c in g2["col"])
     assert checked > 0, "no one-directional inbound link was exercised"
     gi.close()
+
+
+# ---- the reference's parameter range: any M (core.rs:322-347); the engine serves M up to 64 --------------------
+@pytest.mark.parametrize("m,dim,ef,n", [(48, 32, 64, 1500), (64, 128, 100, 1200), (40, 4, 48, 900)])
+def test_large_m_builds_the_reference_graph(eng, oracle_mod, m, dim, ef, n):
+    """M > 32: the shrink's select_neighbors(m_max0 = 2M) selects up to 128 links (two register slices of S),
+    rows are up to 2M + slack ids wide.  Exact inserts (windowed and serial), deletes and searches equal the oracle's."""
+    from tests.util import graphs_equal
+    V = make_data(n + 30, dim, seed=41)
+    lv = oracle_mod.draw_levels(n + 30, m, 7)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch(V[:n], lv[:n])
+    gi = eng.Index("bigm", dim, m, ef)
+    gi.add_batch(V[:n], levels=lv[:n], mode="exact")                 # windowed exact build
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    assert gi.info().max_degree0 > 64                                  # rows really are wider than one wave load
+    for i in range(n, n + 30):                                         # serial exact inserts (hnsw_add)
+        gi.add_node("late%d" % i, V[i], level=int(lv[i]))
+        o.add(V[i], int(lv[i]))
+    for i in (7, 333, 800):
+        gi.delete_node("node%d" % i)
+        o.delete(i)
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    Q = make_data(100, dim, seed=42)
+    k = 10
+    gi.set_tuning("visited_bounded", 0)
+    gi.reset_counters()
+    ids, sims, n_out = gi.search_batch(Q, k)
+    oids, osims, on, oct = o.search_batch(Q, k, threads=8)
+    assert np.array_equal(n_out, on)
+    for q in range(len(Q)):
+        nv = int(on[q])
+        assert np.array_equal(ids[q, :nv], oids[q, :nv]) and np.array_equal(_bits(sims[q, :nv]), _bits(osims[q, :nv]))
+    sc, _ = gi.counters()
+    assert (sc.n_dist, sc.n_ids, sc.n_expand) == (oct.n_dist, oct.n_ids, oct.n_expand)
+    gi.close(); o.close()
+
+
+def test_m_above_64_is_refused_with_the_limit_in_the_message(eng):
+    with pytest.raises(eng.HNSWError) as e:
+        eng.Index("toobig", 16, 65, 100)
+    assert "M <= 64" in e.value.msg
+    gi = eng.Index("fast64", 64, 64, 128)                              # and the fast build works at the limit
+    V = make_data(3000, 64, seed=43)
+    gi.add_batch(V, mode="fast")
+    ids, _, n_out = gi.search_batch(V[:50], 5)
+    assert np.all(n_out == 5) and np.mean(ids[:, 0] == np.arange(50)) > 0.9
+    gi.close()
