@@ -172,7 +172,7 @@ typedef struct {
     uint32_t upper_used;       /* rows of adj_upper                                                            */
     uint32_t stride0, stride_upper;
     uint32_t max_layer, max_degree0, max_degree_upper;
-    uint32_t n_dead, asymmetric, bf16;
+    uint32_t n_dead, asymmetric, format;   /* format: 0 f32, 1 bf16, 2 fp8 (compressed serving copies)          */
     uint32_t reserved;
     int64_t enterpoint;
     uint64_t vec_bytes, adj0_bytes, adj_upper_bytes;
@@ -214,7 +214,8 @@ hnsw_status hnsw_deserialize(const void *buf, uint64_t bytes, uint64_t seed, int
  *   build     "occ_window" (slots of the exact parallel insert, 0 = serial), "occ_min_batch",
  *             "occ_ahead_x10", "select_shortcut" (1: select_neighbors after search_level is the head
  *             of W, see csrc/hnsw_insert.hpp), "fast_seed" / "fast_batch_max" / "fast_batch_div"
- *   storage   "compress_bf16" (one way: bf16 vector storage, the index becomes read-only; dim 128),
+ *   storage   "compress_bf16" / "compress_fp8" (one way: 2 / 1 bytes per component in the gather, the index becomes
+ *             read-only; results are the reference's on the stored, rounded values; any dim % 32 == 0),
  *             "force_restride" (tests)                                                              */
 hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value);
 

@@ -23,13 +23,13 @@ class Info(C.Structure):
 class Replica(C.Structure):
     _fields_ = [("n", C.c_uint32), ("dim", C.c_uint32), ("upper_used", C.c_uint32), ("stride0", C.c_uint32),
                 ("stride_upper", C.c_uint32), ("max_layer", C.c_uint32), ("max_degree0", C.c_uint32),
-                ("max_degree_upper", C.c_uint32), ("n_dead", C.c_uint32), ("asymmetric", C.c_uint32), ("bf16", C.c_uint32),
+                ("max_degree_upper", C.c_uint32), ("n_dead", C.c_uint32), ("asymmetric", C.c_uint32), ("format", C.c_uint32),
                 ("reserved", C.c_uint32), ("enterpoint", C.c_int64), ("vec_bytes", C.c_uint64), ("adj0_bytes", C.c_uint64),
                 ("adj_upper_bytes", C.c_uint64), ("vec", C.c_void_p), ("adj0", C.c_void_p), ("adj_upper", C.c_void_p),
                 ("upper_base", C.c_void_p), ("levels", C.c_void_p)]
 
     SCALARS = ("n", "dim", "upper_used", "stride0", "stride_upper", "max_layer", "max_degree0", "max_degree_upper", "n_dead",
-               "asymmetric", "bf16", "enterpoint")
+               "asymmetric", "format", "enterpoint")
 
 
 class Pipeline(C.Structure):

@@ -916,7 +916,30 @@ __device__ __forceinline__ bool first_unexpanded(const uint64_t (&w)[R], uint64_
 // T == 0 (any dim % 32 == 0): query pieces come from LDS and the row is walked 128 floats at a
 // time with the accumulators carried -- the per-lane FMA order in t is the same.  hook() runs once,
 // right after the first loads have been issued (work to overlap with their latency).
-template <int T, int NR, typename Hook>
+// Storage formats of the vector matrix.  FMT_F32 is the reference's data.  FMT_BF16 / FMT_FP8 are the compressed,
+// read-only serving copies (hnsw_set_tuning "compress_bf16" / "compress_fp8"): 2 / 1 bytes per component in the
+// gather, widened back to f32 in registers (exactly), after which the arithmetic is the reference's f32 kernel --
+// so results are bit-identical to the reference run on the stored (rounded) values.  A piece is the 4 components
+// one lane owns of every 32-component block: 16, 8 or 4 bytes.
+constexpr int FMT_F32 = 0, FMT_BF16 = 1, FMT_FP8 = 2;
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+template <int FMT>
+__device__ __forceinline__ float4 load_piece(const float4 *vec4, size_t piece)
+{
+    if constexpr (FMT == FMT_F32) {
+        return vec4[piece];
+    } else if constexpr (FMT == FMT_BF16) {
+        const uint2 u = reinterpret_cast<const uint2 *>(vec4)[piece];
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u),
+                           __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+    } else {
+        const uint32_t u = reinterpret_cast<const uint32_t *>(vec4)[piece];
+        const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)u, false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)u, true);
+        return make_float4(lo.x, lo.y, hi.x, hi.y);
+    }
+}
+
+template <int T, int NR, int FMT = FMT_F32, typename Hook>
 __device__ __forceinline__ void dist_rounds(const float4 *vec4, uint32_t row4, const uint32_t (&idr)[NR],
                                             const QReg<T> &qr, const float *qlds, int pp, float (&d)[NR],
                                             Hook &&hook)
@@ -925,9 +948,9 @@ __device__ __forceinline__ void dist_rounds(const float4 *vec4, uint32_t row4, c
         float4 v[NR][T];
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr) {
-            const float4 *p = vec4 + (size_t)idr[rr] * row4 + pp;
+            const size_t p = (size_t)idr[rr] * row4 + pp;
 #pragma unroll
-            for (int t = 0; t < T; ++t) v[rr][t] = p[t * 8];
+            for (int t = 0; t < T; ++t) v[rr][t] = load_piece<FMT>(vec4, p + t * 8);
         }
         hook();
 #pragma unroll
@@ -946,7 +969,7 @@ __device__ __forceinline__ void dist_rounds(const float4 *vec4, uint32_t row4, c
                 if (t0 + tb < Trt) {
                     q[tb] = q4[(t0 + tb) * 8];
 #pragma unroll
-                    for (int rr = 0; rr < NR; ++rr) v[rr][tb] = (vec4 + (size_t)idr[rr] * row4 + pp)[(t0 + tb) * 8];
+                    for (int rr = 0; rr < NR; ++rr) v[rr][tb] = load_piece<FMT>(vec4, (size_t)idr[rr] * row4 + pp + (t0 + tb) * 8);
                 }
             }
             if (first) { hook(); first = false; }
@@ -970,7 +993,7 @@ __device__ __forceinline__ void dist_rounds(const float4 *vec4, uint32_t row4, c
     }
 }
 
-template <int MODE, int T, int R>
+template <int MODE, int T, int R, int FMT = FMT_F32>
 __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const WaveMem &m, Visited &vis, const QReg<T> &qr,
                                     uint32_t ep, uint32_t ef, uint32_t lc, WorkCtr &ctr, int lane, bool &fail)
 {
@@ -991,7 +1014,7 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
     {
         const uint32_t id1[1] = {ep};
         float d1[1];
-        dist_rounds<T, 1>(vec4, row4, id1, qr, m.qlds, pp, d1, [] {});   // core.rs:621
+        dist_rounds<T, 1, FMT>(vec4, row4, id1, qr, m.qlds, pp, d1, [] {});   // core.rs:621
         const float d = d1[0];
         ctr.n_dist += 1;
 #pragma unroll
@@ -1088,7 +1111,7 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
                     idr[rr] = ((pm >> (r * 8 + grp)) & 1u) ? got : safe_id;
                 }
                 float dd[RB];
-                dist_rounds<T, RB>(vec4, row4, idr, qr, m.qlds, pp, dd, [&] {
+                dist_rounds<T, RB, FMT>(vec4, row4, idr, qr, m.qlds, pp, dd, [&] {
                     if (r0 == 0 && __ballot(ptake)) {      // deferred scatter, under the loads just issued
                         nW = merge_apply<R>(w, m.W, nW, ef, pkey, ptake, pup, ppos, lane, &worst);
                         ptake = false;
@@ -1137,7 +1160,7 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
                         idr[rr] = ((pm >> s) & 1u) ? got : safe_id;
                     }
                     float dd[RB];
-                    dist_rounds<T, RB>(vec4, row4, idr, qr, m.qlds, pp, dd, [&] {
+                    dist_rounds<T, RB, FMT>(vec4, row4, idr, qr, m.qlds, pp, dd, [&] {
                         if (r0 == 0) {
                             const uint64_t fm = __ballot(visited_insert_wave(vis, valid, word, lane, &g.hdr->ctr_search[3]));
                             const uint32_t nf = __popcll(fm);
@@ -1227,12 +1250,13 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
     return nW;
 }
 
-template <int MODE, int T, int R>
+template <int MODE, int T, int R, int FMT = FMT_F32>
 __device__ __forceinline__ uint32_t search_level(const GraphView &g, const WaveMem &m, Visited &vis,
                                                  const QReg<T> &qr, uint32_t ep, uint32_t ef, uint32_t lc,
                                                  WorkCtr &ctr, int lane, bool &fail)
 {
-    if constexpr (MODE == MODE_AVX) return search_level_v2<MODE, T, R>(g, m, vis, qr, ep, ef, lc, ctr, lane, fail);
+    static_assert(FMT == FMT_F32 || MODE == MODE_AVX, "compressed storage: AVX2 summation order only (dim % 32 == 0)");
+    if constexpr (MODE == MODE_AVX) return search_level_v2<MODE, T, R, FMT>(g, m, vis, qr, ep, ef, lc, ctr, lane, fail);
     else return search_level_v1<MODE, T, R>(g, m, vis, qr, ep, ef, lc, ctr, lane, fail);
 }
 

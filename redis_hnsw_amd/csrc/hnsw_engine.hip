@@ -378,9 +378,8 @@ hnsw_status ensure_spill_one(hnsw_index *h)
     return HNSW_OK;
 }
 
-// The specialised kernel's preconditions that do not depend on the launch (nullptr = all hold).  The bf16 serving
-// copy has no other kernel, so "compress_bf16" checks them before converting and the knobs below are refused
-// afterwards.
+// The specialised kernel's preconditions that do not depend on the launch (nullptr = all hold).  Indexes it cannot
+// serve (other dims, ef > 256, rows wider than 127 ids, test overrides, fp8 storage) use the general kernel.
 const char *lean_blocker(const hnsw_index *h)
 {
     const int R = pick_R(h->efc);
@@ -403,7 +402,7 @@ hnsw_status try_launch_lean(hnsw_index *h, const float *dQ, uint32_t B, uint32_t
 {
     *done = false;
     const int R = pick_R(h->efc);
-    if (lean_blocker(h)) return HNSW_OK;
+    if (lean_blocker(h) || h->fmt == FMT_FP8) return HNSW_OK;
     uint32_t per_cu = ((uint64_t)B * std::max(h->cur_conc, 1u) + 255) / 256;
     per_cu = std::min(std::max(per_cu, 1u), h->max_waves_per_cu);
     // 32 KB table at <= 4 waves per CU, 16 KB at <= 8, 8 KB beyond (tuning waves_per_cu > 8)
@@ -451,9 +450,10 @@ hnsw_status launch_search(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k
     h->last_search_lean = false;
     if ((s = try_launch_lean(h, dQ, B, k, d_ids, d_sims, d_nout, st, &done)) != HNSW_OK) return s;
     if (done) { h->last_search_lean = true; return HNSW_OK; }
-    if (h->bf16) return fail(h, HNSW_ERR_INVALID, std::string("bf16 storage is served by the specialised kernel only: ") + (lean_blocker(h) ? lean_blocker(h) : "launch shape"));
     const int R = pick_R(h->efc);
-    if (h->mode == MODE_SCALAR) s = launch_search_r<MODE_SCALAR, 0>(h, R, dQ, B, k, d_ids, d_sims, d_nout, st);
+    if (h->fmt == FMT_BF16) s = launch_search_fmt<FMT_BF16>(h, R, dQ, B, k, d_ids, d_sims, d_nout, st);   // any dim % 32 == 0, any M / ef
+    else if (h->fmt == FMT_FP8) s = launch_search_fmt<FMT_FP8>(h, R, dQ, B, k, d_ids, d_sims, d_nout, st);
+    else if (h->mode == MODE_SCALAR) s = launch_search_r<MODE_SCALAR, 0>(h, R, dQ, B, k, d_ids, d_sims, d_nout, st);
     else if (h->T == 4) s = launch_search_r<MODE_AVX, 4>(h, R, dQ, B, k, d_ids, d_sims, d_nout, st);
     else if (h->T == 24) s = launch_search_r<MODE_AVX, 24>(h, R, dQ, B, k, d_ids, d_sims, d_nout, st);
     else s = launch_search_r<MODE_AVX, 0>(h, R, dQ, B, k, d_ids, d_sims, d_nout, st);
@@ -861,15 +861,6 @@ const char *hnsw_last_error(const hnsw_index *h) { return h ? h->err.c_str() : "
 hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
 {
     if (!h || !key) return HNSW_ERR_INVALID;
-    if (h->bf16) {
-        // a bf16 index is served by the specialised kernel only: knobs that would take it away are refused
-        const bool off = (!std::strcmp(key, "lean") && !value) || (!std::strcmp(key, "visited_bounded") && !value) ||
-                         (!std::strcmp(key, "tag_table") && !value) || (!std::strcmp(key, "tag_bb") && value >= 0) ||
-                         (!std::strcmp(key, "lds_buckets") && value >= 0) || !std::strcmp(key, "lds_hash_bits") ||
-                         (!std::strcmp(key, "idbits") && value > 24) || (!std::strcmp(key, "waves_per_cu") && value > 8) ||
-                         !std::strcmp(key, "force_restride") || !std::strcmp(key, "query_in_lds");
-        if (off) return fail(h, HNSW_ERR_INVALID, std::string("tuning ") + key + " is refused on a bf16 index (it would leave it without a search kernel)");
-    }
     if (!std::strcmp(key, "force_restride")) {   // tests: widen both adjacency tables by `value` words now
         HIP_TRY(h, hipSetDevice(h->device));
         return restride(h, h->stride0 + (uint32_t)value, h->strideU + (uint32_t)value);
@@ -886,27 +877,35 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
     if (!std::strcmp(key, "pipe_chunk")) { h->pipe_chunk = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 64), 1 << 20); return HNSW_OK; }
     if (!std::strcmp(key, "pipe_min_batch")) { h->pipe_min_batch = (uint32_t)std::max<int64_t>(value, 2); return HNSW_OK; }
     if (!std::strcmp(key, "pipe_device")) { h->pipe_device = value != 0; return HNSW_OK; }
-    if (!std::strcmp(key, "compress_bf16")) {
-        // One way: the f32 vector matrix becomes a bf16 one (round to nearest even) and the index read-only.
-        // A separate, clearly-labelled serving mode: half the bytes of the gather; the
-        // arithmetic stays the reference's f32 kernel on the stored values, so results are those of the
-        // reference run on the bf16-rounded vectors (not on the original f32 ones).
-        if (!value || h->bf16) return HNSW_OK;
-        // only the specialised kernel reads bf16 rows: refuse, with the index untouched, unless it can serve this index
-        if (const char *why = lean_blocker(h))
-            return fail(h, HNSW_ERR_INVALID, std::string("compress_bf16 needs the specialised dim-128 search kernel, which this index cannot use: ") + why);
+    if (!std::strcmp(key, "compress_bf16") || !std::strcmp(key, "compress_fp8")) {
+        // One way: the f32 vector matrix becomes a bf16 (2 bytes per component, round to nearest even) or fp8 (1 byte,
+        // e4m3) one and the index read-only.  Separate, clearly-labelled serving modes: a half / a
+        // quarter of the bytes of the gather; the arithmetic stays the reference's f32 kernel on the stored values
+        // widened back (exactly), so results are those of the reference run on the ROUNDED vectors, not on the
+        // original ones (hnsw_get_vector reports the stored values).  Any dim % 32 == 0 (the AVX2 summation order),
+        // any M / ef_construction: dim-128 indexes the specialised kernel can serve use its bf16 form, everything
+        // else the general kernel's.
+        const int want = !std::strcmp(key, "compress_bf16") ? FMT_BF16 : FMT_FP8;
+        if (!value || h->fmt == want) return HNSW_OK;
+        if (h->fmt) return fail(h, HNSW_ERR_INVALID, "the index is already compressed (the original vectors are gone)");
+        if (h->mode != MODE_AVX) return fail(h, HNSW_ERR_INVALID, std::string(key) + " needs dim % 32 == 0 (the AVX2 summation order, metrics.rs:18)");
         HIP_TRY(h, hipSetDevice(h->device));
         HIP_TRY(h, hipDeviceSynchronize());
-        unsigned short *d16 = nullptr;
-        const size_t nel = (size_t)h->cap * h->dim;
-        HIP_TRY(h, hipMalloc((void **)&d16, std::max<size_t>(nel, 1) * 2));
-        hipLaunchKernelGGL(k_f32_to_bf16, dim3(4096), dim3(256), 0, h->stream, h->d_vec, d16, (size_t)h->n * h->dim);
+        const size_t nel = (size_t)h->cap * h->dim, esz = want == FMT_BF16 ? 2 : 1;
+        void *dnew = nullptr;
+        HIP_TRY(h, hipMalloc(&dnew, std::max<size_t>(nel, 1) * esz));
+        if (want == FMT_BF16)
+            hipLaunchKernelGGL(k_f32_to_bf16, dim3(4096), dim3(256), 0, h->stream, h->d_vec, (unsigned short *)dnew, (size_t)h->n * h->dim);
+        else
+            hipLaunchKernelGGL(k_f32_to_fp8, dim3(4096), dim3(256), 0, h->stream, h->d_vec, (unsigned char *)dnew, (size_t)h->n * h->dim);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         (void)hipFree(h->d_vec);
-        h->hbm_bytes -= std::min<uint64_t>(h->hbm_bytes, nel * 2);
-        h->d_vec = reinterpret_cast<float *>(d16);
-        h->bf16 = true;
+        h->hbm_bytes -= std::min<uint64_t>(h->hbm_bytes, nel * (4 - esz));
+        h->d_vec = reinterpret_cast<float *>(dnew);
+        h->fmt = want;
+        h->bf16 = want == FMT_BF16;
+        h->T = 0;                                    // the compressed kernels take the query from LDS
         return HNSW_OK;
     }
     if (!std::strcmp(key, "select_shortcut")) { h->select_shortcut = value != 0; return HNSW_OK; }
@@ -918,7 +917,7 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
     if (!std::strcmp(key, "lean")) { h->lean = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "grid_stride")) { h->grid_stride = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "query_in_lds")) {     // dims 128 / 768 normally keep the query in registers (T = dim/32)
-        if (h->mode == MODE_AVX) h->T = value ? 0 : ((h->dim == 128 || h->dim == 768) ? (int)(h->dim / 32) : 0);
+        if (h->mode == MODE_AVX && !h->fmt) h->T = value ? 0 : ((h->dim == 128 || h->dim == 768) ? (int)(h->dim / 32) : 0);
         return HNSW_OK;
     }
     if (!std::strcmp(key, "visited_bounded")) { h->visited_bounded = value != 0; return HNSW_OK; }
@@ -933,7 +932,7 @@ hnsw_status hnsw_add(hnsw_index *h, const float *v, uint32_t dim, int32_t level,
                      uint32_t *touched, uint32_t touched_cap, uint32_t *n_touched)
 {
     if (!h || !v) return HNSW_ERR_INVALID;
-    if (h->bf16) return fail(h, HNSW_ERR_INVALID, "the index is read-only in bf16 storage mode");
+    if (h->fmt) return fail(h, HNSW_ERR_INVALID, "the index is read-only in compressed (bf16 / fp8) storage mode");
     if (dim != h->dim) {                         // core.rs:389-391
         char buf[96];
         snprintf(buf, sizeof buf, "data dimension: %u does not match Index", dim);
@@ -963,7 +962,7 @@ hnsw_status hnsw_add_batch(hnsw_index *h, const float *V, uint32_t n, uint32_t d
                            uint32_t mode)
 {
     if (!h || (!V && n)) return HNSW_ERR_INVALID;
-    if (h->bf16) return fail(h, HNSW_ERR_INVALID, "the index is read-only in bf16 storage mode");
+    if (h->fmt) return fail(h, HNSW_ERR_INVALID, "the index is read-only in compressed (bf16 / fp8) storage mode");
     if (dim != h->dim) {
         char buf[96];
         snprintf(buf, sizeof buf, "data dimension: %u does not match Index", dim);
@@ -1050,7 +1049,7 @@ hnsw_status hnsw_delete(hnsw_index *h, uint32_t id, uint32_t *touched, uint32_t 
 {
     if (!h) return HNSW_ERR_INVALID;
     if (n_touched) *n_touched = 0;
-    if (h->bf16) return fail(h, HNSW_ERR_INVALID, "the index is read-only in bf16 storage mode");
+    if (h->fmt) return fail(h, HNSW_ERR_INVALID, "the index is read-only in compressed (bf16 / fp8) storage mode");
     if (id >= h->n || h->h_dead[id]) {                          // core.rs:419-422
         char buf[64];
         snprintf(buf, sizeof buf, "Node: %u does not exist", id);
@@ -1164,7 +1163,7 @@ hnsw_status hnsw_import(hnsw_index *h, uint32_t n, const float *vectors, const u
                         const uint32_t *const *col)
 {
     if (!h) return HNSW_ERR_INVALID;
-    if (h->bf16) return fail(h, HNSW_ERR_INVALID, "the index is read-only in bf16 storage mode");
+    if (h->fmt) return fail(h, HNSW_ERR_INVALID, "the index is read-only in compressed (bf16 / fp8) storage mode");
     if (h->n != 0) return fail(h, HNSW_ERR_INVALID, "hnsw_import needs an empty index");
     if (n == 0) return HNSW_OK;
     if (enterpoint < 0 || enterpoint >= (int64_t)n || n_layers == 0 || n_layers > kMaxLayers)
@@ -1273,9 +1272,9 @@ hnsw_status hnsw_replica_view(hnsw_index *h, hnsw_replica *out)
     out->n = h->n; out->dim = h->dim; out->upper_used = h->upper_used;
     out->stride0 = h->stride0; out->stride_upper = h->strideU;
     out->max_layer = h->max_layer; out->max_degree0 = h->max_deg0; out->max_degree_upper = h->max_degU;
-    out->n_dead = h->n_dead; out->asymmetric = h->asymmetric ? 1u : 0u; out->bf16 = h->bf16 ? 1u : 0u;
+    out->n_dead = h->n_dead; out->asymmetric = h->asymmetric ? 1u : 0u; out->format = (uint32_t)h->fmt;
     out->enterpoint = h->enterpoint;
-    out->vec_bytes = (uint64_t)h->n * h->dim * (h->bf16 ? 2 : 4);
+    out->vec_bytes = (uint64_t)h->n * h->dim * (h->fmt == FMT_F32 ? 4 : (h->fmt == FMT_BF16 ? 2 : 1));
     out->adj0_bytes = (uint64_t)h->n * h->stride0 * 4;
     out->adj_upper_bytes = (uint64_t)h->upper_used * h->strideU * 4;
     out->vec = h->d_vec; out->adj0 = h->d_adj0; out->adj_upper = h->d_adjU;
@@ -1286,7 +1285,7 @@ hnsw_status hnsw_replica_view(hnsw_index *h, hnsw_replica *out)
 hnsw_status hnsw_replica_prepare(hnsw_index *h, hnsw_replica *r)
 {
     if (!h || !r) return HNSW_ERR_INVALID;
-    if (h->n != 0 || h->bf16) return fail(h, HNSW_ERR_INVALID, "hnsw_replica_prepare needs an empty index");
+    if (h->n != 0 || h->fmt) return fail(h, HNSW_ERR_INVALID, "hnsw_replica_prepare needs an empty index");
     if (r->dim != h->dim) return fail(h, HNSW_ERR_DIM_MISMATCH, "replica: data dimension does not match Index");
     if (r->n == 0 || r->enterpoint >= (int64_t)r->n || r->max_layer >= kMaxLayers || r->n_dead > r->n ||
         r->stride0 < h->stride0 || r->stride_upper < h->strideU || r->stride0 > kAuxWords || r->stride_upper > kAuxWords ||
@@ -1297,24 +1296,28 @@ hnsw_status hnsw_replica_prepare(hnsw_index *h, hnsw_replica *r)
     if ((s = restride(h, r->stride0, r->stride_upper)) != HNSW_OK) return s;      // the source's row layout
     if ((s = ensure_node_cap(h, r->n)) != HNSW_OK) return s;
     if ((s = ensure_upper_cap(h, std::max(r->upper_used, 1u))) != HNSW_OK) return s;
-    if (r->bf16 && lean_blocker(h)) return fail(h, HNSW_ERR_INVALID, "replica: a bf16 source needs an index the specialised kernel can serve");
-    if (r->bf16) {
-        // the vector matrix of a bf16 replica is half the size: swap the f32 allocation for a bf16 one now
-        unsigned short *d16 = nullptr;
+    if (r->format > (uint32_t)FMT_FP8 || (r->format && h->mode != MODE_AVX))
+        return fail(h, HNSW_ERR_INVALID, "replica: unknown storage format (or a compressed source with dim % 32 != 0)");
+    const uint32_t esz = r->format == FMT_F32 ? 4 : (r->format == FMT_BF16 ? 2 : 1);
+    if (r->format) {
+        // the vector matrix of a compressed replica is smaller: swap the f32 allocation for one of the right size
+        void *dnew = nullptr;
         const size_t nel = (size_t)h->cap * h->dim;
-        HIP_TRY(h, hipMalloc((void **)&d16, std::max<size_t>(nel, 1) * 2));
+        HIP_TRY(h, hipMalloc(&dnew, std::max<size_t>(nel, 1) * esz));
         HIP_TRY(h, hipDeviceSynchronize());
         (void)hipFree(h->d_vec);
-        h->hbm_bytes -= std::min<uint64_t>(h->hbm_bytes, nel * 2);
-        h->d_vec = reinterpret_cast<float *>(d16);
+        h->hbm_bytes -= std::min<uint64_t>(h->hbm_bytes, nel * (4 - esz));
+        h->d_vec = reinterpret_cast<float *>(dnew);
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));          // the allocations' fills are done before anyone writes
-    r->vec_bytes = (uint64_t)r->n * h->dim * (r->bf16 ? 2 : 4);
+    r->vec_bytes = (uint64_t)r->n * h->dim * esz;
     r->adj0_bytes = (uint64_t)r->n * h->stride0 * 4;
     r->adj_upper_bytes = (uint64_t)r->upper_used * h->strideU * 4;
     r->vec = h->d_vec; r->adj0 = h->d_adj0; r->adj_upper = h->d_adjU;
     r->upper_base = h->d_upper_base; r->levels = h->d_levels;
-    h->bf16 = r->bf16 != 0;                               // the tables are being filled: not searchable until commit (n == 0)
+    h->fmt = (int)r->format;                              // the tables are being filled: not searchable until commit (n == 0)
+    h->bf16 = h->fmt == FMT_BF16;
+    if (h->fmt) h->T = 0;
     return HNSW_OK;
 }
 
@@ -1386,15 +1389,17 @@ hnsw_status hnsw_get_vector(hnsw_index *h, uint32_t id, float *out)
     if (!h || !out) return HNSW_ERR_INVALID;
     if (id >= h->n) return fail(h, HNSW_ERR_NOT_FOUND, "node id out of range");
     HIP_TRY(h, hipSetDevice(h->device));
-    if (h->bf16) {                                   // the stored (rounded) value, widened
-        std::vector<uint16_t> tmp(h->dim);
-        const uint16_t *src = reinterpret_cast<const uint16_t *>(h->d_vec) + (size_t)id * h->dim;
-        HIP_TRY(h, hipMemcpyAsync(tmp.data(), src, (size_t)h->dim * 2, hipMemcpyDeviceToHost, h->stream));
+    if (h->fmt) {                                    // the stored (rounded) values, widened by the search kernels' own code
+        DevScratch<float> row;
+        HIP_TRY(h, row.alloc(h->dim));
+        const uint32_t blocks = (h->dim / 4 + 63) / 64;
+        if (h->fmt == FMT_BF16)
+            hipLaunchKernelGGL(k_decode_row<FMT_BF16>, dim3(blocks), dim3(64), 0, h->stream, reinterpret_cast<const float4 *>(h->d_vec), (size_t)id, h->dim, row.p);
+        else
+            hipLaunchKernelGGL(k_decode_row<FMT_FP8>, dim3(blocks), dim3(64), 0, h->stream, reinterpret_cast<const float4 *>(h->d_vec), (size_t)id, h->dim, row.p);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipMemcpyAsync(out, row.p, (size_t)h->dim * 4, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
-        for (uint32_t i = 0; i < h->dim; ++i) {
-            const uint32_t u = (uint32_t)tmp[i] << 16;
-            std::memcpy(&out[i], &u, 4);
-        }
         return HNSW_OK;
     }
     HIP_TRY(h, hipMemcpyAsync(out, h->d_vec + (size_t)id * h->dim, (size_t)h->dim * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1514,7 +1519,7 @@ hnsw_status hnsw_serialize_size(hnsw_index *h, uint64_t *bytes)
 hnsw_status hnsw_serialize(hnsw_index *h, void *buf, uint64_t cap, uint64_t *written)
 {
     if (!h || !buf || !written) return HNSW_ERR_INVALID;
-    if (h->bf16) return fail(h, HNSW_ERR_INVALID, "snapshots are taken from the f32 index (bf16 storage is a derived serving copy)");
+    if (h->fmt) return fail(h, HNSW_ERR_INVALID, "snapshots are taken from the f32 index (compressed storage is a derived serving copy)");
     uint64_t need = 0;
     hnsw_status s = hnsw_serialize_size(h, &need);
     if (s != HNSW_OK) return s;

@@ -108,7 +108,8 @@ struct hnsw_index {
     bool asymmetric = false;        // links may be one-directional (the fast build prunes that way; imports are checked)
     uint32_t lds_fill_x2 = 13;       // LDS visited table holds lnb * fill/2 ids (of 7 per bucket) before spilling
     int grid_override = -1;
-    bool bf16 = false;               // vectors are stored as bf16 (compress_bf16): read-only, dim 128, specialised kernel only
+    int fmt = 0;                     // storage format of d_vec: FMT_F32, or a compressed read-only serving copy (FMT_BF16 / FMT_FP8)
+    bool bf16 = false;               // fmt == FMT_BF16 (the specialised dim-128 kernel has a bf16 form)
     bool select_shortcut = true;     // select_neighbors after search_level = the head of W (hnsw_insert.hpp); 0 = the full extension
     bool lean = true;                // dim-128 searches use the specialised kernel (hnsw_search_lean.hpp) when its preconditions hold
     size_t lds_reserve = 0;          // LDS a kernel needs besides the wave's own share (the OCC kernels' validation scratch)
@@ -150,7 +151,7 @@ constexpr int kVarMode = MODE_AVX, kVarT = 24;
 #elif HNSW_VARIANT == 3
 constexpr int kVarMode = MODE_AVX, kVarT = 0;
 #else
-#error "HNSW_VARIANT must be 0..3"
+constexpr int kVarMode = MODE_AVX, kVarT = 0;     // 4, 5: the compressed-storage kernels of hnsw_tu_search.hip
 #endif
 #endif
 
@@ -199,6 +200,9 @@ hnsw_status raise_lds_attr(hnsw_index *h, Kern kern, size_t lds, size_t (&have)[
 template <int MODE, int T>
 hnsw_status launch_search_r(hnsw_index *h, int R, const float *dQ, uint32_t B, uint32_t k, uint32_t *d_ids,
                             float *d_sims, uint32_t *d_nout, hipStream_t st);
+template <int FMT>
+hnsw_status launch_search_fmt(hnsw_index *h, int R, const float *dQ, uint32_t B, uint32_t k, uint32_t *d_ids,
+                              float *d_sims, uint32_t *d_nout, hipStream_t st);
 // hnsw_tu_lean.hip: launches k_search_lean<VEC,R,BB,DB> if that instantiation exists (*done), else leaves *done false
 template <class VEC, bool WIDE>
 hnsw_status launch_lean_v(hnsw_index *h, int R, uint32_t bb, uint32_t db, const float *dQ, uint32_t B, uint32_t k,

@@ -8,7 +8,7 @@ namespace hnsw {
 // HNSW.SEARCH (core.rs:477-486 -> search_knn_internal :865-892), one wave per
 // query, grid-stride over the batch.
 // ---------------------------------------------------------------------------
-template <int MODE, int T, int R>
+template <int MODE, int T, int R, int FMT = FMT_F32>
 __global__ __launch_bounds__(64) void k_search(GraphView g, const float *__restrict__ Q, uint32_t B,
                                                uint32_t k, uint32_t ef, uint32_t lnb, uint32_t lcap,
                                                uint32_t *__restrict__ gspill, uint32_t gnb,
@@ -48,12 +48,12 @@ __global__ __launch_bounds__(64) void k_search(GraphView g, const float *__restr
         bool fail = false;
         uint32_t ep = (uint32_t)ep0;
         for (uint32_t lc = lmax; lc >= 1 && !fail; --lc) {  // core.rs:870-874
-            search_level<MODE, T, 1>(g, m, vis, qr, ep, 1, lc, ctr, lane, fail);
+            search_level<MODE, T, 1, FMT>(g, m, vis, qr, ep, 1, lc, ctr, lane, fail);
             ep = key_id(m.W[0]);                          // core.rs:872
             __syncthreads();
         }
         uint32_t nW = 0;
-        if (!fail) nW = search_level<MODE, T, R>(g, m, vis, qr, ep, ef, 0, ctr, lane, fail); // core.rs:876
+        if (!fail) nW = search_level<MODE, T, R, FMT>(g, m, vis, qr, ep, ef, 0, ctr, lane, fail); // core.rs:876
         if (fail) {
             nW = 0;
             if (lane == 0) atomicOr(&g.hdr->status, ST_VISITED_OVERFLOW);
@@ -259,6 +259,31 @@ __global__ void k_f32_to_bf16(const float *__restrict__ src, unsigned short *__r
         const uint32_t u = __float_as_uint(src[i]);
         dst[i] = (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
     }
+}
+
+// f32 -> fp8 (e4m3 as this part's conversion instructions define it; round to nearest even, magnitudes beyond the
+// format's largest finite value saturate to it), two components per conversion
+__global__ void k_f32_to_fp8(const float *__restrict__ src, unsigned char *__restrict__ dst, size_t n)
+{
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x * 2) {
+        const float a = fminf(fmaxf(src[i], -448.f), 448.f);
+        const float b = i + 1 < n ? fminf(fmaxf(src[i + 1], -448.f), 448.f) : 0.f;
+        const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+        dst[i] = (unsigned char)(pk & 0xFF);
+        if (i + 1 < n) dst[i + 1] = (unsigned char)((pk >> 8) & 0xFF);
+    }
+}
+
+// one stored row widened back to f32 (what hnsw_get_vector reports for a compressed index): the same widening the
+// search kernels apply
+template <int FMT>
+__global__ void k_decode_row(const float4 *__restrict__ vec4, size_t row, uint32_t dim, float *__restrict__ out)
+{
+    const uint32_t piece = blockIdx.x * blockDim.x + threadIdx.x;         // 4 components each
+    if (piece * 4 >= dim) return;
+    const float4 v = load_piece<FMT>(vec4, row * (dim >> 2) + piece);
+    reinterpret_cast<float4 *>(out)[piece] = v;
 }
 
 // -inf fill (similarities of an empty result)
