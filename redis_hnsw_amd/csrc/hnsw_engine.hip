@@ -389,10 +389,10 @@ const char *lean_blocker(const hnsw_index *h)
     if (!h->tag_table || h->tag_bb_override >= 0 || h->lds_buckets_override >= 0) return "visited-table test overrides (tag_table / tag_bb / lds_buckets)";
     if (h->stride0 > 128 || h->strideU > 128) return "adjacency rows wider than 127 ids";
     if (R != 1 && R != 4) return "ef_construction > 256";
-    // 16-bit entries: tag (idbits - bb bits) + >= 2 displacement bits; bb is 10 or 11 (9 with waves_per_cu > 8)
+    // 16-bit entries: tag (idbits - bb bits) + >= 2 displacement bits; bb is 9..11 (try_launch_lean picks the largest table the id range needs)
     uint32_t idbits = std::max(ceil_log2(std::max(h->cap, 2u)), 11u);
     if (h->idbits_override > (int)idbits && h->idbits_override <= 31) idbits = (uint32_t)h->idbits_override;
-    if (idbits - (h->max_waves_per_cu > 8 ? 9u : 10u) > 14) return "more than 2^24 node ids";
+    if (idbits > 25) return "more than 2^25 node ids";   // 2048 buckets + 14 tag bits
     return nullptr;
 }
 
@@ -404,14 +404,20 @@ hnsw_status try_launch_lean(hnsw_index *h, const float *dQ, uint32_t B, uint32_t
     const int R = pick_R(h->efc);
     if (lean_blocker(h) || h->fmt == FMT_FP8) return HNSW_OK;
     uint32_t per_cu = ((uint64_t)B * std::max(h->cur_conc, 1u) + 255) / 256;
-    per_cu = std::min(std::max(per_cu, 1u), h->max_waves_per_cu);
-    // 32 KB table at <= 4 waves per CU, 16 KB at <= 8, 8 KB beyond (tuning waves_per_cu > 8)
+    // residency the table is sized for: 8 waves per CU (two per SIMD: the f32 kernel's 177 VGPRs allow no more, and
+    // it is at the memory system's gather ceiling there); the bf16 kernel needs 159 VGPRs and is bound by its
+    // instruction stream, not by HBM -- three waves per SIMD (12 per CU, 8 KB table) measured 3.24 -> 4.0-4.1 M QPS
+    // at C2 (f32 with a 168-VGPR build: 2.54 -> 2.55, and 2 % slower alone on the chip)
+    const uint32_t max_wpc = (h->bf16 && !h->wpc_user) ? 12u : h->max_waves_per_cu;
+    per_cu = std::min(std::max(per_cu, 1u), max_wpc);
+    // 32 KB table at <= 4 waves per CU, 16 KB at <= 8, 8 KB beyond
     uint32_t bb = per_cu >= 9 ? 9 : (per_cu >= 5 ? 10 : 11);
     uint32_t idbits = std::max(ceil_log2(std::max(h->cap, 2u)), 11u);
     if (h->idbits_override > (int)idbits && h->idbits_override <= 31) idbits = (uint32_t)h->idbits_override;
-    // 16-bit entries: tag (idbits - bb bits) + displacement.  3 displacement bits normally; 2^24 ids at 1024
-    // buckets need 14 tag bits, which leaves 2 (chains of at most 3 buckets: more ids go unrecorded, see
-    // tagset_visit -- results are unaffected)
+    // 16-bit entries: tag (idbits - bb bits) + displacement.  3 displacement bits normally; 14 tag bits leave 2
+    // (chains of at most 3 buckets: more ids go unrecorded, see tagset_visit -- results are unaffected).  An id
+    // range too wide for the smaller tables takes the next larger one (fewer waves per CU).
+    while (bb < 11 && idbits - bb > ((bb == 9) ? 13u : 14u)) ++bb;
     uint32_t db = 3;
     if (idbits - bb > 13) {
         if (idbits - bb == 14) db = 2;
@@ -921,7 +927,7 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
         return HNSW_OK;
     }
     if (!std::strcmp(key, "visited_bounded")) { h->visited_bounded = value != 0; return HNSW_OK; }
-    if (!std::strcmp(key, "waves_per_cu")) { h->max_waves_per_cu = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 16); return HNSW_OK; }
+    if (!std::strcmp(key, "waves_per_cu")) { h->wpc_user = true; h->max_waves_per_cu = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 16); return HNSW_OK; }
     if (!std::strcmp(key, "fast_seed")) { h->fast_seed = (uint32_t)std::max<int64_t>(value, 1); return HNSW_OK; }
     if (!std::strcmp(key, "fast_batch_max")) { h->fast_batch_max = (uint32_t)std::max<int64_t>(value, 1); return HNSW_OK; }
     if (!std::strcmp(key, "fast_batch_div")) { h->fast_batch_div = (uint32_t)std::max<int64_t>(value, 1); return HNSW_OK; }

@@ -115,6 +115,7 @@ struct hnsw_index {
     size_t lds_reserve = 0;          // LDS a kernel needs besides the wave's own share (the OCC kernels' validation scratch)
     bool grid_stride = false;        // specialised kernel: cap the grid at the resident waves and walk the batch grid-stride (tuning, for comparison)
     bool visited_bounded = true;     // k_search: a full LDS visited table stops recording (exact results)
+    bool wpc_user = false;           // waves_per_cu was set by the caller (else the kernel's own best residency is used)
     uint32_t max_waves_per_cu = 8;   // residency the LDS visited table is sized for (tuning: waves_per_cu)
     uint32_t launch_concurrency = 0; // tuning: search launches the CALLER keeps in flight at once (0 = observed per launch, see search_concurrency)
     uint32_t pipe_inflight = 1;      // ... and how many the engine's own pipeline has in flight right now
