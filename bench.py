@@ -327,6 +327,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     myQ = torch.from_numpy(Qall[rank * n_qbatches * B:(rank + 1) * n_qbatches * B]).to(dev)
     streams = [torch.cuda.Stream() for _ in range(S)]
+    extra_stream = torch.cuda.Stream()               # a fourth one for the bf16 leg (created now: streams made later, once more
+    #                                                  than GPU_MAX_HW_QUEUES exist, share a hardware queue and serialise)
     # ids and similarities share one buffer so that a single all-gather moves both
     bufs = [torch.empty((2, B, k), dtype=torch.int32, device=dev) for _ in range(S)]
     d_ns = [torch.empty((B,), dtype=torch.int32, device=dev) for _ in range(S)]
@@ -648,7 +650,7 @@ def main():
             gb["vectors"] = V
             ib.import_graph(gb)
             ib.set_tuning("compress_" + fmt_name, 1)
-            cstreams = [torch.cuda.Stream() for _ in range(cs)]
+            cstreams = (streams + [extra_stream])[:cs]
             cbufs = [(torch.empty((B, k), dtype=torch.int32, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev),
                       torch.empty((B,), dtype=torch.int32, device=dev)) for _ in range(cs)]
 
