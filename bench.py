@@ -314,14 +314,28 @@ def main():
         # -- vectors included -- as device-pointer broadcasts over RCCL (host-staged when the ranks share one
         # device in the gloo functional mode)
         tb = time.time()
-        moved = shard.replicate_index(dist, index, src=0, device=torch.device("cuda", local_rank),
-                                      via="device" if backend == "nccl" else "host")
+        via = "device" if backend == "nccl" else "host"
+        if via == "device":
+            # the collective has never carried raw engine pointers on this node before: prove it on 4 KB first
+            probe = torch.arange(1024, dtype=torch.int32, device=torch.device("cuda", local_rank)) * (1 if rank == 0 else 0)
+            try:
+                dist.broadcast(shard.device_bytes(probe.data_ptr(), 4096, torch.device("cuda", local_rank)), src=0)
+                torch.cuda.synchronize()
+                ok_probe = bool((probe == torch.arange(1024, dtype=torch.int32, device=probe.device)).all().item())
+            except RuntimeError as e:                    # pragma: no cover (needs a multi-GPU node)
+                log("RCCL broadcast on a raw device pointer failed (%s): host-staged replication instead" % (e,))
+                ok_probe = False
+            flag = torch.tensor([1 if ok_probe else 0], dtype=torch.int32, device=torch.device("cuda", local_rank))
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                via = "host"
+        moved = shard.replicate_index(dist, index, src=0, device=torch.device("cuda", local_rank), via=via)
         dist.barrier()
         t_repl = time.time() - tb
         log("replicated the index to %d ranks: %.2f GB per replica in %.2f s (%s)" % (
-            world, moved / 1e9, t_repl, "RCCL, HBM to HBM" if backend == "nccl" else "host-staged, gloo"))
+            world, moved / 1e9, t_repl, "RCCL, HBM to HBM" if via == "device" else "host-staged, %s" % backend))
         replication = dict(bytes_per_replica=int(moved), seconds=round(t_repl, 3),
-                           transport="rccl broadcast of device pointers" if backend == "nccl" else "gloo, host-staged")
+                           transport="rccl broadcast of device pointers" if via == "device" else "%s, host-staged" % backend)
 
     # ---- device-resident inputs/outputs ---------------------------------------------
     dev = torch.device("cuda", local_rank)
@@ -335,6 +349,18 @@ def main():
     d_out = bufs[0]
     d_ids, d_sims, d_n = d_out[0], d_out[1].view(torch.float32), d_ns[0]
     cur = torch.cuda.current_stream()
+    if replication is not None:
+        # every replica must answer like rank 0's index: the same 64 queries everywhere, ids + similarity bits gathered
+        chk_q = torch.from_numpy(Qall[:64]).to(dev)
+        chk = torch.empty((2, 64, k), dtype=torch.int32, device=dev)
+        chk_n = torch.empty((64,), dtype=torch.int32, device=dev)
+        index.search_batch_device(chk_q.data_ptr(), 64, k, chk[0].data_ptr(), chk[1].data_ptr(), chk_n.data_ptr(), cur.cuda_stream)
+        torch.cuda.synchronize()
+        allc = shard.gather_packed(dist, chk if backend == "nccl" else chk.cpu(), world).cpu().numpy()
+        same = all(np.array_equal(allc[0], allc[r_]) for r_ in range(1, world))
+        replication["replicas_answer_identically"] = bool(same)
+        if not same:
+            raise SystemExit("index replication: a replica answers differently from rank 0")
 
     # N > 1: the gather of step i runs on its own stream while later steps search
     if world > 1:

@@ -32,6 +32,7 @@ def test_bench_spawns_two_ranks_and_gather_matches_unsharded():
     want = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
     assert out["collective_backend"] == want and (out["rccl_world"] == 2) == (want == "nccl")
     assert out["index_replication"]["bytes_per_replica"] > 20000 * 128 * 4
+    assert out["index_replication"]["replicas_answer_identically"] is True
     assert len(out["per_rank"]["qps"]) == 2 and out["per_rank"]["ms_per_step_max"] >= out["per_rank"]["ms_per_step_min"]
     assert out["topk_exchange"]["allgather_us"] > 0 and out["topk_exchange"]["d2h_to_pinned_us"] > 0
     assert out["scaling"] == "weak" and out["value"] > 0
