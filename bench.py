@@ -660,8 +660,8 @@ def main():
 
     # ---- informational: the compressed serving copies of the same graph (NOT the reference's
     # arithmetic inputs: vectors rounded to bf16 / fp8 e4m3, then the reference's f32 kernel on the stored values) --
-    # same kind of timed loop, 1024-query calls round-robin on `cs` streams (the bf16 form of the dim-128 kernel holds
-    # three waves per SIMD: four calls in flight fill it; fp8 rows are served by the general kernel)
+    # same kind of timed loop, 1024-query calls round-robin on `cs` streams (the bf16 / fp8 forms of the dim-128 kernel
+    # hold three waves per SIMD: four calls in flight fill it)
     bf16 = None
     fp8 = None
     if extras and graph is not None and dim % 32 == 0:
@@ -670,7 +670,7 @@ def main():
         del V_dev
         search_now(myQ[:B], B)
         got32 = d_ids.cpu().numpy().astype(np.int64)
-        for fmt_name, esz, cs in (("bf16", 2, 4), ("fp8", 1, 3)):
+        for fmt_name, esz, cs in (("bf16", 2, 4), ("fp8", 1, 4)):
             ib = Index("bench-" + fmt_name, dim, M, ef, device=local_rank)
             gb = dict(graph)
             gb["vectors"] = V
@@ -698,7 +698,7 @@ def main():
             gotc = d_ids.cpu().numpy().astype(np.int64)
             byc = B * (n_dist_q * esz * dim + n_ids_q * 4 + 4 * dim + 8 * k)
             ent = dict(value=round(B / tbc, 1), unit="queries/s", ms_per_step=round(1e3 * tbc, 4), calls_in_flight=cs,
-                       kernel="specialised dim-128 kernel, bf16 rows" if ib.last_search_was_lean() else "general kernel, %s rows" % fmt_name,
+                       kernel=("specialised dim-128 kernel, %s rows" if ib.last_search_was_lean() else "general kernel, %s rows") % fmt_name,
                        recall_at_10=round(sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(gotc, gt_c)) / (B * k), 4),
                        top10_overlap_with_f32=round(sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(gotc, got32)) / (B * k), 4),
                        achieved=round(byc / tbc / 1e9, 1), frac=round(byc / tbc / 1e9 / HBM_PEAK_GBS, 4),

@@ -402,13 +402,13 @@ hnsw_status try_launch_lean(hnsw_index *h, const float *dQ, uint32_t B, uint32_t
 {
     *done = false;
     const int R = pick_R(h->efc);
-    if (lean_blocker(h) || h->fmt == FMT_FP8) return HNSW_OK;
+    if (lean_blocker(h)) return HNSW_OK;
     uint32_t per_cu = ((uint64_t)B * std::max(h->cur_conc, 1u) + 255) / 256;
     // residency the table is sized for: 8 waves per CU (two per SIMD: the f32 kernel's 177 VGPRs allow no more, and
     // it is at the memory system's gather ceiling there); the bf16 kernel needs 159 VGPRs and is bound by its
     // instruction stream, not by HBM -- three waves per SIMD (12 per CU, 8 KB table) measured 3.24 -> 4.0-4.1 M QPS
     // at C2 (f32 with a 168-VGPR build: 2.54 -> 2.55, and 2 % slower alone on the chip)
-    const uint32_t max_wpc = (h->bf16 && !h->wpc_user) ? 12u : h->max_waves_per_cu;
+    const uint32_t max_wpc = (h->fmt && !h->wpc_user) ? 12u : h->max_waves_per_cu;   // the bf16 / fp8 forms fit three waves per SIMD
     per_cu = std::min(std::max(per_cu, 1u), max_wpc);
     // 32 KB table at <= 4 waves per CU, 16 KB at <= 8, 8 KB beyond
     uint32_t bb = per_cu >= 9 ? 9 : (per_cu >= 5 ? 10 : 11);
@@ -423,11 +423,14 @@ hnsw_status try_launch_lean(hnsw_index *h, const float *dQ, uint32_t B, uint32_t
         if (idbits - bb == 14) db = 2;
         else return HNSW_OK;
     }
-    if (h->stride0 > 64 || h->strideU > 64)              // rows of 64..127 ids: two row words per lane
-        return h->bf16 ? launch_lean_v<VecBF16<4>, true>(h, R, bb, db, dQ, B, k, idbits, per_cu, d_ids, d_sims, d_nout, st, done)
-                       : launch_lean_v<VecF32<4>, true>(h, R, bb, db, dQ, B, k, idbits, per_cu, d_ids, d_sims, d_nout, st, done);
-    return h->bf16 ? launch_lean_v<VecBF16<4>, false>(h, R, bb, db, dQ, B, k, idbits, per_cu, d_ids, d_sims, d_nout, st, done)
-                   : launch_lean_v<VecF32<4>, false>(h, R, bb, db, dQ, B, k, idbits, per_cu, d_ids, d_sims, d_nout, st, done);
+    const bool wide = h->stride0 > 64 || h->strideU > 64;   // rows of 64..127 ids: two row words per lane
+#define LEAN_GO(VEC)                                                                                                          \
+    return wide ? launch_lean_v<VEC, true>(h, R, bb, db, dQ, B, k, idbits, per_cu, d_ids, d_sims, d_nout, st, done)          \
+                : launch_lean_v<VEC, false>(h, R, bb, db, dQ, B, k, idbits, per_cu, d_ids, d_sims, d_nout, st, done)
+    if (h->fmt == FMT_BF16) LEAN_GO(VecBF16<4>);
+    if (h->fmt == FMT_FP8) LEAN_GO(VecFP8<4>);
+    LEAN_GO(VecF32<4>);
+#undef LEAN_GO
 }
 
 // How many search launches share the CUs with the one about to be enqueued on `st` (it sizes the LDS visited

@@ -147,6 +147,10 @@ struct VecBF16 {
                 acc[k] = __builtin_elementwise_fma(d, d, acc[k]);                            // metrics.rs:57,60,64,68
             }
         }
+        return quad_reduce(acc);
+    }
+    static __device__ __forceinline__ float quad_reduce(const f32x2 (&acc)[4])
+    {
         // (e1+e2)+(e3+e4) per AVX lane (metrics.rs:71-74): the accumulators are the 4 lanes of a quad
         float e[8] = {acc[0].x, acc[0].y, acc[1].x, acc[1].y, acc[2].x, acc[2].y, acc[3].x, acc[3].y};
 #pragma unroll
@@ -157,6 +161,51 @@ struct VecBF16 {
         // low128 + high128 (metrics.rs:37-39), then (s0+s1)+(s2+s3) (:27-31)
         const float s0 = __fadd_rn(e[0], e[4]), s1 = __fadd_rn(e[1], e[5]), s2 = __fadd_rn(e[2], e[6]), s3 = __fadd_rn(e[3], e[7]);
         return __fadd_rn(__fadd_rn(s0, s1), __fadd_rn(s2, s3));
+    }
+};
+
+// fp8 rows (e4m3, "compress_fp8"): a quarter of the bytes.  Same layout idea as bf16: lane a of a quad is the
+// reference's accumulator a and loads its 8 components of every 32-component block -- 8 bytes; a quad reads 32
+// contiguous bytes per block.  v_cvt_pk_f32_fp8 widens two components per instruction (exactly), so the widening costs
+// half of what bf16's shift / mask pairs cost; the arithmetic after it is the reference's f32 kernel.
+template <int T>
+struct VecFP8 {
+    static constexpr int LPV = 4, SPR = 16, NR = 3;     // a chunk is 48 ids
+    static constexpr int MIN_WAVES = 2;
+    struct Q { f32x2 q[T][4]; };          // q[t][k] = elements 32t + 8a + 2k, +1
+    struct V { uint2 x[T]; };
+    static __device__ __forceinline__ void load_q(const float *src, Q &q, int lane)
+    {
+        const int a = lane & 3;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const float4 lo = *reinterpret_cast<const float4 *>(src + 32 * t + 8 * a);
+            const float4 hi = *reinterpret_cast<const float4 *>(src + 32 * t + 8 * a + 4);
+            q.q[t][0] = f32x2{lo.x, lo.y}; q.q[t][1] = f32x2{lo.z, lo.w};
+            q.q[t][2] = f32x2{hi.x, hi.y}; q.q[t][3] = f32x2{hi.z, hi.w};
+        }
+    }
+    static __device__ __forceinline__ void load_v(const GraphView &g, uint32_t id, int lane, V &v)
+    {
+        // row = dim bytes = dim/8 pieces of 8 bytes; block t is pieces 4t .. 4t+3
+        const uint2 *p = reinterpret_cast<const uint2 *>(g.vec) + (size_t)id * (g.dim >> 3) + (lane & 3);
+#pragma unroll
+        for (int t = 0; t < T; ++t) v.x[t] = p[t * 4];
+    }
+    static __device__ __forceinline__ float dist(const Q &q, const V &v)
+    {
+        f32x2 acc[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};   // AVX lanes j = 2k, 2k+1
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const f32x2 w[4] = {__builtin_amdgcn_cvt_pk_f32_fp8((int)v.x[t].x, false), __builtin_amdgcn_cvt_pk_f32_fp8((int)v.x[t].x, true),
+                                __builtin_amdgcn_cvt_pk_f32_fp8((int)v.x[t].y, false), __builtin_amdgcn_cvt_pk_f32_fp8((int)v.x[t].y, true)};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x2 d = q.q[t][k] - w[k];
+                acc[k] = __builtin_elementwise_fma(d, d, acc[k]);                            // metrics.rs:57,60,64,68
+            }
+        }
+        return VecBF16<T>::quad_reduce(acc);
     }
 };
 

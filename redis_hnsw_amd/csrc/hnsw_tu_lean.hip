@@ -1,6 +1,6 @@
 // hnsw_tu_lean.hip -- the specialised dim-128 search kernel k_search_lean<VEC,R,BB,DB,WIDE> for one vector format
 // and row width (HNSW_VARIANT 0: f32 rows, the reference's data; 1: the bf16 serving copy; 2 / 3: the same two
-// for adjacency rows of 64..127 ids) and its launcher.
+// for adjacency rows of 64..127 ids; 4 / 5: the fp8 serving copy, narrow / wide rows) and its launcher.
 #include "hnsw_host.hpp"
 #include "hnsw_search_lean.hpp"
 
@@ -57,8 +57,12 @@ LEAN_INSTANCE(VecF32<4>, false)
 LEAN_INSTANCE(VecBF16<4>, false)
 #elif HNSW_VARIANT == 2
 LEAN_INSTANCE(VecF32<4>, true)
-#else
+#elif HNSW_VARIANT == 3
 LEAN_INSTANCE(VecBF16<4>, true)
+#elif HNSW_VARIANT == 4
+LEAN_INSTANCE(VecFP8<4>, false)
+#else
+LEAN_INSTANCE(VecFP8<4>, true)
 #endif
 
 } // namespace hnsw_host
