@@ -63,3 +63,26 @@ def test_error_string_is_the_debug_rendering():
     assert HNSWError("data dimension: 3 does not match Index").error_string() == \
         'String("data dimension: 3 does not match Index")'
     assert HNSWError('Node: "a\\b" already exists').error_string() == 'String("Node: \\"a\\\\b\\" already exists")'
+
+
+def test_ctypes_structs_have_the_header_s_layout(capi, tmp_path):
+    """the Python binding's Structures against the C compiler's view of include/hnsw_mi355x.h: sizes and the offset
+    of every field (a silent mismatch would corrupt hnsw_get_info / replica / pipeline calls)"""
+    import ctypes as C
+    import subprocess
+    structs = {"hnsw_info": capi.Info, "hnsw_counters": capi.Counters, "hnsw_replica": capi.Replica, "hnsw_pipeline": capi.Pipeline}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "hnsw_mi355x.h"', 'int main(void) {']
+    for cname, st in structs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in st._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['return 0; }']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, st in structs.items():
+        assert int(got[cname]) == C.sizeof(st), cname
+        for fname, _ in st._fields_:
+            assert int(got["%s.%s" % (cname, fname)]) == getattr(st, fname).offset, (cname, fname)
