@@ -299,9 +299,11 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
 #pragma unroll
     for (int r = 0; r < R; ++r) pup[r] = 0;
 
+    PH_T0();
     for (;;) {
         ctr.n_expand += 1;
         uint32_t cnt = __builtin_amdgcn_readfirstlane(word);
+        PH_MARK(ctr, 0);  // waiting for the adjacency row
         if (cnt > stride - 1) cnt = stride - 1;
         ctr.n_ids += cnt;
         bool have_next = false;
@@ -342,6 +344,7 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
                 typename VEC::V v[NR];
 #pragma unroll
                 for (int r = 0; r < NR; ++r) VEC::load_v(g, idr[r], lane, v[r]);
+                PH_MARK(ctr, 1);  // chunk set-up, ids to the groups, vector requests
                 // ---- under those loads: visited filter (core.rs:648-649) and the deferred merge ----
                 if (!vis.lossy && vis.count + CH > vis.lcap) {
                     vis.lossy = true;
@@ -354,6 +357,7 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
                 const uint32_t nf = (uint32_t)__popcll(fm);
                 vis.count += nf;
                 ctr.n_dist += nf;                                 // the reference evaluates the fresh ones (core.rs:652)
+                PH_MARK(ctr, 2);  // visited filter
                 if (pn) {
                     nW = merge_apply_lean<R>(w, Wbuf, nW, ef, pkey, ptake, pup, ppos, pn, lane, worst);
                     ptake = false;
@@ -366,6 +370,7 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
                     int r2, l2;
                     if (!first_unexpanded<R>(w, rkey, r2, l2)) rkey = ~0ull;
                 }
+                PH_MARK(ctr, 3);  // deferred merge + first unexpanded
                 // ---- distances ----
                 float dsel = 0.f;
                 uint32_t idsel = idr[0];
@@ -381,6 +386,7 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
                 key = pack_key(dsel, idsel);
                 take = mine && key < worst;                       // core.rs:657
                 if (vis.lossy) take = drop_members<R>(w, key, take, lane);
+                PH_MARK(ctr, 4);  // waiting for the vectors + distances + accept
             } else {
                 if (pn) {
                     nW = merge_apply_lean<R>(w, Wbuf, nW, ef, pkey, ptake, pup, ppos, pn, lane, worst);
@@ -412,6 +418,7 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
                 }
                 pkey = key;
                 ptake = take;
+                PH_MARK(ctr, 5);  // choice of the next candidate + its row request
             }
             c0 += CH;
         } while (c0 < cnt);
@@ -427,6 +434,7 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
         }
         pn = (uint32_t)__popcll(__ballot(ptake));
         if (pn) merge_rank<R>(w, pkey, ptake, pup, ppos, lane);
+        PH_MARK(ctr, 6);  // mark expanded + ranks of the pending keys
         ckey = nkey;
         word = word_next;
         word2 = word2_next;
@@ -482,6 +490,9 @@ __global__ __launch_bounds__(64, VEC::MIN_WAVES) void k_search_lean(GraphView g,
         atomicAdd(&g.hdr->ctr_search[0], (unsigned long long)ctr.n_dist);
         atomicAdd(&g.hdr->ctr_search[1], (unsigned long long)ctr.n_ids);
         atomicAdd(&g.hdr->ctr_search[2], (unsigned long long)ctr.n_expand);
+#ifdef HNSW_PHASE_TIMERS
+        for (int i = 0; i < 7; ++i) atomicAdd(&g.hdr->prof[i], ctr.ph[i]);
+#endif
     }
 }
 
