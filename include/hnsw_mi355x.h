@@ -76,7 +76,9 @@ const char *hnsw_last_error(const hnsw_index *h); /* valid until the next call o
  * exactly the reference's serial algorithm.  level < 0 draws
  * floor(-ln U / ln m) (core.rs:601-605); the first node ignores it
  * (core.rs:393-405).  touched (may be NULL) receives the ids the reference
- * would pass to update_fn (core.rs:580-584), unordered.                      */
+ * would pass to update_fn (core.rs:580-584), each once, unordered; *n_touched
+ * is their number even when it exceeds touched_cap (only touched_cap are
+ * written then: the caller must treat that as an error, not skip the rest).  */
 hnsw_status hnsw_add(hnsw_index *h, const float *v, uint32_t dim, int32_t level,
                      uint32_t *out_id, uint32_t *touched, uint32_t touched_cap,
                      uint32_t *n_touched);
@@ -182,6 +184,41 @@ hnsw_status hnsw_replica_view(hnsw_index *h, hnsw_replica *out);
 hnsw_status hnsw_replica_prepare(hnsw_index *h, hnsw_replica *inout);
 hnsw_status hnsw_replica_commit(hnsw_index *h, const hnsw_replica *r, const uint8_t *dead);
 hnsw_status hnsw_get_tombstones(hnsw_index *h, uint8_t *dead /*[allocated_ids]*/);
+
+/* ---- one process, several GPUs ("one process, 8 devices, one stream each") ----------------------
+ * What a Redis module -- one process -- uses instead of one rank per GPU: a GROUP is the primary index plus one
+ * replica per further device.  Replicas are made by hnsw_replica_view / _prepare / _commit with peer copies
+ * (HBM to HBM over xGMI, no host hop).  Searches are independent (search_knn takes &self, core.rs:477): a batch is
+ * split contiguously, member g takes queries [g*B/G, (g+1)*B/G), every member runs its slice through
+ * hnsw_search_batch on its own device at the same time, results land in the caller's buffers in query order --
+ * no collective, no merge (disjoint queries, not disjoint data).  Writes keep the members identical by being
+ * REPLAYED: insert (core.rs:489-599) and delete_node (:414-475) are deterministic given the level, so
+ * hnsw_group_add / _delete / _add_batch(mode 0) run the same exact operation on every member concurrently, with
+ * the level drawn once by the group (floor(-ln U / ln m), core.rs:601-605, its own seeded generator).  The fast
+ * build (mode 1) is not reproducible link for link: it runs on the primary and the replicas are re-copied
+ * (hnsw_group_refresh, also the way back after writing to the primary directly).
+ * A device may be listed more than once (several members on one GPU: how the path is tested on a one-GPU box).
+ * One caller at a time per group; do not use the primary's handle concurrently with group calls.             */
+typedef struct hnsw_group hnsw_group;
+hnsw_status hnsw_group_create(hnsw_index *primary, const int *devices, uint32_t n_devices, uint64_t seed,
+                              hnsw_group **out);             /* devices: where the REPLICAS go (may be empty);
+                                                                * on failure *out still holds a group to ask
+                                                                * hnsw_group_last_error and to destroy          */
+void hnsw_group_destroy(hnsw_group *g);                      /* destroys the replicas, not the primary        */
+const char *hnsw_group_last_error(const hnsw_group *g);
+uint32_t hnsw_group_size(const hnsw_group *g);               /* members, primary included                     */
+hnsw_index *hnsw_group_member(hnsw_group *g, uint32_t i);    /* 0 = the primary                               */
+hnsw_status hnsw_group_refresh(hnsw_group *g);               /* re-copy every replica from the primary        */
+/* Index::search_knn for B queries, sharded over the members (arguments as hnsw_search_batch)                  */
+hnsw_status hnsw_group_search_batch(hnsw_group *g, const float *Q, uint32_t B, uint32_t dim, uint32_t k,
+                                    uint32_t *ids, float *sims, uint32_t *n_out);
+/* Index::add_node / delete_node on every member (arguments as hnsw_add / hnsw_delete; touched from the primary) */
+hnsw_status hnsw_group_add(hnsw_group *g, const float *v, uint32_t dim, int32_t level, uint32_t *out_id,
+                           uint32_t *touched, uint32_t touched_cap, uint32_t *n_touched);
+hnsw_status hnsw_group_delete(hnsw_group *g, uint32_t id, uint32_t *touched, uint32_t touched_cap,
+                              uint32_t *n_touched);
+hnsw_status hnsw_group_add_batch(hnsw_group *g, const float *V, uint32_t n, uint32_t dim, const int32_t *levels,
+                                 uint32_t mode);
 
 /* Export for IndexRedis/NodeRedis write-through (src/types.rs:62-91,292-309). */
 hnsw_status hnsw_get_info(hnsw_index *h, hnsw_info *info);

@@ -9,6 +9,12 @@ pub struct hnsw_index {
     _private: [u8; 0],
 }
 
+/// one process, several GPUs: the primary index plus one replica per further device
+#[repr(C)]
+pub struct hnsw_group {
+    _private: [u8; 0],
+}
+
 pub const HNSW_OK: c_int = 0;
 pub const HNSW_ERR_DIM_MISMATCH: c_int = 1;
 pub const HNSW_ERR_DUPLICATE: c_int = 2;
@@ -66,4 +72,18 @@ extern "C" {
     pub fn hnsw_serialize_size(h: *mut hnsw_index, bytes: *mut u64) -> c_int;
     pub fn hnsw_serialize(h: *mut hnsw_index, buf: *mut c_void, cap: u64, written: *mut u64) -> c_int;
     pub fn hnsw_deserialize(buf: *const c_void, bytes: u64, seed: u64, device: c_int, out: *mut *mut hnsw_index) -> c_int;
+    // more than one GPU behind one Redis process: searches shard over the members, writes are replayed on each
+    pub fn hnsw_group_create(primary: *mut hnsw_index, devices: *const c_int, n_devices: u32, seed: u64,
+                             out: *mut *mut hnsw_group) -> c_int;
+    pub fn hnsw_group_destroy(g: *mut hnsw_group);
+    pub fn hnsw_group_last_error(g: *const hnsw_group) -> *const c_char;
+    pub fn hnsw_group_size(g: *const hnsw_group) -> u32;
+    pub fn hnsw_group_member(g: *mut hnsw_group, i: u32) -> *mut hnsw_index;
+    pub fn hnsw_group_refresh(g: *mut hnsw_group) -> c_int;
+    pub fn hnsw_group_search_batch(g: *mut hnsw_group, q: *const f32, b: u32, dim: u32, k: u32, ids: *mut u32,
+                                   sims: *mut f32, n_out: *mut u32) -> c_int;
+    pub fn hnsw_group_add(g: *mut hnsw_group, v: *const f32, dim: u32, level: i32, out_id: *mut u32, touched: *mut u32,
+                          touched_cap: u32, n_touched: *mut u32) -> c_int;
+    pub fn hnsw_group_delete(g: *mut hnsw_group, id: u32, touched: *mut u32, touched_cap: u32, n_touched: *mut u32) -> c_int;
+    pub fn hnsw_group_add_batch(g: *mut hnsw_group, v: *const f32, n: u32, dim: u32, levels: *const i32, mode: u32) -> c_int;
 }

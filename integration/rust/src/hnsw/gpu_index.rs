@@ -56,6 +56,10 @@ impl<'a> NodeView<'a> {
     }
 }
 
+/// room for the ids one insert / delete passes to update_fn (core.rs:580-584, :441-446); the engine reports the count
+/// even when it is larger, and the call then fails instead of skipping write-throughs
+const TOUCHED_CAP: usize = 65536;
+
 pub struct GpuIndex {
     pub name: String,
     pub data_dim: usize,
@@ -147,13 +151,16 @@ impl GpuIndex {
             return Err(format!("Node: {:?} already exists", name).into()); // core.rs:407-409 (after the first-node branch)
         }
         let (mut id, mut nt) = (0u32, 0u32);
-        let mut touched = vec![0u32; 8192];
+        let mut touched = vec![0u32; TOUCHED_CAP];
         let st = unsafe {
             ffi::hnsw_add(self.h, data.as_ptr(), data.len() as u32, -1, &mut id, touched.as_mut_ptr(),
                           touched.len() as u32, &mut nt)
         };
         if st != ffi::HNSW_OK {
             return Err(self.last_error());
+        }
+        if nt as usize > touched.len() {
+            return Err(format!("update_fn list of {} ids does not fit the buffer", nt).into());
         }
         debug_assert_eq!(id as usize, self.names.len());
         self.names.push(Some(name.to_owned()));
@@ -174,10 +181,13 @@ impl GpuIndex {
             Some(&id) => id,
             None => return Err(format!("Node: {:?} does not exist", name).into()), // core.rs:419-422
         };
-        let (mut nt, mut touched) = (0u32, vec![0u32; 8192]);
+        let (mut nt, mut touched) = (0u32, vec![0u32; TOUCHED_CAP]);
         let st = unsafe { ffi::hnsw_delete(self.h, id, touched.as_mut_ptr(), touched.len() as u32, &mut nt) };
         if st != ffi::HNSW_OK {
             return Err(self.last_error());
+        }
+        if nt as usize > touched.len() {
+            return Err(format!("update_fn list of {} ids does not fit the buffer", nt).into());
         }
         self.ids.remove(name);
         self.names[id as usize] = None;

@@ -148,7 +148,7 @@ class OracleIndex:
         v = _f32(v)
         assert v.size == self.dim
         if want_touched:
-            cap = 4096
+            cap = 65536
             t = np.empty(cap, dtype=np.uint32)
             n = C.c_uint32(0)
             i = lib().hnsw_oracle_add(self._h, _fp(v), int(level), _u32p(t), cap, C.byref(n))
@@ -163,12 +163,13 @@ class OracleIndex:
 
     # -- delete (core.rs:414-475) ----------------------------------------------
     def delete(self, i, want_touched=False):
-        cap = 8192
+        cap = 65536
         t = np.empty(cap, dtype=np.uint32)
         n = C.c_uint32(0)
         rc = lib().hnsw_oracle_delete(self._h, int(i), _u32p(t), cap, C.byref(n))
         if rc != 0:
             raise KeyError("Node: %r does not exist" % (i,))
+        assert n.value <= cap
         return t[: n.value].copy() if want_touched else None
 
     @property

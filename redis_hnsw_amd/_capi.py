@@ -75,6 +75,17 @@ SIGNATURES = {
     "hnsw_reset_counters": (C.c_int, [H]),
     "hnsw_last_search_kernel_ms": (C.c_int, [H, fp]),
     "hnsw_metric_pairs": (C.c_int, [C.c_int, fp, fp, C.c_uint32, C.c_uint32, fp]),
+    # one process, several GPUs
+    "hnsw_group_create": (C.c_int, [H, C.POINTER(C.c_int), C.c_uint32, C.c_uint64, C.POINTER(H)]),
+    "hnsw_group_destroy": (None, [H]),
+    "hnsw_group_last_error": (C.c_char_p, [H]),
+    "hnsw_group_size": (C.c_uint32, [H]),
+    "hnsw_group_member": (H, [H, C.c_uint32]),
+    "hnsw_group_refresh": (C.c_int, [H]),
+    "hnsw_group_search_batch": (C.c_int, [H, fp, C.c_uint32, C.c_uint32, C.c_uint32, u32p, fp, u32p]),
+    "hnsw_group_add": (C.c_int, [H, fp, C.c_uint32, C.c_int32, u32p, u32p, C.c_uint32, u32p]),
+    "hnsw_group_delete": (C.c_int, [H, C.c_uint32, u32p, C.c_uint32, u32p]),
+    "hnsw_group_add_batch": (C.c_int, [H, fp, C.c_uint32, C.c_uint32, i32p, C.c_uint32]),
 }
 
 _lib = None

@@ -22,6 +22,7 @@ UNITS = [
     ("hnsw_tu_search.hip", [0, 1, 2, 3, 4, 5], ["hnsw_kernels.hpp"]),
     ("hnsw_tu_insert.hip", [0, 1, 2, 3], []),
     ("hnsw_tu_occ.hip", [0, 1, 2, 3], []),
+    ("hnsw_group.hip", [None], []),                   # one process, several GPUs: host code above the C ABI
 ]
 SOURCES = [u[0] for u in UNITS]
 DEPS = sorted(set(SOURCES + _COMMON + [d for u in UNITS for d in u[2]]))

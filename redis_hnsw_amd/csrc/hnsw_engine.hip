@@ -379,7 +379,7 @@ hnsw_status ensure_spill_one(hnsw_index *h)
 }
 
 // The specialised kernel's preconditions that do not depend on the launch (nullptr = all hold).  Indexes it cannot
-// serve (other dims, ef > 256, rows wider than 127 ids, test overrides, fp8 storage) use the general kernel.
+// serve (other dims, ef > 512, rows wider than 127 ids, test overrides, fp8 storage) use the general kernel.
 const char *lean_blocker(const hnsw_index *h)
 {
     const int R = pick_R(h->efc);
@@ -388,7 +388,7 @@ const char *lean_blocker(const hnsw_index *h)
     if (!h->visited_bounded) return "tuning visited_bounded = 0";
     if (!h->tag_table || h->tag_bb_override >= 0 || h->lds_buckets_override >= 0) return "visited-table test overrides (tag_table / tag_bb / lds_buckets)";
     if (h->stride0 > 128 || h->strideU > 128) return "adjacency rows wider than 127 ids";
-    if (R != 1 && R != 4) return "ef_construction > 256";
+    if (R != 1 && R != 4 && R != 8) return "ef_construction > 512";
     // 16-bit entries: tag (idbits - bb bits) + >= 2 displacement bits; bb is 9..11 (try_launch_lean picks the largest table the id range needs)
     uint32_t idbits = std::max(ceil_log2(std::max(h->cap, 2u)), 11u);
     if (h->idbits_override > (int)idbits && h->idbits_override <= 31) idbits = (uint32_t)h->idbits_override;
@@ -954,6 +954,7 @@ hnsw_status hnsw_add(hnsw_index *h, const float *v, uint32_t dim, int32_t level,
     if (s != HNSW_OK) return s;
     if (touched && nt) {
         // the device list may repeat ids (the reference's `updated` is a HashSet, core.rs:522)
+        if (nt > h->touched_cap) return fail(h, HNSW_ERR_CAPACITY, "update_fn list overflow (the insert itself is complete)");
         uint32_t have = std::min(nt, h->touched_cap);
         std::vector<uint32_t> tmp(have);
         HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->d_touched, (size_t)have * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1069,6 +1070,7 @@ hnsw_status hnsw_delete(hnsw_index *h, uint32_t id, uint32_t *touched, uint32_t 
     hnsw_status s = delete_exact(h, id, &nt);
     if (s != HNSW_OK) return s;
     if (touched && (nt || !h->purged_owners.empty())) {
+        if (nt > h->touched_cap) return fail(h, HNSW_ERR_CAPACITY, "update_fn list overflow (the delete itself is complete)");
         uint32_t have = std::min(nt, h->touched_cap);
         std::vector<uint32_t> tmp(have);
         if (have) {

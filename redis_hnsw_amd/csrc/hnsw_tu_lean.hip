@@ -43,6 +43,8 @@ hnsw_status launch_lean_v(hnsw_index *h, int R, uint32_t bb, uint32_t db, const 
     LEAN_CASE(1, 10, 3) LEAN_CASE(1, 11, 3) LEAN_CASE(4, 10, 3) LEAN_CASE(4, 11, 3)
     LEAN_CASE(1, 10, 2) LEAN_CASE(1, 11, 2) LEAN_CASE(4, 10, 2) LEAN_CASE(4, 11, 2)
     LEAN_CASE(1, 9, 3) LEAN_CASE(4, 9, 3)
+    // ef_construction 257..512 (W in eight register slices)
+    LEAN_CASE(8, 10, 3) LEAN_CASE(8, 11, 3) LEAN_CASE(8, 10, 2) LEAN_CASE(8, 11, 2) LEAN_CASE(8, 9, 3)
 #undef LEAN_CASE
     *done = false;
     return HNSW_OK;

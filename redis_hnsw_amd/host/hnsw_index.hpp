@@ -82,7 +82,7 @@ public:
         if (node_count() != 0 && ids_.count(node))                     // core.rs:393-409
             throw HNSWError("Node: \"" + node + "\" already exists", HNSW_ERR_DUPLICATE);
         uint32_t id = 0, nt = 0;
-        std::vector<uint32_t> touched(update_fn ? 8192 : 0);
+        std::vector<uint32_t> touched(update_fn ? 65536 : 0);
         check(hnsw_add(h_, data.data(), (uint32_t)data.size(), level, &id, update_fn ? touched.data() : nullptr,
                        (uint32_t)touched.size(), update_fn ? &nt : nullptr));
         names_.push_back(node);
@@ -98,7 +98,7 @@ public:
         if (it == ids_.end()) throw HNSWError("Node: \"" + node + "\" does not exist", HNSW_ERR_NOT_FOUND);  // :421
         const uint32_t id = it->second;
         uint32_t nt = 0;
-        std::vector<uint32_t> touched(8192);
+        std::vector<uint32_t> touched(65536);
         check(hnsw_delete(h_, id, touched.data(), (uint32_t)touched.size(), &nt));
         ids_.erase(it);
         if (update_fn)                                                 // core.rs:441-446

@@ -111,7 +111,7 @@ class Index:
             raise HNSWError('Node: "%s" already exists' % name, _capi.ERR_DUPLICATE)
         out_id = C.c_uint32(0)
         if update_fn is not None:
-            cap = 8192
+            cap = 65536
             touched = np.empty(cap, dtype=np.uint32)
             nt = C.c_uint32(0)
             self._check(self._lib.hnsw_add(self._h, _fp(data), data.size, int(level), C.byref(out_id),
@@ -124,23 +124,30 @@ class Index:
         self._names.append(name)
         self._ids[name] = i
         if update_fn is not None:                              # core.rs:580-584
-            for t in touched[: min(nt.value, cap)]:
+            for t in self._touched(touched, nt, cap):
                 update_fn(self._name_of(int(t)), int(t))
         return i
+
+    @staticmethod
+    def _touched(buf, nt, cap):
+        """the ids update_fn is called with; the engine reports how many there are even when the buffer is smaller"""
+        if nt.value > cap:
+            raise HNSWError("update_fn list of %d ids does not fit the %d-entry buffer" % (nt.value, cap), _capi.ERR_CAPACITY)
+        return buf[: nt.value]
 
     # -- HNSW.NODE.DEL (core.rs:414-475) --------------------------------------------
     def delete_node(self, name, update_fn=None):
         i = self._ids.get(name)
         if i is None:                                          # core.rs:419-422
             raise HNSWError('Node: "%s" does not exist' % name, _capi.ERR_NOT_FOUND)
-        cap = 8192
+        cap = 65536
         touched = np.empty(cap, dtype=np.uint32)
         nt = C.c_uint32(0)
         self._check(self._lib.hnsw_delete(self._h, i, _u32p(touched), cap, C.byref(nt)))
         del self._ids[name]
         self._names[i] = None
         if update_fn is not None:                              # core.rs:441-446
-            for t in touched[: min(nt.value, cap)]:
+            for t in self._touched(touched, nt, cap):
                 update_fn(self._name_of(int(t)), int(t))
 
     def add_batch(self, vectors, names=None, levels=None, mode="exact"):

@@ -61,7 +61,10 @@ CASES = [
 
 
 @pytest.mark.parametrize("kind,dim,m,ef,n_ops,seed", CASES)
-def test_random_op_sequences_match_the_oracle(eng, oracle_mod, kind, dim, m, ef, n_ops, seed, tunings=()):
+def test_random_op_sequences_match_the_oracle(eng, oracle_mod, kind, dim, m, ef, n_ops, seed, tunings=(), stress=False):
+    """stress (scripts/fuzz_campaign.py): batches large enough for the library's own search pipeline (chunks on three
+    lanes), and at the end the index is turned into a bf16 / fp8 serving copy and compared with the oracle on the
+    stored values (tombstones, wide rows and whatever tunings the case carries included)."""
     rng = np.random.default_rng(seed)
     pool = _data(kind, 6000, dim, rng)
     used = 0
@@ -115,7 +118,7 @@ def test_random_op_sequences_match_the_oracle(eng, oracle_mod, kind, dim, m, ef,
             assert sorted(got) == sorted(ot.tolist()), "op %d: touched set of delete %d" % (op_i, i)
             live.remove(i)
         elif r < 0.93:                                                       # SEARCH, batch and single
-            B = int(rng.choice([1, 3, 40]))
+            B = int(rng.choice([1, 3, 40, 130, 700, 1500] if stress else [1, 3, 40]))
             k = int(rng.choice([1, 5, ef, ef + 7]))
             Q = pool[rng.integers(0, pool.shape[0], B)] + (0 if rng.random() < 0.5 else
                                                             rng.random((B, dim), dtype=np.float32) * np.float32(0.1))
@@ -140,6 +143,30 @@ def test_random_op_sequences_match_the_oracle(eng, oracle_mod, kind, dim, m, ef,
         if op_i % 6 == 5:
             check_graph("after op %d" % op_i)
     check_graph("end")
+    if stress and dim % 32 == 0 and o.live_count > 4:
+        fmt = str(rng.choice(["bf16", "fp8"]))
+        if kind in ("line",) and fmt == "fp8":
+            fmt = "bf16"                                  # coordinates up to 6000: beyond e4m3's range (clamped at 448)
+        gi.set_tuning("compress_" + fmt, 1)
+        g = o.export()
+        n_all = o.node_count
+        Vs = np.zeros((n_all, dim), np.float32)
+        for i in range(n_all):
+            Vs[i] = gi._vector(i)
+        g["vectors"] = Vs
+        o2 = oracle_mod.OracleIndex.from_graph(dim, m, ef, g)
+        for B in (1, 90, 1100):
+            Q = np.ascontiguousarray(pool[rng.integers(0, pool.shape[0], B)] +
+                                     rng.random((B, dim), dtype=np.float32) * np.float32(0.05), dtype=np.float32)
+            k = int(rng.choice([1, 10, ef]))
+            ids, sims, n_out = gi.search_batch(Q, k)
+            oids, osims, on, _ = o2.search_batch(Q, k, threads=8)
+            assert np.array_equal(n_out, on), "compressed %s B=%d" % (fmt, B)
+            for b in range(B):
+                c = int(on[b])
+                assert np.array_equal(ids[b, :c], oids[b, :c]), "compressed %s query %d" % (fmt, b)
+                assert np.array_equal(_bits(sims[b, :c]), _bits(osims[b, :c])), "compressed %s query %d" % (fmt, b)
+        o2.close()
     gi.close()
 
 
@@ -152,3 +179,21 @@ def test_random_op_sequences_match_the_oracle(eng, oracle_mod, kind, dim, m, ef,
 ])
 def test_random_op_sequences_under_non_default_tunings(eng, oracle_mod, kind, dim, m, ef, n_ops, seed, tunings):
     test_random_op_sequences_match_the_oracle(eng, oracle_mod, kind, dim, m, ef, n_ops, seed, tunings)
+
+
+@pytest.mark.parametrize("kind,dim,m,ef,n_ops,seed,tunings", [
+    # found by the round-3 campaign (scripts/fuzz_campaign.py with stress=True, 40 of 282 cases, all M > 32): the device
+    # list behind update_fn is pushed without deduplication and was capped at 8192 entries -- a delete at M = 48 / 64
+    # pushes 10-40 k -- so the reported touched set silently lost ids (the graph itself was right)
+    ("lattice", 64, 64, 200, 40, 300003, ()),
+    ("uniform", 4, 48, 100, 80, 300065, ()),
+    ("clustered", 33, 33, 300, 120, 300067, (("occ_log_cap", 300), ("lean", 1), ("lds_hash_bits", 8), ("occ_min_batch", 2),
+                                              ("occ_ahead_x10", 30), ("waves_per_cu", 4), ("tag_table", 1), ("pipe_chunk", 256),
+                                              ("grid_stride", 1))),
+    ("uniform", 256, 64, 40, 80, 300281, (("select_shortcut", 0), ("pipe_chunk", 1024), ("force_restride", 48))),
+    # the stress form on the reference's usual shapes: large batches through the pipeline, compressed copy at the end
+    ("uniform", 128, 16, 200, 60, 300500, ()),
+    ("clustered", 64, 40, 100, 60, 300501, (("pipe_chunk", 64),)),
+])
+def test_stress_sequences_large_m_pipeline_and_compressed_copies(eng, oracle_mod, kind, dim, m, ef, n_ops, seed, tunings):
+    test_random_op_sequences_match_the_oracle(eng, oracle_mod, kind, dim, m, ef, n_ops, seed, tunings, stress=True)

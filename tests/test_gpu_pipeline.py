@@ -170,6 +170,41 @@ def test_delete_keeps_an_m16_index_on_the_specialised_kernel(eng, oracle_mod):
     gi.close(); o.close()
 
 
+@pytest.mark.parametrize("m,ef,k", [(16, 400, 10), (32, 512, 100), (5, 257, 300)])
+def test_ef_up_to_512_stays_on_the_specialised_kernel(eng, oracle_mod, m, ef, k):
+    """ef_construction 257..512 at dim 128 (W in eight register slices, R = 8): same answers and counters as the oracle
+    through the specialised kernel, narrow and wide rows, k above and below ef"""
+    n, dim = 2500, 128
+    V = make_data(n, dim, seed=23)
+    o, lv = build_oracle(oracle_mod, V, m, ef)
+    g = o.export()
+    g["vectors"] = V
+    gi = eng.Index("r8", dim, m, ef)
+    gi.import_graph(g)
+    Q = make_data(200, dim, seed=24)
+    gi.set_tuning("waves_per_cu", 4)                               # the 32 KB table: nothing is forgotten at this size
+    gi.reset_counters()
+    ids, sims, n_out = gi.search_batch(Q, k)
+    assert gi.last_search_was_lean(), gi.lean_blocker()
+    oids, osims, on, oct = o.search_batch(Q, k, threads=8)
+    assert np.array_equal(n_out, on)
+    for b in range(Q.shape[0]):
+        c = int(on[b])
+        assert np.array_equal(ids[b, :c], oids[b, :c]) and np.array_equal(_bits(sims[b, :c]), _bits(osims[b, :c]))
+    sc, _ = gi.counters()
+    assert (sc.n_dist, sc.n_ids, sc.n_expand) == (oct.n_dist, oct.n_ids, oct.n_expand)
+    gi.set_tuning("waves_per_cu", 8)                               # bounded table: re-met nodes may be evaluated twice
+    gi.reset_counters()
+    ids2, sims2, n2 = gi.search_batch(Q, k)
+    assert gi.last_search_was_lean()
+    assert np.array_equal(n2, on) and np.array_equal(ids2, ids) and np.array_equal(_bits(sims2), _bits(sims))
+    sc, _ = gi.counters()
+    assert (sc.n_ids, sc.n_expand) == (oct.n_ids, oct.n_expand) and sc.n_dist >= oct.n_dist
+    one = gi.search_knn(Q[0], k)
+    assert [x.id for x in one] == oids[0, : int(on[0])].tolist()
+    gi.close(); o.close()
+
+
 @pytest.mark.parametrize("m,widen", [(16, 0), (16, 32), (32, 0), (24, 0)])
 def test_wide_rows_stay_on_the_specialised_kernel(eng, oracle_mod, m, widen):
     """rows of 64..127 ids (M > 16, or an M = 16 index after a restride): same answers and counters as the oracle,
@@ -206,7 +241,7 @@ def _stored(gi, n):
 
 
 @pytest.mark.parametrize("fmt,dim,m,ef,k", [("bf16", 128, 16, 200, 10),    # the specialised kernel's bf16 form
-                                            ("bf16", 128, 16, 400, 10),    # ef > 256: the general kernel
+                                            ("bf16", 128, 16, 400, 10),    # ef 257..512: the R = 8 form of the dim-128 kernel
                                             ("bf16", 64, 8, 100, 10), ("bf16", 768, 32, 400, 100), ("bf16", 128, 32, 64, 10),
                                             ("fp8", 128, 16, 200, 10), ("fp8", 256, 5, 16, 5), ("fp8", 768, 32, 400, 50)])
 def test_compressed_storage_is_the_reference_on_the_stored_values(eng, oracle_mod, fmt, dim, m, ef, k):

@@ -45,13 +45,14 @@ def _c_type_to_rust(ctype):
 def _header_functions():
     text = _strip_comments(open(os.path.join(ROOT, "include", "hnsw_mi355x.h")).read())
     fns = {}
-    for m in re.finditer(r"\b(hnsw_status|void|const char \*)\s*(hnsw_[a-z_0-9]+)\s*\(([^)]*)\)\s*;", text):
+    for m in re.finditer(r"\b(hnsw_status|void|const char \*|uint32_t|hnsw_index \*)\s*(hnsw_[a-z_0-9]+)\s*\(([^)]*)\)\s*;", text):
         ret, name, args = m.group(1), m.group(2), m.group(3)
         params = []
         for a in [x.strip() for x in args.split(",") if x.strip()]:
             mm = re.match(r"(.*?)([A-Za-z_][A-Za-z_0-9]*)$", a)          # type, then the parameter name
             params.append(_c_type_to_rust(mm.group(1)))
-        fns[name] = (params, {"hnsw_status": "c_int", "void": None, "const char *": "*const c_char"}[ret])
+        fns[name] = (params, {"hnsw_status": "c_int", "void": None, "const char *": "*const c_char", "uint32_t": "u32",
+                                "hnsw_index *": "*mut hnsw_index"}[ret])
     return fns
 
 
