@@ -13,7 +13,8 @@ lanes got is measured and reported as config.pipeline).  The same pipelining liv
 callers that hand over one large batch: `host_buffers` (hnsw_search_batch, 8192 queries from host memory, PCIe
 in and out) and `device_call` (one hnsw_search_batch_device call of 4096 / 8192 / 16384 queries) report it.
 One process per GPU; the index is replicated, every rank serves its own batches (weak scaling) and the [B,k]
-results are all-gathered over RCCL.  Prints ONE JSON line on rank 0.
+results are all-gathered over RCCL.  Prints ONE JSON line on rank 0.  (`single_process_group`, informational: the
+one-process form a Redis module would use, hnsw_group_* -- only when this process sees more than one device.)
 
 The graph the headline runs on (--graph):
   reference  the REFERENCE-ORDER graph (core.rs:489-599, one insert after the other): read from the fixture
@@ -730,6 +731,40 @@ def main():
     log("host buffers: %.0f QPS at B=%d, %.0f at B=%d" % (host_qps, Qh.shape[0], host_qps_1024, B))
     pipe = index.pipeline_info()
 
+    # ---- one process, every visible GPU (SURVEY 8e "one process, 8 devices"; what a Redis module would use): the
+    # C ABI's hnsw_group_* layer -- replicas by peer copies, the host batch split over the members, one host thread
+    # per replica.  Informational: runs when this process sees more than one device (HNSW_BENCH_GROUP=1 forces the
+    # functional form with a second member on the same device); never `value`.
+    group_leg = None
+    ndev_vis = torch.cuda.device_count()
+    if extras and (ndev_vis > 1 or os.environ.get("HNSW_BENCH_GROUP") == "1"):
+        try:
+            from redis_hnsw_amd.group import Group
+            devs = [d for d in range(ndev_vis) if d != local_rank] if ndev_vis > 1 else [local_rank]
+            tg0 = time.perf_counter()
+            grp = Group(index, devs)
+            t_make = time.perf_counter() - tg0
+            Gn = len(grp)
+            Qg = np.ascontiguousarray(np.tile(Qall[:8 * B], (Gn, 1))[:8 * B * Gn])
+            g_ids, _, _ = grp.search_batch(Qg, k)
+            tg = time.perf_counter()
+            for _ in range(3):
+                g_ids, _, _ = grp.search_batch(Qg, k)
+            g_qps = 3 * Qg.shape[0] / (time.perf_counter() - tg)
+            same = bool(np.array_equal(g_ids[:Qh.shape[0]], hb_ids))
+            group_leg = dict(members=Gn, devices=[local_rank] + devs, create_seconds=round(t_make, 3),
+                             batch=int(Qg.shape[0]), value=round(g_qps, 1), unit="queries/s",
+                             vs_one_member=round(g_qps / host_qps, 3), answers_equal_single_index=same,
+                             note="hnsw_group_search_batch from pageable host memory (8192 queries per member per call); "
+                                  "weak scaling against host_buffers")
+            grp.close()
+            log("single-process group of %d: %.0f QPS (%.2fx one member), identical answers: %s" % (Gn, g_qps, g_qps / host_qps, same))
+            if not same:
+                raise SystemExit("hnsw_group_search_batch answers differ from the single index")
+        except Exception as e:                       # informational leg: report, never fail the bench line
+            group_leg = dict(error=repr(e)[:300])
+            log("single-process group leg failed: %r" % (e,))
+
     # ---- roofline of the dominant kernel (k_search) -------------------------------------
     # algorithmic bytes per launch = B x (n_dist*4*dim + n_ids*4 + 4*dim + 8*k)  (SURVEY 8d), the reference's counts
     bytes_per_launch = B * (n_dist_q * 4 * dim + n_ids_q * 4 + 4 * dim + 8 * k)
@@ -865,7 +900,7 @@ def main():
         "per_rank": per_rank, "index_replication": replication, "topk_exchange": gather_cmp,
         "recall_at_%d" % k: None if recall is None else round(recall, 4),
         "build_seconds": None if t_build is None else round(t_build, 2),
-        "host_buffers_qps": round(host_qps, 1), "host_buffers": host, "device_call": dev_calls,
+        "host_buffers_qps": round(host_qps, 1), "host_buffers": host, "single_process_group": group_leg, "device_call": dev_calls,
         "gpu_fast_build": fast_build, "gpu_exact_build": exact_build,
         "clustered": clus,
         "bf16_storage_mode": bf16, "fp8_storage_mode": fp8,
