@@ -24,8 +24,8 @@ while time.time() - t0 < budget:
     dim = int(rng.choice([4, 32, 64, 128, 128, 256]))
     if kind == "line":
         dim = 4
-    m = int(rng.choice([2, 5, 8, 16, 16, 32]))
-    ef = int(rng.choice([max(m, 8), 40, 100, 200]))
+    m = int(rng.choice([2, 5, 8, 16, 16, 32, 40, 64]))
+    ef = int(rng.choice([max(m, 8), 40, 100, 200, 400]))
     n = int(rng.choice([8000, 20000, 40000]))
     tun = []
     for key, vals in (("occ_window", [8, 32, 64]), ("occ_ahead_x10", [10, 15, 40]), ("select_shortcut", [0, 1]),

@@ -27,10 +27,10 @@ while time.time() - t0 < budget:
     dim = int(rng.choice([32, 64, 96, 128, 128, 128, 256, 768, 100]))
     if dim >= 256:
         n = min(n, 20000)
-    m = int(rng.choice([3, 5, 8, 16, 16, 24, 32]))
-    ef = int(rng.choice([10, 50, 200, 200, 400, 700]))
+    m = int(rng.choice([3, 5, 8, 16, 16, 24, 32, 40, 48]))
+    ef = int(rng.choice([10, 50, 200, 200, 300, 400, 512, 700]))
     k = int(rng.choice([1, 10, 100]))
-    B = int(rng.choice([1, 17, 256, 1500]))
+    B = int(rng.choice([1, 17, 256, 1500, 5000]))
     kind = str(rng.choice(["uniform", "clustered", "lattice"]))
     if kind == "uniform":
         V = rng.random((n, dim), dtype=np.float32)
@@ -43,11 +43,13 @@ while time.time() - t0 < budget:
     tun = []
     for key, vals in (("visited_bounded", [0, 1]), ("lean", [0, 1]), ("waves_per_cu", [1, 2, 4, 8, 12]),
                       ("lds_hash_bits", [8, 10, 12]), ("tag_table", [0, 1]), ("idbits", [20, 24]),
-                      ("launch_concurrency", [1, 2]), ("query_in_lds", [0, 1])):
+                      ("launch_concurrency", [1, 2]), ("query_in_lds", [0, 1]), ("pipe_chunk", [64, 512, 1024]),
+                      ("grid_stride", [0, 1]), ("force_restride", [16, 64])):
         if rng.random() < 0.35:
             tun.append((key, int(rng.choice(vals))))
-    bf16 = rng.random() < 0.3 and dim == 128 and ef <= 256 and m <= 24
-    case = dict(seed=seed, n=n, dim=dim, m=m, ef=ef, k=k, B=B, kind=kind, tun=tun, bf16=bf16)
+    # compressed serving copies: any dim % 32 == 0, any M and ef (round 3)
+    fmt = str(rng.choice(["f32", "f32", "bf16", "fp8"])) if dim % 32 == 0 else "f32"
+    case = dict(seed=seed, n=n, dim=dim, m=m, ef=ef, k=k, B=B, kind=kind, tun=tun, fmt=fmt)
     try:
         gi = eng.Index("fs", dim, m, ef)
         gi.add_batch(V, levels=oracle_mod.draw_levels(n, m, seed), mode="fast")
@@ -61,10 +63,12 @@ while time.time() - t0 < budget:
                 gi.set_tuning(key, val)
             except eng.HNSWError:
                 pass
-        if bf16:
-            gi.set_tuning("compress_bf16", 1)
+        if fmt != "f32":
+            gi.set_tuning("compress_" + fmt, 1)
             import torch
-            g["vectors"] = torch.from_numpy(g["vectors"]).to(torch.bfloat16).to(torch.float32).numpy()
+            g["vectors"] = torch.from_numpy(g["vectors"]).to(torch.bfloat16 if fmt == "bf16" else torch.float8_e4m3fn).to(torch.float32).numpy()
+            probe = rng.integers(0, n, 8)
+            assert all(np.array_equal(bits(gi._vector(int(i))), bits(g["vectors"][int(i)])) for i in probe), "stored values"
         Qo = Q                                                # queries stay f32 in the bf16 storage mode
         o = oracle_mod.OracleIndex.from_graph(dim, m, ef, g)
         gi.reset_counters()
