@@ -622,6 +622,11 @@ hnsw_status search_batch_pipelined(hnsw_index *h, const float *Q, uint32_t B, ui
     if ((s = ensure_pipe_stage(h, per, k)) != HNSW_OK) return s;
     const uint32_t lanes = std::min(nch, hnsw_index::kPipe);
     auto lane_st = [&](uint32_t l) { return l == 0 ? h->stream : h->pipe_st[l]; };
+    // Whatever a launch may still enqueue on the engine's stream must be there BEFORE the other lanes take their
+    // dependency on it: the HBM visited tables are (re)allocated and filled on h->stream when the index has grown
+    // (or on the very first search), and a chunk on lane 1 that started under that fill read and lost visited
+    // marks -- duplicate ids in its answers (found by scripts/fuzz_search.py; launch_search's own call is a no-op then)
+    if ((s = ensure_spill(h)) != HNSW_OK) return s;
     // the graph was written on the engine's stream: the other lanes start after it
     if (lanes > 1) {
         HIP_TRY(h, hipEventRecord(h->ev_sync, h->stream));

@@ -401,3 +401,32 @@ def test_m_above_64_is_refused_with_the_limit_in_the_message(eng):
     ids, _, n_out = gi.search_batch(V[:50], 5)
     assert np.all(n_out == 5) and np.mean(ids[:, 0] == np.arange(50)) > 0.9
     gi.close()
+
+
+def test_pipelined_search_waits_for_the_lazily_filled_spill_tables(eng, oracle_mod):
+    """The HBM visited tables are (re)allocated and filled on the engine's stream when a search finds them too small --
+    the first search, or the first one after the index grew or restrode.  A host batch split over the engine's lanes
+    took its dependency on that stream BEFORE the fill was enqueued, so the chunk on lane 1 ran under the fill and lost
+    visited marks: duplicate ids in its answers (scripts/fuzz_search.py seed 410169, reproduced 5 of 5 with
+    scripts/repro_search.py: 270 of the second chunk's 750 queries)."""
+    n, dim, m, ef, k = 20000, 64, 16, 200, 10
+    V = make_data(n, dim, seed=71)
+    gi = eng.Index("spillrace", dim, m, ef)
+    gi.add_batch(V, levels=oracle_mod.draw_levels(n, m, 7), mode="fast")
+    g = gi.export_graph()
+    g["vectors"] = V
+    o = oracle_mod.OracleIndex.from_graph(dim, m, ef, g)
+    Q = make_data(1500, dim, seed=72)
+    want = o.search_batch(Q, k, threads=8)
+    gi.set_tuning("visited_bounded", 0)                       # the exact set: every query moves to its HBM table ...
+    gi.set_tuning("lds_hash_bits", 8)                         # ... after 224 ids
+    for widen in (16, 16):                                    # each restride makes the next search re-allocate the tables
+        gi.set_tuning("force_restride", widen)
+        ids, sims, n_out = gi.search_batch(Q, k)              # two chunks of 750 on two lanes
+        assert np.array_equal(n_out, want[2])
+        bad = [b for b in range(Q.shape[0]) if not np.array_equal(ids[b], want[0][b]) or not np.array_equal(_bits(sims[b]), _bits(want[1][b]))]
+        assert not bad, "queries %s ... differ (%d)" % (bad[:6], len(bad))
+        assert all(len(set(r.tolist())) == k for r in ids)    # no id twice in an answer
+    sc, _ = gi.counters()
+    assert sc.n_spill > 0                                     # the HBM tables were really in use
+    gi.close(); o.close()
