@@ -8,6 +8,7 @@
 #include "hnsw_host.hpp"
 #include "hnsw_kernels.hpp"
 #include "hnsw_search_lean.hpp"
+#include "hnsw_plan_lean.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -394,6 +395,34 @@ const char *lean_blocker(const hnsw_index *h)
     if (h->idbits_override > (int)idbits && h->idbits_override <= 31) idbits = (uint32_t)h->idbits_override;
     if (idbits > 25) return "more than 2^25 node ids";   // 2048 buckets + 14 tag bits
     return nullptr;
+}
+
+// The insert plans' form of the same question (hnsw_plan_lean.hpp): 0 = the general plan kernels, else the width of
+// the id hash.  One plan per workgroup: always the 2048-bucket table with 3 displacement bits (ids < 2^24).
+uint32_t plan_lean_idbits(const hnsw_index *h, const InsertCfg &c)
+{
+    if (!h->plan_lean || h->mode != MODE_AVX || h->dim != 128 || h->fmt != FMT_F32) return 0;
+    if (h->stride0 > 128 || h->strideU > 128) return 0;
+    if (c.R != 1 && c.R != 4 && c.R != 8) return 0;
+    if ((uint32_t)c.R * 64u < h->efc) return 0;
+    uint32_t idbits = std::max(ceil_log2(std::max(h->cap, 2u)), 11u);
+    if (h->idbits_override > (int)idbits && h->idbits_override <= 31) idbits = (uint32_t)h->idbits_override;
+    if (idbits > 24) return 0;
+    if (c.lds + plan_lean_lds(c.R) > 160 * 1024 - 2048) return 0;
+    return idbits;
+}
+size_t plan_lean_lds(int R)
+{
+    return R == 1 ? plan_lean_bytes<1>() : (R == 4 ? plan_lean_bytes<4>() : plan_lean_bytes<8>());
+}
+hnsw_status launch_occ_plan_lean(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t head, uint32_t count, bool *done)
+{
+    *done = false;
+    const uint32_t idbits = plan_lean_idbits(h, c);
+    if (!idbits) return HNSW_OK;
+    *done = true;
+    return (h->stride0 > 64 || h->strideU > 64) ? launch_occ_plan_lean_v<true>(h, c, ob, head, count, idbits)
+                                                : launch_occ_plan_lean_v<false>(h, c, ob, head, count, idbits);
 }
 
 // returns HNSW_OK and sets *done when the specialised kernel was launched
@@ -923,6 +952,7 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
         return HNSW_OK;
     }
     if (!std::strcmp(key, "select_shortcut")) { h->select_shortcut = value != 0; return HNSW_OK; }
+    if (!std::strcmp(key, "plan_lean")) { h->plan_lean = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "occ_window")) { h->occ_window = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), kOccMaxW); return HNSW_OK; }
     if (!std::strcmp(key, "occ_ahead_x10")) { h->occ_ahead_x10 = (uint32_t)std::max<int64_t>(value, 5); return HNSW_OK; }
     if (!std::strcmp(key, "occ_slack_extra")) { h->occ_slack_extra = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 64); return HNSW_OK; }
@@ -1667,6 +1697,14 @@ hnsw_status hnsw_debug_occ(hnsw_index *h, uint64_t *out5 /* [16] */)
     out5[3] = h->occ_last.n_stale; out5[4] = h->occ_last.nJ; out5[5] = h->occ_last.stop;   // [5] = rounds
     for (int i = 0; i < 8; ++i) out5[6 + i] = h->occ_last.prof[i];   // commit kernel phases, shader clocks
     out5[14] = h->occ_last.n_norec; out5[15] = h->occ_last.n_rowstale;
+    return HNSW_OK;
+}
+
+// recomputed shrinks of the last windowed build by cause (development aid; not in the public header)
+hnsw_status hnsw_debug_occ_causes(hnsw_index *h, uint64_t *out8)
+{
+    if (!h || !out8) return HNSW_ERR_INVALID;
+    for (int i = 0; i < 8; ++i) out8[i] = h->occ_last.n_cls[i];
     return HNSW_OK;
 }
 

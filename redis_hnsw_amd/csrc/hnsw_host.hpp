@@ -6,6 +6,7 @@
 //   hnsw_tu_lean.hip     k_search_lean<VEC,R,BB,DB,WIDE>       (dim-128 specialisation)        x 4 variants
 //   hnsw_tu_insert.hip   k_insert_plan / k_insert_commit_exact / k_delete_exact / k_shrink_batch x 4 variants
 //   hnsw_tu_occ.hip      k_occ_validate / plan / shrinks / commit                              x 4 variants
+//   hnsw_tu_planlean.hip k_insert_plan_lean / k_occ_plan_lean  (dim-128 plans, specialised search) x 2 row widths
 // A variant is one (metric order, query placement) pair, HNSW_VARIANT = 0..3:
 //   0 MODE_SCALAR,T=0   1 MODE_AVX,T=4 (dim 128)   2 MODE_AVX,T=24 (dim 768)   3 MODE_AVX,T=0 (any dim % 32 == 0)
 // Each launcher template is defined in its family's file and explicitly instantiated there for the variant
@@ -111,6 +112,7 @@ struct hnsw_index {
     int fmt = 0;                     // storage format of d_vec: FMT_F32, or a compressed read-only serving copy (FMT_BF16 / FMT_FP8)
     bool bf16 = false;               // fmt == FMT_BF16 (the specialised dim-128 kernel has a bf16 form)
     bool select_shortcut = true;     // select_neighbors after search_level = the head of W (hnsw_insert.hpp); 0 = the full extension
+    bool plan_lean = true;           // dim-128 insert plans (single adds, the windowed exact build) search with the specialised routine (hnsw_plan_lean.hpp)
     bool lean = true;                // dim-128 searches use the specialised kernel (hnsw_search_lean.hpp) when its preconditions hold
     size_t lds_reserve = 0;          // LDS a kernel needs besides the wave's own share (the OCC kernels' validation scratch)
     bool grid_stride = false;        // specialised kernel: cap the grid at the resident waves and walk the batch grid-stride (tuning, for comparison)
@@ -216,6 +218,15 @@ template <int MODE, int T>
 hnsw_status launch_shrink_t(hnsw_index *h, uint32_t *pending0, uint32_t *pendingU, uint32_t *work_n);
 template <int MODE, int T>
 hnsw_status launch_delete_r(hnsw_index *h, const InsertCfg &c, uint32_t id);
+// hnsw_tu_planlean.hip: the plans that search with the specialised dim-128 routine (narrow / wide adjacency rows)
+template <bool WIDE>
+hnsw_status launch_plan_lean_v(hnsw_index *h, const InsertCfg &c, uint32_t first, uint32_t count, uint32_t idbits);
+template <bool WIDE>
+hnsw_status launch_occ_plan_lean_v(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t head, uint32_t count, uint32_t idbits);
+// hnsw_engine.hip: 0 when the specialised plan cannot serve this index, else the id-hash width to launch it with
+uint32_t plan_lean_idbits(const hnsw_index *h, const InsertCfg &c);
+size_t plan_lean_lds(int R);
+hnsw_status launch_occ_plan_lean(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t head, uint32_t count, bool *done);
 // hnsw_tu_occ.hip
 template <int MODE, int T>
 hnsw_status occ_round_r(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t head, uint32_t count, uint32_t end_node);

@@ -42,6 +42,7 @@ struct OccSlot {
     uint32_t node, planned, snap, epoch;
     uint32_t n_reads, n_shr, top, fail;     // fail: the plan could not be logged (log overflow, visited overflow)
 };
+enum { OCC_WHY_ROW = 1, OCC_WHY_OPEN = 2, OCC_WHY_ADD = 4, OCC_WHY_REMOVE = 8 };   // why a speculative shrink is stale (flags[2 + sub]; the first cause met, later entries are not looked at)
 enum { OCC_STOP_NONE = 0, OCC_STOP_REPLAN = 1, OCC_STOP_RESTRIDE = 2, OCC_STOP_SERIAL = 3 };
 struct OccCtl {
     uint32_t head;                          // next node id to commit
@@ -49,6 +50,7 @@ struct OccCtl {
     uint32_t epoch;                         // bumped when enterpoint / max_layer change (every plan reads them)
     uint32_t stop;                          // why the last commit kernel stopped
     unsigned long long n_commit, n_spec, n_fallback, n_stale, n_norec, n_rowstale;
+    unsigned long long n_cls[8];            // recomputed shrinks by cause: no record, row changed, pool not full, a relevant removal, relevant additions only
     unsigned long long prof[8];             // commit kernel, shader clocks: hash, first check, connect, shrink checks, apply, recompute, finish, total
 };
 
@@ -159,20 +161,20 @@ __device__ __forceinline__ void occ_check_range(const GraphView &g, const WaveMe
                     if (kind == OCC_SHRINK_ROW) {
                         if (d.z == q && add) continue;                   // this node's own connect
                         if (!sc.flags[2 + sub]) atomicAdd(&ob.ctl->n_rowstale, 1ull);
-                        sc.flags[2 + sub] = 1;
+                        atomicOr(&sc.flags[2 + sub], OCC_WHY_ROW);
                         continue;
                     }
                     if (kind == OCC_SHRINK_NB) {
                         if (d.z == sc.flags[2 + kOccMaxShr + sub] || d.z == q) continue;   // e is excluded (core.rs:704); q is in econn already
                         if (sc.flags[2 + sub]) continue;
-                        if (!full) { sc.flags[2 + sub] = 1; continue; }
+                        if (!full) { atomicOr(&sc.flags[2 + sub], OCC_WHY_OPEN); continue; }
                     } else {
                         if (shrinks_only) continue;                      // the link plan was already accepted
                         if (!full) { sc.flags[0] = 1; continue; }
                     }
                     const uint32_t p = atomicAdd(&sc.flags[1], 1u);
                     if (p < kOccMaxHits) {
-                        sc.hits[3 * p] = kind == OCC_SHRINK_NB ? 1u + sub : 0u;
+                        sc.hits[3 * p] = (kind == OCC_SHRINK_NB ? 1u + sub : 0u) | (add ? 0x100u : 0u);
                         sc.hits[3 * p + 1] = d.z;
                         sc.hits[3 * p + 2] = sc.rbound[i];
                     } else sc.flags[0] = 1;                              // too many to evaluate: treat as stale
@@ -187,7 +189,9 @@ __device__ __forceinline__ void occ_check_range(const GraphView &g, const WaveMe
     for (uint32_t base = 0; base < nh; base += 64) {
         const uint32_t i = base + lane;
         bool active = i < nh;
-        const uint32_t reader = active ? sc.hits[3 * i] : 0u, z = active ? sc.hits[3 * i + 1] : 0u;
+        const uint32_t reader_w = active ? sc.hits[3 * i] : 0u, z = active ? sc.hits[3 * i + 1] : 0u;
+        const uint32_t reader = reader_w & 0xFFu;
+        const bool was_add = (reader_w & 0x100u) != 0;
         const uint32_t bound = active ? sc.hits[3 * i + 2] : 0u;
         // a shrink already known stale needs no more distances
         if (active && reader && sc.flags[1 + reader]) active = false;
@@ -208,7 +212,7 @@ __device__ __forceinline__ void occ_check_range(const GraphView &g, const WaveMe
             compute_dists<MODE, T>(g, qr, m, nf, lane);
             __syncthreads();
             if (sel && __float_as_uint(m.dsc[idx]) <= bound) {
-                if (rd) sc.flags[1 + rd] = 1;
+                if (rd) atomicOr(&sc.flags[1 + rd], was_add ? OCC_WHY_ADD : OCC_WHY_REMOVE);
                 else sc.flags[0] = 1;
             }
             am &= ~sm;
@@ -216,6 +220,62 @@ __device__ __forceinline__ void occ_check_range(const GraphView &g, const WaveMe
     }
     if (lane == 0) sc.flags[1] = 0;
     __syncthreads();
+}
+
+// The tail of a plan: the shrinks the connect will trigger (core.rs:560-561) are listed here (k_occ_shrinks computes
+// them speculatively, one wave each), then the slot is published.  Shared by k_occ_plan and k_occ_plan_lean.
+__device__ __forceinline__ void occ_plan_finish(const GraphView &g, const OccBufs &ob, OccSlot *sl, OccShr *shr, const uint32_t *pl0,
+                                                WorkCtr &ctr, uint32_t id, uint32_t top, uint32_t mlinks, uint32_t log_cap,
+                                                uint32_t snap, uint32_t epoch, bool fail, Visited &vis, int lane)
+{
+    (void)ob;
+    // ---- the shrinks the connect will trigger (core.rs:560-561): listed here, computed speculatively by
+    // k_occ_shrinks, one wave each ----
+    uint32_t n_shr = 0;
+    for (uint32_t lc1 = top + 1; lc1-- > 0 && !fail;) {
+        const uint32_t lc = lc1;
+        const uint32_t stride = lc ? g.strideU : g.stride0;
+        const uint32_t mmax = lc ? mlinks : 2 * mlinks;     // core.rs:560
+        const uint32_t *pl = pl0 + (size_t)lc * kPlanStride;
+        const uint32_t nsel = pl[0];
+        const uint32_t e = (uint32_t)lane < nsel ? pl[1 + lane] : 0u;
+        uint32_t cnt = (uint32_t)lane < nsel ? row_ptr(g, e, lc)[0] : 0u;
+        if (cnt > stride - 1) cnt = stride - 1;
+        const bool need = (uint32_t)lane < nsel && cnt + 1 > mmax;   // :561 (the row with this node appended)
+        const uint64_t nm = __ballot(need);
+        const uint32_t k = n_shr + (uint32_t)__popcll(nm & lanemask_lt(lane));
+        // log ranges: running sum of (cnt + 2) over the lanes that need a shrink, in selection order
+        uint32_t off = 0;
+        uint32_t run = ctr.log_n;
+        for (uint64_t mm = nm; mm; mm &= mm - 1) {
+            const int j = __ffsll((unsigned long long)mm) - 1;
+            const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cnt, j);
+            if (lane == j) off = run;
+            run += cj + 2;
+        }
+        if (need) {
+            if (k >= kOccMaxShr || cnt + 1 > kAuxWords) fail = true;
+            else {
+                OccShr *sp = &shr[k];
+                sp->lc = lc; sp->e = e; sp->nS = 0; sp->bound = 0; sp->log0 = off; sp->cnt = cnt;
+            }
+        }
+        fail = __ballot(fail) != 0;
+        ctr.log_n = run;
+        n_shr += (uint32_t)__popcll(nm);
+    }
+    if (ctr.log_n > log_cap) fail = true;           // (log_cap < kOccMaxReads only in tests: forces the serial path)
+    if (vis.glob_dirty) visited_clear(vis, lane);
+    __threadfence();
+    if (lane == 0) {
+        sl->node = id; sl->snap = snap; sl->epoch = epoch;
+        sl->n_reads = ctr.log_n < kOccMaxReads ? ctr.log_n : kOccMaxReads;
+        sl->n_shr = n_shr; sl->top = top; sl->fail = fail ? 1u : 0u;
+        sl->planned = 1;
+        atomicAdd(&g.hdr->ctr_insert[0], (unsigned long long)ctr.n_dist);
+        atomicAdd(&g.hdr->ctr_insert[1], (unsigned long long)ctr.n_ids);
+        atomicAdd(&g.hdr->ctr_insert[2], (unsigned long long)ctr.n_expand);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -301,53 +361,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_plan(GraphView g, OccBufs ob, uin
     __threadfence();
     __syncthreads();
 
-    // ---- the shrinks the connect will trigger (core.rs:560-561): listed here, computed speculatively by
-    // k_occ_shrinks, one wave each ----
-    uint32_t n_shr = 0;
-    for (uint32_t lc1 = top + 1; lc1-- > 0 && !fail;) {
-        const uint32_t lc = lc1;
-        const uint32_t stride = lc ? g.strideU : g.stride0;
-        const uint32_t mmax = lc ? mlinks : 2 * mlinks;     // core.rs:560
-        const uint32_t *pl = pl0 + (size_t)lc * kPlanStride;
-        const uint32_t nsel = pl[0];
-        const uint32_t e = (uint32_t)lane < nsel ? pl[1 + lane] : 0u;
-        uint32_t cnt = (uint32_t)lane < nsel ? row_ptr(g, e, lc)[0] : 0u;
-        if (cnt > stride - 1) cnt = stride - 1;
-        const bool need = (uint32_t)lane < nsel && cnt + 1 > mmax;   // :561 (the row with this node appended)
-        const uint64_t nm = __ballot(need);
-        const uint32_t k = n_shr + (uint32_t)__popcll(nm & lanemask_lt(lane));
-        // log ranges: running sum of (cnt + 2) over the lanes that need a shrink, in selection order
-        uint32_t off = 0;
-        uint32_t run = ctr.log_n;
-        for (uint64_t mm = nm; mm; mm &= mm - 1) {
-            const int j = __ffsll((unsigned long long)mm) - 1;
-            const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cnt, j);
-            if (lane == j) off = run;
-            run += cj + 2;
-        }
-        if (need) {
-            if (k >= kOccMaxShr || cnt + 1 > kAuxWords) fail = true;
-            else {
-                OccShr *sp = &shr[k];
-                sp->lc = lc; sp->e = e; sp->nS = 0; sp->bound = 0; sp->log0 = off; sp->cnt = cnt;
-            }
-        }
-        fail = __ballot(fail) != 0;
-        ctr.log_n = run;
-        n_shr += (uint32_t)__popcll(nm);
-    }
-    if (ctr.log_n > log_cap) fail = true;           // (log_cap < kOccMaxReads only in tests: forces the serial path)
-    if (vis.glob_dirty) visited_clear(vis, lane);
-    __threadfence();
-    if (lane == 0) {
-        sl->node = id; sl->snap = snap; sl->epoch = epoch;
-        sl->n_reads = ctr.log_n < kOccMaxReads ? ctr.log_n : kOccMaxReads;
-        sl->n_shr = n_shr; sl->top = top; sl->fail = fail ? 1u : 0u;
-        sl->planned = 1;
-        atomicAdd(&g.hdr->ctr_insert[0], (unsigned long long)ctr.n_dist);
-        atomicAdd(&g.hdr->ctr_insert[1], (unsigned long long)ctr.n_ids);
-        atomicAdd(&g.hdr->ctr_insert[2], (unsigned long long)ctr.n_expand);
-    }
+    occ_plan_finish(g, ob, sl, shr, pl0, ctr, id, top, mlinks, log_cap, snap, epoch, fail, vis, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -482,6 +496,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
     uint32_t head = ob.ctl->head;
     uint32_t stop = OCC_STOP_NONE;
     unsigned long long n_commit = 0, n_spec = 0, n_fallback = 0, n_norec = 0;
+    unsigned long long n_cls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t nt = 0;
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long t_begin = __builtin_readcyclecounter();
@@ -595,6 +610,11 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
                     if (fail) break;
                     n_fallback += 1;
                     if (k < 0) n_norec += 1;
+                    {
+                        const uint32_t why = k >= 0 ? sc.flags[2 + k] : 0u;
+                        const int c = k < 0 ? 0 : (why & OCC_WHY_ROW) ? 1 : (why & OCC_WHY_OPEN) ? 2 : (why & OCC_WHY_REMOVE) ? 3 : 4;
+                        n_cls[c] += 1;
+                    }
                     OCC_T(5);
                 }
                 update_connections(g, m, e, erow, cnt, nS, lc, stride, maxdeg, kEmpty, nullptr, 0, nt, lane, &jr);
@@ -626,6 +646,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
         ob.ctl->n_spec += n_spec;
         ob.ctl->n_fallback += n_fallback;
         ob.ctl->n_norec += n_norec;
+        for (int i = 0; i < 8; ++i) ob.ctl->n_cls[i] += n_cls[i];
         OCC_T(6);
         prof[7] = __builtin_readcyclecounter() - t_begin;
         for (int i = 0; i < 8; ++i) ob.ctl->prof[i] += prof[i];

@@ -1,0 +1,204 @@
+// hnsw_plan_lean.hpp -- the PLAN half of HNSW.NODE.ADD (core.rs:511-531) with the specialised dim-128 search
+// routine (hnsw_search_lean.hpp) doing the descent and the per-layer search_level(ef_construction).
+//
+// A plan is one wavefront's dependent chain (~230 expansions); the general routine the insert kernels were
+// written with (search_level_v2) costs a lone wave 3.5-5.6 us per expansion, the specialised one 1.5-2.2 us
+// (DESIGN.md 4.1c).  Both produce the same W, the same work counters and -- for the exact-order parallel insert --
+// the same read log; everything after the search (select_neighbors, the node's own rows, the list of shrinks)
+// is the code of k_insert_plan / k_occ_plan.  Used when the index has the shape the specialised routine serves
+// (f32 rows of dim 128, adjacency rows of at most 127 ids, ef_construction <= 512, ids < 2^24): single
+// hnsw_add calls (the only form the Redis command can issue, src/lib.rs:356) and the windowed exact build.
+//
+// LDS: the insert kernels' carve-up (W, S, fresh, dsc, aux, the general visited table -- select_neighbors and the
+// shrinks still use it), then the specialised routine's Wbuf and its 32 KB tag table.
+#pragma once
+#include "hnsw_occ.hpp"
+#include "hnsw_search_lean.hpp"
+
+namespace hnsw {
+
+constexpr int kPlanLeanBB = 11;                       // one plan per workgroup: the largest tag table (12 288 ids before it stops recording)
+template <int R>
+constexpr size_t plan_lean_bytes() { return LeanW<R>::kBytes + ((size_t)16 << kPlanLeanBB); }
+
+template <int R, int DB, bool WIDE, bool LOG>
+struct PlanLean {
+    using VEC = VecF32<4>;
+    uint64_t *Wbuf;
+    TagSet<kPlanLeanBB, DB> ts;
+    typename VEC::Q q;
+
+    __device__ __forceinline__ void init(unsigned char *lds, uint32_t idbits, const QReg<4> &qr)
+    {
+        Wbuf = reinterpret_cast<uint64_t *>(lds);
+        ts.tab = reinterpret_cast<uint32_t *>(lds + LeanW<R>::kBytes);
+        ts.idbits = idbits;
+        ts.lcap = (1u << kPlanLeanBB) * 6u;
+        ts.count = 0;
+        ts.lossy = false;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) q.q[t] = qr.q[t];   // same pieces, same lanes (load_query / VecF32::load_q)
+    }
+    // descent step (core.rs:511-520): the nearest node of layer lc
+    __device__ __forceinline__ uint32_t nearest(const GraphView &g, uint32_t ep, uint32_t lc, WorkCtr &ctr, int lane)
+    {
+        search_level_lean<VEC, 1, kPlanLeanBB, DB, WIDE, LOG>(g, Wbuf, ts, q, ep, 1, lc, ctr, lane, &g.hdr->ctr_search[3]);
+        const uint32_t n = key_id(Wbuf[0]);
+        __builtin_amdgcn_wave_barrier();
+        return n;
+    }
+    // search_level(ef) (core.rs:524): W sorted in Wbuf[0..nW), expanded bits set
+    __device__ __forceinline__ uint32_t search(const GraphView &g, uint32_t ep, uint32_t ef, uint32_t lc, WorkCtr &ctr, int lane)
+    {
+        return search_level_lean<VEC, R, kPlanLeanBB, DB, WIDE, LOG>(g, Wbuf, ts, q, ep, ef, lc, ctr, lane, &g.hdr->ctr_search[3]);
+    }
+};
+
+// ---------------------------------------------------------------------------
+// k_insert_plan with the specialised search: one wave per new node.
+// ---------------------------------------------------------------------------
+template <int R, int DB, bool WIDE>
+__global__ __launch_bounds__(64, 1) void k_insert_plan_lean(GraphView g, uint32_t first_id, uint32_t count, uint32_t ef,
+                                                         uint32_t mlinks, uint32_t lnb, uint32_t lcap, uint32_t *__restrict__ gspill,
+                                                         uint32_t gnb, uint32_t *__restrict__ plan, uint32_t shortcut,
+                                                         uint32_t lean_off, uint32_t idbits)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    WaveMem m;
+    Visited vis;
+    carve<R, 4, true>(smem, g.dim, lnb, lcap, m, vis, g.tagcfg);
+    vis.glob = gspill + (size_t)blockIdx.x * gnb * 8;
+    vis.gnb = gnb;
+    vis.glob_dirty = false;
+    vis.spilled = false;
+    vis.count = 0;
+    vis.bounded = false;
+    vis.lossy = false;
+
+    WorkCtr ctr = {};
+    const uint32_t lmax = g.hdr->max_layer;                 // core.rs:496
+    const uint32_t ep0 = (uint32_t)g.hdr->enterpoint;       // core.rs:508
+
+    for (uint32_t s = blockIdx.x; s < count; s += gridDim.x) {
+        const uint32_t id = first_id + s;
+        const uint32_t l = g.levels[id];
+        QReg<4> qr;
+        load_query<MODE_AVX, 4>(g.vec + (size_t)id * g.dim, g.dim, qr, m.qlds, lane);
+        PlanLean<R, DB, WIDE, false> pl_;
+        pl_.init(smem + lean_off, idbits, qr);
+        m.W = pl_.Wbuf;                                     // the search leaves W there; select_* read it through m.W
+        bool fail = false;
+        uint32_t ep = ep0;
+        for (uint32_t lc = lmax; lc > l; --lc) ep = pl_.nearest(g, ep, lc, ctr, lane);   // core.rs:511-520
+        const uint32_t top = lmax < l ? lmax : l;
+        for (uint32_t lc1 = top + 1; lc1-- > 0 && !fail;) { // core.rs:523
+            const uint32_t lc = lc1;
+            const uint32_t nW = pl_.search(g, ep, ef, lc, ctr, lane);                    // :524
+            __syncthreads();
+            const uint32_t wnearest = key_id(m.W[0]);
+            const uint32_t nS = shortcut && select_is_head_of_W(ef, mlinks, nW)
+                                    ? select_head_of_W(m, nW, mlinks, lane)
+                                    : select_topm<MODE_AVX, 4>(g, m, vis, qr, m.W, nW, id, mlinks, lc, ctr, lane, fail); // :531
+            if (fail) break;
+            uint32_t *pl = plan + ((size_t)s * kMaxLayers + lc) * kPlanStride;
+            if (lane == 0) pl[0] = nS;
+            if ((uint32_t)lane < nS) pl[1 + lane] = key_id(m.S[lane]);
+            ep = wnearest;                                  // core.rs:576
+            __syncthreads();
+        }
+        if (fail && lane == 0) atomicOr(&g.hdr->status, ST_VISITED_OVERFLOW);
+    }
+    if (vis.glob_dirty) visited_clear(vis, lane);
+    if (lane == 0) {
+        atomicAdd(&g.hdr->ctr_insert[0], (unsigned long long)ctr.n_dist);
+        atomicAdd(&g.hdr->ctr_insert[1], (unsigned long long)ctr.n_ids);
+        atomicAdd(&g.hdr->ctr_insert[2], (unsigned long long)ctr.n_expand);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_occ_plan with the specialised search (read log included): one wave per window node without a valid plan.
+// ---------------------------------------------------------------------------
+template <int R, int DB, bool WIDE>
+__global__ __launch_bounds__(64, 1) void k_occ_plan_lean(GraphView g, OccBufs ob, uint32_t first_node, uint32_t count, uint32_t ef,
+                                                      uint32_t mlinks, uint32_t lnb, uint32_t lcap, uint32_t *__restrict__ gspill,
+                                                      uint32_t gnb, uint32_t *__restrict__ plan, uint32_t shortcut, uint32_t log_cap,
+                                                      uint32_t lean_off, uint32_t idbits)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const uint32_t id = first_node + blockIdx.x;
+    if (blockIdx.x >= count) return;
+    const uint32_t slot = id % ob.W;
+    OccSlot *sl = &ob.slots[slot];
+    if (sl->planned && sl->node == id) return;
+
+    WaveMem m;
+    Visited vis;
+    carve<R, 4, true>(smem, g.dim, lnb, lcap, m, vis, g.tagcfg);
+    vis.glob = gspill + (size_t)blockIdx.x * gnb * 8;
+    vis.gnb = gnb;
+    vis.glob_dirty = false;
+    vis.spilled = false;
+    vis.count = 0;
+    vis.bounded = false;
+    vis.lossy = false;
+
+    OccRead *reads = ob.reads + (size_t)slot * kOccMaxReads;
+    OccShr *shr = ob.shr + (size_t)slot * kOccMaxShr;
+    WorkCtr ctr = {};
+    ctr.log = reads;
+    ctr.log_cap = kOccMaxReads;
+    const uint32_t snap = ob.ctl->nJ, epoch = ob.ctl->epoch;
+    const uint32_t lmax = g.hdr->max_layer;                 // core.rs:496
+    const uint32_t ep0 = (uint32_t)g.hdr->enterpoint;       // core.rs:508
+    const uint32_t l = g.levels[id];
+    uint32_t *pl0 = plan + (size_t)slot * kMaxLayers * kPlanStride;
+
+    QReg<4> qr;
+    load_query<MODE_AVX, 4>(g.vec + (size_t)id * g.dim, g.dim, qr, m.qlds, lane);
+    PlanLean<R, DB, WIDE, true> pl_;
+    pl_.init(smem + lean_off, idbits, qr);
+    m.W = pl_.Wbuf;
+    bool fail = false;
+    uint32_t ep = ep0;
+    for (uint32_t lc = lmax; lc > l; --lc) ep = pl_.nearest(g, ep, lc, ctr, lane);       // core.rs:511-520
+    const uint32_t top = lmax < l ? lmax : l;
+    for (uint32_t lc1 = top + 1; lc1-- > 0 && !fail;) {     // core.rs:523
+        const uint32_t lc = lc1;
+        const uint32_t nW = pl_.search(g, ep, ef, lc, ctr, lane);                        // :524
+        __syncthreads();
+        const uint32_t wnearest = key_id(m.W[0]);
+        uint32_t nS;
+        if (shortcut && select_is_head_of_W(ef, mlinks, nW)) {
+            nS = select_head_of_W(m, nW, mlinks, lane);
+        } else {
+            // select's reads: the rows of all members of W (logged before S exists; the bound is patched in below)
+            const uint32_t sel_log0 = ctr.log_n;
+            for (uint32_t i = lane; i < nW; i += 64)
+                if (sel_log0 + i < kOccMaxReads) reads[sel_log0 + i] = OccRead{key_id(m.W[i]), occ_meta(lc, OCC_SELECT, 0, false), 0u};
+            ctr.log_n += nW;
+            nS = select_topm<MODE_AVX, 4>(g, m, vis, qr, m.W, nW, id, mlinks, lc, ctr, lane, fail); // :531
+            if (fail) break;
+            const bool sfull = nS >= mlinks;
+            const uint32_t sbound = nS ? (uint32_t)(m.S[nS - 1] >> 32) : 0u;
+            for (uint32_t i = lane; i < nW; i += 64)
+                if (sel_log0 + i < kOccMaxReads) { reads[sel_log0 + i].meta = occ_meta(lc, OCC_SELECT, 0, sfull); reads[sel_log0 + i].bound = sbound; }
+        }
+        uint32_t *pl = pl0 + (size_t)lc * kPlanStride;
+        if (lane == 0) pl[0] = nS;
+        if ((uint32_t)lane < nS) pl[1 + lane] = key_id(m.S[lane]);
+        // the node's own row: what connect_neighbors will make it (core.rs:770); nobody can reach it yet
+        uint32_t *qrow = row_ptr(g, id, lc);
+        if (lane == 0) qrow[0] = nS;
+        if ((uint32_t)lane < nS) qrow[1 + lane] = key_id(m.S[lane]);
+        ep = wnearest;                                      // core.rs:576
+        __syncthreads();
+    }
+    __threadfence();
+    __syncthreads();
+    occ_plan_finish(g, ob, sl, shr, pl0, ctr, id, top, mlinks, log_cap, snap, epoch, fail, vis, lane);
+}
+
+} // namespace hnsw

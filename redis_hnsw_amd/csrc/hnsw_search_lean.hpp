@@ -263,7 +263,9 @@ __device__ __forceinline__ uint32_t merge_regs_lean(uint64_t (&w)[R], uint64_t *
 // brought to lanes 0.. of one register (two ds_bpermute + a select per chunk), the rest is the narrow code with
 // base 0.  The reference does not bound degrees (core.rs:790-796), M = 32 rows are 112 words, and a restride can
 // widen an M = 16 index past 64: those stay on this kernel instead of falling back to the general one.
-template <class VEC, int R, int BB, int DB, bool WIDE>
+// LOG: the caller is a plan of the exact-order parallel insert (hnsw_occ.hpp) -- every expanded row goes to its
+// read log with the popped candidate's distance, turned into the row's threshold by occ_finalize_search_log.
+template <class VEC, int R, int BB, int DB, bool WIDE, bool LOG = false>
 __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64_t *Wbuf, TagSet<BB, DB> &vis,
                                                       const typename VEC::Q &qr, uint32_t ep, uint32_t ef, uint32_t lc,
                                                       WorkCtr &ctr, int lane, unsigned long long *lossy_ctr)
@@ -299,9 +301,15 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
 #pragma unroll
     for (int r = 0; r < R; ++r) pup[r] = 0;
 
+    const uint32_t log_start = ctr.log_n;
     PH_T0();
     for (;;) {
         ctr.n_expand += 1;
+        if constexpr (LOG) {
+            if (lane == 0 && ctr.log_n < ctr.log_cap)
+                ctr.log[ctr.log_n] = OccRead{key_id(ckey), occ_meta(lc, OCC_SEARCH, 0, false), (uint32_t)(ckey >> 32)};
+            ctr.log_n += 1;
+        }
         uint32_t cnt = __builtin_amdgcn_readfirstlane(word);
         PH_MARK(ctr, 0);  // waiting for the adjacency row
         if (cnt > stride - 1) cnt = stride - 1;
@@ -444,6 +452,8 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
     for (int r = 0; r < R; ++r) Wbuf[r * 64 + lane] = w[r];
     __builtin_amdgcn_wave_barrier();
     (void)ckey;
+    if constexpr (LOG) occ_finalize_search_log(ctr, log_start, lc, nW == ef ? Wbuf[ef - 1] : ~0ull, lane);
+    else (void)log_start;
     return nW;
 }
 

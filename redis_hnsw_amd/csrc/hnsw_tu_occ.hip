@@ -27,8 +27,14 @@ static hnsw_status occ_round_t(hnsw_index *h, const InsertCfg &c, const OccBufs 
     }
     const GraphView gv = view_tag(h, c.tagcfg);
     hipLaunchKernelGGL(kv, dim3(count), dim3(64), lds_val, h->stream, gv, ob, head, count);
-    hipLaunchKernelGGL(kp, dim3(count), dim3(64), c.lds, h->stream, gv, ob, head, count, h->efc, h->m, c.lnb, c.lcap, h->d_spill,
-                       h->spill_gnb, h->d_plan, h->select_shortcut ? 1u : 0u, h->occ_log_cap);
+    bool lean_plan = false;
+    if constexpr (MODE == MODE_AVX && T == 4) {
+        hnsw_status ls = launch_occ_plan_lean(h, c, ob, head, count, &lean_plan);   // the specialised search routine where the index allows it
+        if (ls != HNSW_OK) return ls;
+    }
+    if (!lean_plan)
+        hipLaunchKernelGGL(kp, dim3(count), dim3(64), c.lds, h->stream, gv, ob, head, count, h->efc, h->m, c.lnb, c.lcap, h->d_spill,
+                           h->spill_gnb, h->d_plan, h->select_shortcut ? 1u : 0u, h->occ_log_cap);
     hipLaunchKernelGGL(ks, dim3(count * kOccMaxShr), dim3(64), c.lds, h->stream, gv, ob, head, count, h->m, c.lnb, c.lcap, h->d_spill,
                        h->spill_gnb);
     hipLaunchKernelGGL(kc, dim3(1), dim3(64), lds_commit, h->stream, gv, ob, end_node, h->m, c.lnb, c.lcap, h->d_spill_one,

@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from bench import draw_levels
 from redis_hnsw_amd import Index
@@ -7,6 +7,7 @@ N, dim, M, ef = 200_000, 128, 16, 200
 V = np.random.default_rng(1).random((N + 2000, dim), dtype=np.float32)
 lv = draw_levels(N + 2000, M)
 ix = Index("p", dim, M, ef)
+if os.environ.get("PLAN_LEAN"): ix.set_tuning("plan_lean", int(os.environ["PLAN_LEAN"]))
 ix.add_batch(V[:N], levels=lv[:N], mode="fast")
 t = time.time()
 for i in range(N, N + 1000):

@@ -15,6 +15,7 @@ V = np.random.default_rng(1).random((N, dim), dtype=np.float32)
 lv = oracle.draw_levels(N, M, 7)
 gi = Index("occ", dim, M, ef)
 gi.set_tuning("occ_window", W)
+if os.environ.get("PLAN_LEAN"): gi.set_tuning("plan_lean", int(os.environ["PLAN_LEAN"]))
 if os.environ.get("OCC_AHEAD"): gi.set_tuning("occ_ahead_x10", int(os.environ["OCC_AHEAD"]))
 t = time.time(); gi.add_batch(V, levels=lv, mode="exact"); dt = time.time() - t
 lib = _capi.load()
@@ -27,6 +28,13 @@ print("N=%d dim=%d M=%d ef=%d W=%d: %.2f s = %.0f inserts/s; commits %d, spec sh
 names = ["hash", "first check", "connect", "shrink checks", "apply", "recompute", "finish/other", "total"]
 print("commit kernel, clocks per commit: " + ", ".join("%s %.0f" % (nm, out[6 + i] / nc) for i, nm in enumerate(names)), flush=True)
 print("recomputed shrinks without a speculative record: %d; row-changed flags (validate+commit): %d" % (out[14], out[15]))
+try:
+    cz = (C.c_uint64 * 8)()
+    lib.hnsw_debug_occ_causes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.hnsw_debug_occ_causes(gi._h, cz)
+    print("recomputed shrinks by first cause: no record %d, own row changed %d, pool not full %d, a relevant removal %d, a relevant addition %d" % tuple(cz[:5]))
+except AttributeError:
+    pass
 if check:
     t = time.time(); o = oracle.OracleIndex(dim, M, ef); o.add_batch(V, lv); to = time.time() - t
     ok, why = graphs_equal(o.export(), gi.export_graph())

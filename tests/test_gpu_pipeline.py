@@ -4,7 +4,7 @@ the oracle's whatever the chunking, the launch shape or the order of calls."""
 import numpy as np
 import pytest
 
-from tests.util import build_oracle, make_data
+from tests.util import build_oracle, graphs_equal, make_data
 
 pytestmark = pytest.mark.gpu
 
@@ -430,3 +430,40 @@ def test_pipelined_search_waits_for_the_lazily_filled_spill_tables(eng, oracle_m
     sc, _ = gi.counters()
     assert sc.n_spill > 0                                     # the HBM tables were really in use
     gi.close(); o.close()
+
+
+@pytest.mark.parametrize("m,ef,widen,n", [(16, 200, 0, 1500),    # C2's shape: narrow rows, W in four register slices
+                                          (16, 200, 32, 1200),   # the same index after a restride: two row words per lane
+                                          (32, 300, 0, 1000),    # M = 32 rows are wide from the start; eight slices
+                                          (5, 40, 0, 1500),      # C1's M, one slice, many layers
+                                          (8, 512, 0, 700)])     # the largest ef the specialised routine takes
+def test_insert_plans_with_the_specialised_search_build_the_reference_graph(eng, oracle_mod, m, ef, widen, n):
+    """dim-128 insert plans -- single hnsw_add calls and the windowed exact build -- search with the specialised
+    routine (hnsw_plan_lean.hpp).  The graph must be the oracle's row for row, and the plans' work counters the
+    ones the general plan kernels (plan_lean = 0) report: same W, same evaluations, same expansions."""
+    dim = 128
+    V = make_data(n, dim, seed=21)
+    lv = oracle_mod.draw_levels(n, m, 9)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch(V, lv)
+    want = o.export()
+    got_counters = []
+    for lean in (1, 0):
+        gi = eng.Index("pl%d" % lean, dim, m, ef)
+        gi.set_tuning("plan_lean", lean)
+        a, b = n // 3, 2 * n // 3
+        gi.add_batch(V[:a], levels=lv[:a], mode="exact")           # the window (read logs included)
+        if widen:
+            gi.set_tuning("force_restride", widen)
+        for i in range(a, a + 40):                                 # single adds: the serial plan kernel
+            gi.add_node("s%d" % i, V[i], level=int(lv[i]))
+        gi.add_batch(V[a + 40:b], levels=lv[a + 40:b], mode="exact")
+        gi.set_tuning("occ_window", 0)                             # the rest one by one through the batch entry point
+        gi.add_batch(V[b:], levels=lv[b:], mode="exact")
+        ok, why = graphs_equal(want, gi.export_graph())
+        assert ok, "plan_lean=%d: %s" % (lean, why)
+        _, ic = gi.counters()
+        got_counters.append((ic.n_dist + ic.n_spill, ic.n_ids, ic.n_expand))
+        gi.close()
+    assert got_counters[0] == got_counters[1]
+    o.close()
