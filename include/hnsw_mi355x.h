@@ -250,7 +250,10 @@ hnsw_status hnsw_deserialize(const void *buf, uint64_t bytes, uint64_t seed, int
  *             "lds_buckets" / "lds_hash_bits" / "tag_table" / "tag_bb" / "idbits" / "grid" (tests)
  *   build     "occ_window" (slots of the exact parallel insert, 0 = serial), "occ_min_batch",
  *             "occ_ahead_x10", "select_shortcut" (1: select_neighbors after search_level is the head
- *             of W, see csrc/hnsw_insert.hpp), "fast_seed" / "fast_batch_max" / "fast_batch_div"
+ *             of W, see csrc/hnsw_insert.hpp), "plan_lean" (1: dim-128 insert plans -- single hnsw_add
+ *             calls and the windowed exact build -- search with the specialised routine of the search
+ *             kernel, csrc/hnsw_plan_lean.hpp; same graph either way), "fast_seed" / "fast_batch_max" /
+ *             "fast_batch_div"
  *   storage   "compress_bf16" / "compress_fp8" (one way: 2 / 1 bytes per component in the gather, the index becomes
  *             read-only; results are the reference's on the stored, rounded values; any dim % 32 == 0),
  *             "force_restride" (tests)                                                              */

@@ -581,7 +581,7 @@ __device__ __forceinline__ int find_unexpanded(const uint64_t *W, uint32_t nW, i
     return -1;
 }
 
-constexpr uint32_t kAuxWords = 512; // insert scratch: one adjacency row (degree <= 511)
+constexpr uint32_t kAuxWords = 1024; // insert scratch: one adjacency row (degree <= 1023; the reference does not bound degrees, core.rs:790-796)
 constexpr uint32_t kSelMax = 128;   // select_neighbors result: m_max0 = 2M ids at most (M <= 64)
 
 // LDS carve-up.  Search: [W: R*64*8][fresh: 64*4][dsc: 64*4][qlds (T==0)][hash: nb*32].

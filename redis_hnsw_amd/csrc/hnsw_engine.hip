@@ -1232,7 +1232,7 @@ hnsw_status hnsw_import(hnsw_index *h, uint32_t n, const float *vectors, const u
             if (row_ptr[l][i + 1] < row_ptr[l][i]) return fail(h, HNSW_ERR_INVALID, "row_ptr is not monotonic");
             uint64_t d = row_ptr[l][i + 1] - row_ptr[l][i];
             if (d > 0 && levels[i] < l) return fail(h, HNSW_ERR_INVALID, "node has links above its level");
-            if (d > kAuxWords - 2) return fail(h, HNSW_ERR_INVALID, "degree > 510 is not supported");
+            if (d > kAuxWords - 2) return fail(h, HNSW_ERR_INVALID, "degree > 1022 is not supported");
             for (uint64_t e = row_ptr[l][i]; e < row_ptr[l][i + 1]; ++e) {
                 if (col[l][e] >= n || col[l][e] == i) return fail(h, HNSW_ERR_INVALID, "neighbour id out of range (or a self link)");
                 if (levels[col[l][e]] < l) return fail(h, HNSW_ERR_INVALID, "link to a node that does not reach this layer");

@@ -360,3 +360,77 @@ def test_inserts_wait_for_searches_in_flight_on_other_streams(eng, oracle_mod):
     ok, why = graphs_equal(o.export(), gi.export_graph())
     assert ok, why
     gi.close()
+
+
+def _with_hub(g, hub, spokes):
+    """layer-0 CSR of g with `hub` linked to every node of `spokes` it is not linked to yet (both directions,
+    appended to the stored rows -- what core.rs:794 does to third parties, many times over)"""
+    rp, col = g["row_ptr"][0].astype(np.int64), g["col"][0]
+    rows = [list(col[rp[i]:rp[i + 1]]) for i in range(len(rp) - 1)]
+    have = set(rows[hub])
+    for s in spokes:
+        if s != hub and s not in have:
+            rows[hub].append(int(s))
+            rows[s].append(int(hub))
+            have.add(s)
+    out = dict(g)
+    out["row_ptr"] = [np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.uint64)] + list(g["row_ptr"][1:])
+    out["col"] = [np.array([x for r in rows for x in r], dtype=np.uint32)] + list(g["col"][1:])
+    return out, len(rows[hub])
+
+
+@pytest.mark.parametrize("dim,m,ef,spokes", [(32, 8, 40, 700), (128, 16, 200, 900), (12, 5, 24, 600)])
+def test_a_hub_of_several_hundred_links_is_searched_shrunk_and_deleted_like_the_oracle(eng, oracle_mod, dim, m, ef, spokes):
+    """The reference does not bound degrees (core.rs:790-796 appends to third parties without a shrink).
+    Rows hold up to 1023 ids: an imported hub far beyond m_max0 is searched with the oracle's counters, shrunk back
+    to m_max0 by the first insert that selects it (select_neighbors over all its links, every dropped link removed
+    from the other side), and can be deleted -- graphs equal after every step."""
+    n, k = 1500, 10
+    V = make_data(n, dim, seed=31)
+    lv = oracle_mod.draw_levels(n, m, 3)
+    o0 = oracle_mod.OracleIndex(dim, m, ef)
+    o0.add_batch(V, lv)
+    g, deg = _with_hub(o0.export(), 5, range(100, 100 + spokes))
+    o0.close()
+    assert deg >= spokes
+    o = oracle_mod.OracleIndex.from_graph(dim, m, ef, g)
+    gi = eng.Index("hub", dim, m, ef)
+    gi.import_graph(g)
+    assert gi.info().max_degree0 == deg and gi.info().stride0 > deg
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    Q = np.concatenate([make_data(60, dim, seed=32), V[5:6] + 1e-3, V[100:140] + 1e-3]).astype(np.float32)
+    gi.reset_counters()
+    ids, sims, n_out = gi.search_batch(Q, k)
+    oids, osims, on, oct = o.search_batch(Q, k)
+    assert np.array_equal(ids, oids) and np.array_equal(_bits(sims), _bits(osims)) and np.array_equal(n_out, on)
+    sc, _ = gi.counters()
+    assert (sc.n_ids, sc.n_expand) == (oct.n_ids, oct.n_expand)
+    # a spoke goes first (the hub re-selects nothing: it is only a neighbour of the deleted node), then inserts
+    # next to the hub: the first one that links to it shrinks its row
+    o.delete(150)
+    gi.delete_node("node150")
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, "after deleting a spoke: " + why
+    rng = np.random.default_rng(33)
+    near = (V[5][None, :] + 0.01 * rng.standard_normal((12, dim))).astype(np.float32)
+    for i in range(6):
+        o.add(near[i], 0)
+        gi.add_node("near%d" % i, near[i], level=0)
+        ok, why = graphs_equal(o.export(), gi.export_graph())
+        assert ok, "after insert %d next to the hub: %s" % (i, why)
+    go = o.export()
+    assert int(go["row_ptr"][0][6] - go["row_ptr"][0][5]) <= 2 * m + 1      # the hub was shrunk (core.rs:560-569)
+    lvb = np.zeros(6, dtype=np.int32)
+    o.add_batch(near[6:], lvb)                                             # and through the window
+    gi.add_batch(near[6:], levels=lvb, mode="exact")
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, "after the windowed inserts: " + why
+    o.delete(5)
+    gi.delete_node("node5")
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, "after deleting the hub: " + why
+    ids, sims, n_out = gi.search_batch(Q, k)
+    oids, osims, on, _ = o.search_batch(Q, k)
+    assert np.array_equal(ids, oids) and np.array_equal(_bits(sims), _bits(osims)) and np.array_equal(n_out, on)
+    gi.close(); o.close()
