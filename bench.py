@@ -608,6 +608,7 @@ def main():
         ifast.close()
         log("fast GPU build: %.2f s, recall@10 %.4f" % (tfb, fast_build["recall_at_10"]))
     exact_build = None
+    single_add = None
     if cfg_is_c2 and extras and world == 1:
         # the reference-order build (hnsw_add_batch mode 0: plans in parallel, validated in-order commits) on a
         # bounded prefix, CHECKED row for row against the oracle's serial build of the same prefix (committed
@@ -633,6 +634,33 @@ def main():
                            checked_against=why,
                            note="hnsw_add_batch mode 0 on the first 50 k nodes (the rate grows with the index; the whole 1 M "
                                 "build: profiles/r3_c5_exact_build_1m.json)")
+        # HNSW.NODE.ADD as the Redis command issues it (src/lib.rs:356: one add_node per call): single hnsw_add
+        # calls on that index, timed, then CHECKED against the oracle making the same inserts on the same graph
+        if identical:
+            NA = 200
+            extra_v = np.random.default_rng(11).random((NA, dim), dtype=np.float32)
+            extra_l = draw_levels(NA, M, 13)
+            ta = time.time()
+            for i in range(NA):
+                ie.add_node("single%d" % i, extra_v[i], level=int(extra_l[i]))
+            ta = (time.time() - ta) / NA
+            from oracle import oracle as _orc                # checker only, after the timed region
+            want["vectors"] = V[:NE]
+            oa = _orc.OracleIndex.from_graph(dim, M, ef, want)
+            tc = time.time()
+            for i in range(NA):
+                oa.add(extra_v[i], int(extra_l[i]))
+            tc = (time.time() - tc) / NA
+            ga, gb = oa.export(), ie.export_graph()
+            same = (ga["enterpoint"] == gb["enterpoint"] and np.array_equal(ga["levels"], gb["levels"])
+                    and all(np.array_equal(a_, b_) for a_, b_ in zip(ga["row_ptr"], gb["row_ptr"]))
+                    and all(np.array_equal(a_, b_) for a_, b_ in zip(ga["col"], gb["col"])))
+            if not same:
+                raise SystemExit("single_add: the graph after %d hnsw_add calls differs from the oracle's" % NA)
+            single_add = dict(workload="HNSW.NODE.ADD: %d single hnsw_add calls (host vectors) on the %d-node reference-order index" % (NA, NE),
+                              gpu_ms=round(1e3 * ta, 3), cpu_oracle_ms=round(1e3 * tc, 3), identical=True)
+            oa.close()
+            log("single hnsw_add: %.3f ms per call (CPU oracle %.3f ms), graphs identical" % (1e3 * ta, 1e3 * tc))
         ie.close()
         log("exact GPU build of %d nodes: %.1f s, identical to the oracle's: %s" % (NE, te, identical))
     if cfg_is_c2 and extras and not args.no_clustered:
@@ -901,7 +929,7 @@ def main():
         "recall_at_%d" % k: None if recall is None else round(recall, 4),
         "build_seconds": None if t_build is None else round(t_build, 2),
         "host_buffers_qps": round(host_qps, 1), "host_buffers": host, "single_process_group": group_leg, "device_call": dev_calls,
-        "gpu_fast_build": fast_build, "gpu_exact_build": exact_build,
+        "gpu_fast_build": fast_build, "gpu_exact_build": exact_build, "single_add": single_add,
         "clustered": clus,
         "bf16_storage_mode": bf16, "fp8_storage_mode": fp8,
         "c1_single_query": c1,

@@ -879,6 +879,7 @@ void hnsw_destroy(hnsw_index *h)
     (void)hipFree(h->d_vec); (void)hipFree(h->d_adj0); (void)hipFree(h->d_adjU);
     (void)hipFree(h->d_upper_base); (void)hipFree(h->d_levels); (void)hipFree(h->d_hdr);
     (void)hipFree(h->d_spill); (void)hipFree(h->d_spill_one); (void)hipFree(h->d_Q); (void)hipFree(h->d_res);
+    if (h->h_ins) (void)hipHostFree(h->h_ins);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
     for (uint32_t l = 0; l < hnsw_index::kPipe; ++l) {
         if (h->pipe_st[l]) { (void)hipStreamSynchronize(h->pipe_st[l]); (void)hipStreamDestroy(h->pipe_st[l]); }
@@ -992,8 +993,13 @@ hnsw_status hnsw_add(hnsw_index *h, const float *v, uint32_t dim, int32_t level,
         if (nt > h->touched_cap) return fail(h, HNSW_ERR_CAPACITY, "update_fn list overflow (the insert itself is complete)");
         uint32_t have = std::min(nt, h->touched_cap);
         std::vector<uint32_t> tmp(have);
-        HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->d_touched, (size_t)have * 4, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (h->h_ins && have <= h->ins_touched_have) {           // it came back with the header (add_exact)
+            const uint32_t *tp = h->h_ins + h->ins_dim_words + (uint32_t)((sizeof(hnsw::DevHeader) + 3) / 4);
+            std::copy(tp, tp + have, tmp.begin());
+        } else {
+            HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->d_touched, (size_t)have * 4, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+        }
         std::sort(tmp.begin(), tmp.end());
         tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
         nt = (uint32_t)tmp.size();

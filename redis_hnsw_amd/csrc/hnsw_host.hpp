@@ -82,6 +82,12 @@ struct hnsw_index {
     uint32_t plan_slots = 0;
     uint32_t *d_touched = nullptr;  // exact insert touched list
     uint32_t touched_cap = 0;
+    // single hnsw_add: pinned staging for the vector going in and the header + the head of the touched list coming
+    // back (one stream synchronisation per call instead of pageable copies that each wait)
+    static constexpr uint32_t kInsTouched = 4096;
+    uint32_t *h_ins = nullptr;      // [dim floats][DevHeader][kInsTouched ids]
+    uint32_t ins_dim_words = 0;
+    uint32_t ins_touched_have = 0;  // ids of the last insert's touched list already on the host
     uint32_t *d_work = nullptr;     // fast build: shrink worklist
     // exact-order parallel insert (hnsw_occ.hpp)
     hnsw::OccSlot *d_occ_slots = nullptr;
