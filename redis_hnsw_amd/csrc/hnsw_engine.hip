@@ -954,6 +954,7 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
     }
     if (!std::strcmp(key, "select_shortcut")) { h->select_shortcut = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "plan_lean")) { h->plan_lean = value != 0; return HNSW_OK; }
+    if (!std::strcmp(key, "single_window")) { h->single_window = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "occ_window")) { h->occ_window = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), kOccMaxW); return HNSW_OK; }
     if (!std::strcmp(key, "occ_ahead_x10")) { h->occ_ahead_x10 = (uint32_t)std::max<int64_t>(value, 5); return HNSW_OK; }
     if (!std::strcmp(key, "occ_slack_extra")) { h->occ_slack_extra = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 64); return HNSW_OK; }
@@ -994,7 +995,7 @@ hnsw_status hnsw_add(hnsw_index *h, const float *v, uint32_t dim, int32_t level,
         uint32_t have = std::min(nt, h->touched_cap);
         std::vector<uint32_t> tmp(have);
         if (h->h_ins && have <= h->ins_touched_have) {           // it came back with the header (add_exact)
-            const uint32_t *tp = h->h_ins + h->ins_dim_words + (uint32_t)((sizeof(hnsw::DevHeader) + 3) / 4);
+            const uint32_t *tp = h->h_ins + ins_touched_off(h);
             std::copy(tp, tp + have, tmp.begin());
         } else {
             HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->d_touched, (size_t)have * 4, hipMemcpyDeviceToHost, h->stream));

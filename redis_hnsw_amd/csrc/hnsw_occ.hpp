@@ -35,7 +35,7 @@ constexpr uint32_t kOccMaxHits = 1024;      // (reader, z) pairs whose distance 
 
 struct OccShr {
     uint32_t lc, e, nS, bound;              // bound = distance bits of the last selected; nS = 0: not computed yet
-    uint32_t log0, cnt, pad0, pad1;         // its read-log range starts at log0: 1 + cnt + 1 entries (row e, its members, this node)
+    uint32_t log0, cnt, w_dist, w_ids;      // its read-log range starts at log0: 1 + cnt + 1 entries (row e, its members, this node); w_*: evaluations / ids scanned computing it
     uint32_t S[kSelMax];                    // selected ids, nearest first (up to m_max0 = 2M)
 };
 struct OccSlot {
@@ -416,9 +416,12 @@ __global__ __launch_bounds__(64, 1) void k_occ_shrinks(GraphView g, OccBufs ob, 
         nE = merge_sorted<R>(m.W, nE, R * 64, key, have, lane);
     }
     WorkCtr nolog = {};
+    nolog.n_dist = tot;                                      // the econn evaluations (core.rs:550)
+    nolog.n_ids = tot;
     const uint32_t nS = select_topm<MODE, T>(g, m, vis, qe, m.W, nE, e, mmax, lc, nolog, lane, fail); // :568
     if (vis.glob_dirty) visited_clear(vis, lane);
     if (fail || nS == 0) { if (lane == 0) sl->fail = 1; return; }
+    if (lane == 0) { sp->w_dist = nolog.n_dist; sp->w_ids = nolog.n_ids; }
     const uint32_t bound = (uint32_t)(m.S[nS - 1] >> 32);
     for (uint32_t i = lane; i < nS; i += 64) sp->S[i] = key_id(m.S[i]);
     // reads: row e itself, and the rows of econn's members
@@ -471,7 +474,8 @@ __global__ __launch_bounds__(64, 1) void k_occ_validate(GraphView g, OccBufs ob,
 template <int MODE, int T, int R>
 __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, uint32_t end_node, uint32_t mlinks, uint32_t lnb,
                                                    uint32_t lcap, uint32_t *__restrict__ gspill, uint32_t gnb,
-                                                   const uint32_t *__restrict__ plan, uint32_t slack)
+                                                   const uint32_t *__restrict__ plan, uint32_t slack,
+                                                   uint32_t *__restrict__ touched, uint32_t touched_cap)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -497,6 +501,8 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
     uint32_t stop = OCC_STOP_NONE;
     unsigned long long n_commit = 0, n_spec = 0, n_fallback = 0, n_norec = 0;
     unsigned long long n_cls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long w_dist = 0, w_ids = 0, w_skipped = 0;   // the shrink loop's work: evaluations made (speculative results
+                                                               // that were used + recomputations), econn evaluations skipped (:561)
     uint32_t nt = 0;
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long t_begin = __builtin_readcyclecounter();
@@ -556,6 +562,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
                 else { nrow[1 + c] = id; nrow[0] = c + 1; atomicMax(maxdeg, c + 1); }
             }
             if (lane == 0) atomicMax(maxdeg, nsel);
+            touch_push(touched, touched_cap, nt, myselid, touched != nullptr && (uint32_t)lane < nsel, lane);   // :535-537
             journal_push(&jr, (uint32_t)lane < nsel, myselid, lc, id, true, lane);
             fence_own_writes();
             __syncthreads();
@@ -566,7 +573,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
                 uint32_t *erow = row_ptr(g, e, lc);
                 uint32_t cnt = erow[0];
                 if (cnt > stride - 1) cnt = stride - 1;
-                if (cnt <= mmax) continue;                  // :561
+                if (cnt <= mmax) { w_skipped += cnt; continue; }   // :561
                 // the speculative result, if nothing relevant happened since it was planned
                 int k = -1;
                 {
@@ -589,6 +596,8 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
                     if (64u + (uint32_t)lane < nS) m.S[64 + lane] = (uint64_t)sv2 << 1;
                     __syncthreads();
                     n_spec += 1;
+                    w_dist += shr[k].w_dist;
+                    w_ids += shr[k].w_ids;
                 } else {
                     // recompute on the spot (core.rs:544-568)
                     QReg<T> qe;
@@ -608,6 +617,8 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
                     WorkCtr nolog = {};
                     nS = select_topm<MODE, T>(g, m, vis, qe, m.W, nE, e, mmax, lc, nolog, lane, fail);
                     if (fail) break;
+                    w_dist += cnt + nolog.n_dist;
+                    w_ids += cnt + nolog.n_ids;
                     n_fallback += 1;
                     if (k < 0) n_norec += 1;
                     {
@@ -617,7 +628,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
                     }
                     OCC_T(5);
                 }
-                update_connections(g, m, e, erow, cnt, nS, lc, stride, maxdeg, kEmpty, nullptr, 0, nt, lane, &jr);
+                update_connections(g, m, e, erow, cnt, nS, lc, stride, maxdeg, kEmpty, touched, touched_cap, nt, lane, &jr);
                 OCC_T(4);
             }
         }
@@ -647,6 +658,10 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
         ob.ctl->n_fallback += n_fallback;
         ob.ctl->n_norec += n_norec;
         for (int i = 0; i < 8; ++i) ob.ctl->n_cls[i] += n_cls[i];
+        if (touched) g.hdr->n_touched = nt;
+        atomicAdd(&g.hdr->ctr_insert[0], w_dist);
+        atomicAdd(&g.hdr->ctr_insert[1], w_ids);
+        atomicAdd(&g.hdr->ctr_insert[3], w_skipped);
         OCC_T(6);
         prof[7] = __builtin_readcyclecounter() - t_begin;
         for (int i = 0; i < 8; ++i) ob.ctl->prof[i] += prof[i];

@@ -38,7 +38,8 @@ static hnsw_status occ_round_t(hnsw_index *h, const InsertCfg &c, const OccBufs 
     hipLaunchKernelGGL(ks, dim3(count * kOccMaxShr), dim3(64), c.lds, h->stream, gv, ob, head, count, h->m, c.lnb, c.lcap, h->d_spill,
                        h->spill_gnb);
     hipLaunchKernelGGL(kc, dim3(1), dim3(64), lds_commit, h->stream, gv, ob, end_node, h->m, c.lnb, c.lcap, h->d_spill_one,
-                       h->spill_one_gnb, h->d_plan, h->m + 2 + h->occ_slack_extra);
+                       h->spill_one_gnb, h->d_plan, h->m + 2 + h->occ_slack_extra, h->occ_want_touched ? h->d_touched : nullptr,
+                       h->occ_want_touched ? h->touched_cap : 0u);
     HIP_TRY(h, hipGetLastError());
     return HNSW_OK;
 }

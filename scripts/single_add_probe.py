@@ -1,0 +1,24 @@
+"""HNSW.NODE.ADD one node per call: the serial kernels (hnsw_add) against a one-node window (hnsw_add_batch with
+occ_min_batch = 1: plan, speculative shrinks in parallel, validated commit).  python scripts/single_add_probe.py [N]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from bench import draw_levels
+from redis_hnsw_amd import Index
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
+dim, M, ef = 128, 16, 200
+V = np.random.default_rng(1).random((N + 1000, dim), dtype=np.float32)
+lv = draw_levels(N + 1000, M)
+ix = Index("p", dim, M, ef)
+ix.add_batch(V[:N], levels=lv[:N], mode="fast")
+t = time.time()
+for i in range(N, N + 500):
+    ix.add_node("n%d" % i, V[i], level=int(lv[i]))
+dt = (time.time() - t) / 500
+print("hnsw_add (serial kernels) at %d nodes: %.3f ms per insert" % (N, 1e3 * dt))
+ix.set_tuning("occ_min_batch", 1)
+t = time.time()
+for i in range(N + 500, N + 1000):
+    ix.add_batch(V[i:i + 1], levels=lv[i:i + 1], mode="exact")
+dt = (time.time() - t) / 500
+print("hnsw_add_batch of one node through the window: %.3f ms per insert" % (1e3 * dt))

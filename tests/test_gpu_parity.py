@@ -342,13 +342,18 @@ def test_errors_match_reference(eng):
 
 
 # ---- exact insert: link-for-link identical graphs ---------------------------------
+@pytest.mark.parametrize("single_window", [1, 0])
 @pytest.mark.parametrize("n,dim,m,ef", [(400, 32, 5, 16), (700, 128, 16, 200), (300, 4, 5, 16), (500, 64, 6, 40)])
-def test_exact_insert_builds_identical_graph(eng, oracle_mod, n, dim, m, ef):
+def test_exact_insert_builds_identical_graph(eng, oracle_mod, n, dim, m, ef, single_window):
+    """single hnsw_add calls: as a one-node window (the default: plan, speculative shrinks in parallel, validated
+    commit) and through the serial kernels -- same graph, same update_fn sets; the serial kernels' work counters
+    are the reference's evaluation counts"""
     V = make_data(n, dim, seed=11)
     lv = oracle_mod.draw_levels(n, m, 5)
     o = oracle_mod.OracleIndex(dim, m, ef)
     gi = eng.Index("foo", dim, m, ef)
     gi.set_tuning("select_shortcut", 0)     # the full select_neighbors extension: its evaluations are the reference's
+    gi.set_tuning("single_window", single_window)
     for i in range(n):
         if i % 7 == 0:   # compare the touched sets on a sample
             oid, ot = o.add(V[i], int(lv[i]), want_touched=True)
@@ -360,10 +365,14 @@ def test_exact_insert_builds_identical_graph(eng, oracle_mod, n, dim, m, ef):
             gi.add_node("node%d" % i, V[i], level=int(lv[i]))
     ok, why = graphs_equal(o.export(), gi.export_graph())
     assert ok, why
-    # the work accounting matches too: evaluations done + the econn evaluations skipped
+    # the work accounting matches too: evaluations done + the econn evaluations skipped (the window counts the work
+    # it did -- speculative shrinks see the rows of the snapshot, so their pools can differ by irrelevant ids)
     _, ic = gi.counters()
     oc = o.insert_counters()
-    assert ic.n_dist + ic.n_spill == oc.n_dist
+    if not single_window:
+        assert ic.n_dist + ic.n_spill == oc.n_dist
+    else:
+        assert 0.9 * oc.n_dist <= ic.n_dist + ic.n_spill <= 1.3 * oc.n_dist
     gi.close()
 
 
