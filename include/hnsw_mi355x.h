@@ -252,7 +252,9 @@ hnsw_status hnsw_deserialize(const void *buf, uint64_t bytes, uint64_t seed, int
  *             "occ_ahead_x10", "select_shortcut" (1: select_neighbors after search_level is the head
  *             of W, see csrc/hnsw_insert.hpp), "plan_lean" (1: dim-128 insert plans -- single hnsw_add
  *             calls and the windowed exact build -- search with the specialised routine of the search
- *             kernel, csrc/hnsw_plan_lean.hpp; same graph either way), "fast_seed" / "fast_batch_max" /
+ *             kernel, csrc/hnsw_plan_lean.hpp; same graph either way), "single_window" (1: a single hnsw_add
+ *             runs as a one-node window -- its shrinks computed in parallel, then validated -- instead of
+ *             the serial kernels; same graph and update_fn list), "fast_seed" / "fast_batch_max" /
  *             "fast_batch_div"
  *   storage   "compress_bf16" / "compress_fp8" (one way: 2 / 1 bytes per component in the gather, the index becomes
  *             read-only; results are the reference's on the stored, rounded values; any dim % 32 == 0),

@@ -95,6 +95,7 @@ struct hnsw_index {
     hnsw::OccShr *d_occ_shr = nullptr;
     hnsw::OccDelta *d_occ_ring = nullptr;
     hnsw::OccCtl *d_occ_ctl = nullptr;
+    bool occ_fresh_slots = false;   // the round about to be launched starts from cleared slots (single hnsw_add)
     bool occ_want_touched = false;  // the commit kernel records the update_fn list (a single hnsw_add through a one-node window)
     bool single_window = true;      // tuning: a single hnsw_add runs as a one-node window (speculative shrinks in parallel) instead of the serial kernels
     uint32_t occ_window = 32;       // tuning: window slots (0 = the serial path only)

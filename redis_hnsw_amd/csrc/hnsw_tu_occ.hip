@@ -26,7 +26,8 @@ static hnsw_status occ_round_t(hnsw_index *h, const InsertCfg &c, const OccBufs 
         }
     }
     const GraphView gv = view_tag(h, c.tagcfg);
-    hipLaunchKernelGGL(kv, dim3(count), dim3(64), lds_val, h->stream, gv, ob, head, count);
+    if (!h->occ_fresh_slots)                              // a one-node window starts from cleared slots: nothing to validate
+        hipLaunchKernelGGL(kv, dim3(count), dim3(64), lds_val, h->stream, gv, ob, head, count);
     bool lean_plan = false;
     if constexpr (MODE == MODE_AVX && T == 4) {
         hnsw_status ls = launch_occ_plan_lean(h, c, ob, head, count, &lean_plan);   // the specialised search routine where the index allows it
