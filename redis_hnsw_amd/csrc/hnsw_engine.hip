@@ -546,7 +546,6 @@ hnsw_status ensure_pipe(hnsw_index *h)
         HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_done[l], hipEventDisableTiming));
     }
     HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_done[0], hipEventDisableTiming));
-    for (uint32_t sl = 0; sl < hnsw_index::kPipeSlots; ++sl) HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_slot_done[sl], hipEventDisableTiming));
     HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_fork, hipEventDisableTiming));
     float ratio = 0.f;
     hnsw_status s = pipe_probe(h, &ratio);
@@ -586,8 +585,9 @@ hnsw_status ensure_pipe_stage(hnsw_index *h, uint32_t chunk, uint32_t k)
     const size_t nq = (size_t)chunk * h->dim, nr = 2 * (size_t)chunk * k + chunk;
     if (nq <= h->pipe_q_words && nr <= h->pipe_r_words) return HNSW_OK;
     const size_t wq = std::max(nq, h->pipe_q_words), wr = std::max(nr, h->pipe_r_words);
-    for (uint32_t l = 0; l < hnsw_index::kPipe; ++l) HIP_TRY(h, hipStreamSynchronize(l == 0 ? h->stream : h->pipe_st[l]));
-    for (uint32_t l = 0; l < hnsw_index::kPipeSlots; ++l) {
+    for (uint32_t l = 0; l < hnsw_index::kPipe; ++l) {
+        hipStream_t st = l == 0 ? h->stream : h->pipe_st[l];
+        HIP_TRY(h, hipStreamSynchronize(st));
         dev_free(h, h->pipe_dq[l], h->pipe_q_words);
         dev_free(h, h->pipe_dres[l], h->pipe_r_words);
         if (h->pipe_hq[l]) (void)hipHostFree(h->pipe_hq[l]);
@@ -596,7 +596,7 @@ hnsw_status ensure_pipe_stage(hnsw_index *h, uint32_t chunk, uint32_t k)
     }
     h->pipe_q_words = h->pipe_r_words = 0;
     hnsw_status s;
-    for (uint32_t l = 0; l < hnsw_index::kPipeSlots; ++l) {
+    for (uint32_t l = 0; l < hnsw_index::kPipe; ++l) {
         if ((s = dev_alloc(h, &h->pipe_dq[l], wq)) != HNSW_OK || (s = dev_alloc(h, &h->pipe_dres[l], wr)) != HNSW_OK) return s;
         HIP_TRY(h, hipHostMalloc((void **)&h->pipe_hq[l], wq * 4, hipHostMallocDefault));
         HIP_TRY(h, hipHostMalloc((void **)&h->pipe_hres[l], wr * 4, hipHostMallocDefault));
@@ -669,13 +669,12 @@ hnsw_status search_batch_pipelined(hnsw_index *h, const float *Q, uint32_t B, ui
     auto tr = [&](const char *what, uint32_t c) {
         if (trace) fprintf(stderr, "[pipe %8.1f us] %s %u\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count(), what, c);
     };
-    constexpr uint32_t kSlots = hnsw_index::kPipeSlots;
     auto collect = [&](uint32_t c) -> hnsw_status {       // chunk c's results: pinned -> the caller's buffers
-        const uint32_t sl = c % kSlots, off = c * per, cb = std::min(per, B - off);
+        const uint32_t l = c % hnsw_index::kPipe, off = c * per, cb = std::min(per, B - off);
         tr("wait", c);
-        HIP_TRY(h, hipEventSynchronize(h->pipe_slot_done[sl]));
+        HIP_TRY(h, hipEventSynchronize(h->pipe_done[l]));
         tr("done", c);
-        const uint32_t *r = h->pipe_hres[sl];
+        const uint32_t *r = h->pipe_hres[l];
         const size_t nk = (size_t)cb * k;
         std::memcpy(ids + (size_t)off * k, r, nk * 4);
         std::memcpy(sims + (size_t)off * k, r + nk, nk * 4);
@@ -684,30 +683,28 @@ hnsw_status search_batch_pipelined(hnsw_index *h, const float *Q, uint32_t B, ui
         return HNSW_OK;
     };
     for (uint32_t c = 0; c < nch; ++c) {
-        // chunk c runs on lane c % kPipe and stages through slot c % kSlots: a lane's next chunk is staged and enqueued
-        // while its previous one runs; a slot is reused once the chunk that used it has been collected
-        const uint32_t l = c % hnsw_index::kPipe, sl = c % kSlots, off = c * per, cb = std::min(per, B - off);
-        if (c >= kSlots && (s = collect(c - kSlots)) != HNSW_OK) return s;   // frees the slot's staging
+        const uint32_t l = c % hnsw_index::kPipe, off = c * per, cb = std::min(per, B - off);
+        if (c >= hnsw_index::kPipe && (s = collect(c - hnsw_index::kPipe)) != HNSW_OK) return s;   // frees lane l's staging
         const size_t nq = (size_t)cb * h->dim, nk = (size_t)cb * k;
         tr("stage", c);
-        if (!copy_finite(h->pipe_hq[sl], Q + (size_t)off * h->dim, nq)) {
+        if (!copy_finite(h->pipe_hq[l], Q + (size_t)off * h->dim, nq)) {
             for (uint32_t d = 0; d < lanes; ++d) (void)hipStreamSynchronize(lane_st(d));
             return fail(h, HNSW_ERR_INVALID, "non-finite query component");
         }
         hipStream_t st = lane_st(l);
         tr("enqueue", c);
-        HIP_TRY(h, hipMemcpyAsync(h->pipe_dq[sl], h->pipe_hq[sl], nq * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(h, hipMemcpyAsync(h->pipe_dq[l], h->pipe_hq[l], nq * 4, hipMemcpyHostToDevice, st));
         tr("h2d", c);
-        uint32_t *d_ids = h->pipe_dres[sl], *d_nout = h->pipe_dres[sl] + 2 * nk;
-        float *d_sims = reinterpret_cast<float *>(h->pipe_dres[sl] + nk);
-        if ((s = launch_search(h, h->pipe_dq[sl], cb, k, d_ids, d_sims, d_nout, st)) != HNSW_OK) return s;
+        uint32_t *d_ids = h->pipe_dres[l], *d_nout = h->pipe_dres[l] + 2 * nk;
+        float *d_sims = reinterpret_cast<float *>(h->pipe_dres[l] + nk);
+        if ((s = launch_search(h, h->pipe_dq[l], cb, k, d_ids, d_sims, d_nout, st)) != HNSW_OK) return s;
         tr("launched", c);
-        HIP_TRY(h, hipMemcpyAsync(h->pipe_hres[sl], h->pipe_dres[sl], (2 * nk + cb) * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipMemcpyAsync(h->pipe_hres[l], h->pipe_dres[l], (2 * nk + cb) * 4, hipMemcpyDeviceToHost, st));
         tr("d2h", c);
-        HIP_TRY(h, hipEventRecord(h->pipe_slot_done[sl], st));
+        HIP_TRY(h, hipEventRecord(h->pipe_done[l], st));
         tr("enqueued", c);
     }
-    for (uint32_t c = nch > kSlots ? nch - kSlots : 0; c < nch; ++c)
+    for (uint32_t c = nch > hnsw_index::kPipe ? nch - hnsw_index::kPipe : 0; c < nch; ++c)
         if ((s = collect(c)) != HNSW_OK) return s;
     if (overflow) return fail(h, HNSW_ERR_CAPACITY, "visited-set spill table overflow");
     return HNSW_OK;
@@ -887,9 +884,6 @@ void hnsw_destroy(hnsw_index *h)
     for (uint32_t l = 0; l < hnsw_index::kPipe; ++l) {
         if (h->pipe_st[l]) { (void)hipStreamSynchronize(h->pipe_st[l]); (void)hipStreamDestroy(h->pipe_st[l]); }
         if (h->pipe_done[l]) (void)hipEventDestroy(h->pipe_done[l]);
-    }
-    for (uint32_t l = 0; l < hnsw_index::kPipeSlots; ++l) {
-        if (h->pipe_slot_done[l]) (void)hipEventDestroy(h->pipe_slot_done[l]);
         (void)hipFree(h->pipe_dq[l]); (void)hipFree(h->pipe_dres[l]);
         if (h->pipe_hq[l]) (void)hipHostFree(h->pipe_hq[l]);
         if (h->pipe_hres[l]) (void)hipHostFree(h->pipe_hres[l]);

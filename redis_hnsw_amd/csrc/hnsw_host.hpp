@@ -57,25 +57,14 @@ struct hnsw_index {
     uint32_t spill_rr = 0;
     // ---- the search pipeline (hnsw_search_batch / hnsw_search_batch_device): kPipe engine-owned streams,
     // each with its own staging (device queries + results, pinned host mirrors) and fork / join events
-#ifndef HNSW_PIPE_LANES
-#define HNSW_PIPE_LANES 3
-#endif
-    static constexpr uint32_t kPipe = HNSW_PIPE_LANES;
-#ifndef HNSW_PIPE_DEPTH
-#define HNSW_PIPE_DEPTH 2
-#endif
-    // host-buffer form: staging slots per lane -- with two, the host stages and enqueues a lane's next chunk while
-    // its previous one still runs (with one, the lane idles from the end of a chunk until the host has copied its
-    // results out, staged the next queries and enqueued them)
-    static constexpr uint32_t kPipeSlots = HNSW_PIPE_DEPTH * kPipe;
-    hipEvent_t pipe_slot_done[kPipeSlots] = {};   // recorded after a slot's copy back
+    static constexpr uint32_t kPipe = 3;
     hipStream_t pipe_st[kPipe] = {};
     hipEvent_t pipe_done[kPipe] = {};      // recorded after a lane's last operation of a call
     hipEvent_t pipe_fork = nullptr;        // the caller's stream at entry (_device form)
-    float *pipe_dq[kPipeSlots] = {};       // device queries of one chunk
-    uint32_t *pipe_dres[kPipeSlots] = {};  // device [ids c*k][sims c*k][n_out c]
-    float *pipe_hq[kPipeSlots] = {};       // pinned mirrors
-    uint32_t *pipe_hres[kPipeSlots] = {};
+    float *pipe_dq[kPipe] = {};            // device queries of one chunk
+    uint32_t *pipe_dres[kPipe] = {};       // device [ids c*k][sims c*k][n_out c]
+    float *pipe_hq[kPipe] = {};            // pinned mirrors
+    uint32_t *pipe_hres[kPipe] = {};
     size_t pipe_q_words = 0, pipe_r_words = 0;
     uint32_t pipe_chunk = 1024;            // queries per chunk (tuning "pipe_chunk")
     uint32_t pipe_min_batch = 1536;        // batches at least this large are pipelined (tuning "pipe_min_batch")
