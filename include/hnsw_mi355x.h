@@ -73,7 +73,10 @@ void hnsw_destroy(hnsw_index *h);
 const char *hnsw_last_error(const hnsw_index *h); /* valid until the next call on h */
 
 /* Index::add_node (core.rs:383-412 -> insert :489-599), executed on the GPU,
- * exactly the reference's serial algorithm.  level < 0 draws
+ * the reference's serial algorithm link for link (one call runs as a one-node window of
+ * csrc/hnsw_occ.hpp: the shrinks its connect triggers are computed in parallel, then
+ * validated and applied in the reference's order; "single_window" = 0 runs the one-wave
+ * serial kernels instead -- same graph, same update_fn ids).  level < 0 draws
  * floor(-ln U / ln m) (core.rs:601-605); the first node ignores it
  * (core.rs:393-405).  touched (may be NULL) receives the ids the reference
  * would pass to update_fn (core.rs:580-584), each once, unordered; *n_touched

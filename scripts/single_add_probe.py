@@ -22,3 +22,11 @@ for i in range(N + 500, N + 1000):
     ix.add_batch(V[i:i + 1], levels=lv[i:i + 1], mode="exact")
 dt = (time.time() - t) / 500
 print("hnsw_add_batch of one node through the window: %.3f ms per insert" % (1e3 * dt))
+# HNSW.NODE.DEL one node per call (k_delete_exact: the neighbours' re-selections one after the other on one wave)
+rng = np.random.default_rng(5)
+victims = rng.choice(N, 300, replace=False)
+t = time.time()
+for v in victims:
+    ix.delete_node("node%d" % int(v))
+dt = (time.time() - t) / len(victims)
+print("hnsw_delete at %d nodes: %.3f ms per delete" % (N, 1e3 * dt))
