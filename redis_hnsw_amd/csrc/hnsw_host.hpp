@@ -239,5 +239,7 @@ hnsw_status launch_occ_plan_lean(hnsw_index *h, const InsertCfg &c, const OccBuf
 // hnsw_tu_occ.hip
 template <int MODE, int T>
 hnsw_status occ_round_r(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t head, uint32_t count, uint32_t end_node);
+template <int MODE, int T>
+hnsw_status occ_delete_r(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t id);
 
 } // namespace hnsw_host

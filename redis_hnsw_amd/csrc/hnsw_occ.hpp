@@ -370,8 +370,10 @@ __global__ __launch_bounds__(64, 1) void k_occ_plan(GraphView g, OccBufs ob, uin
 // ---------------------------------------------------------------------------------------------------------
 template <int MODE, int T, int R>
 __global__ __launch_bounds__(64, 1) void k_occ_shrinks(GraphView g, OccBufs ob, uint32_t first_node, uint32_t count, uint32_t mlinks,
-                                                    uint32_t lnb, uint32_t lcap, uint32_t *__restrict__ gspill, uint32_t gnb)
+                                                    uint32_t lnb, uint32_t lcap, uint32_t *__restrict__ gspill, uint32_t gnb,
+                                                    uint32_t del_id)
 {
+    // del_id != kEmpty: the slot lists the re-selections of HNSW.NODE.DEL (k_occ_del_list): the row as it is, del_id ignored
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
     const uint32_t b = blockIdx.x / kOccMaxShr, k = blockIdx.x % kOccMaxShr;
@@ -399,11 +401,11 @@ __global__ __launch_bounds__(64, 1) void k_occ_shrinks(GraphView g, OccBufs ob, 
     const uint32_t mmax = lc ? mlinks : 2 * mlinks;         // core.rs:560
     const uint32_t *erow = row_ptr(g, e, lc);
     bool fail = false;
-    // econn: e's row in stored order, this node last (core.rs:544-558)
+    // econn: e's row in stored order, this node last (core.rs:544-558); nconn of a delete: the row as it is (:832-844)
     QReg<T> qe;
     load_query<MODE, T>(g.vec + (size_t)e * g.dim, g.dim, qe, m.qlds, lane);
     uint32_t nE = 0;
-    const uint32_t tot = cnt + 1;
+    const uint32_t tot = del_id == kEmpty ? cnt + 1 : cnt;
     for (uint32_t base = 0; base < tot; base += 64) {
         const uint32_t i = base + lane;
         const uint32_t nf = tot - base < 64 ? tot - base : 64;
@@ -418,16 +420,19 @@ __global__ __launch_bounds__(64, 1) void k_occ_shrinks(GraphView g, OccBufs ob, 
     WorkCtr nolog = {};
     nolog.n_dist = tot;                                      // the econn evaluations (core.rs:550)
     nolog.n_ids = tot;
-    const uint32_t nS = select_topm<MODE, T>(g, m, vis, qe, m.W, nE, e, mmax, lc, nolog, lane, fail); // :568
+    const uint32_t nS = select_topm<MODE, T>(g, m, vis, qe, m.W, nE, e, mmax, lc, nolog, lane, fail, del_id); // :568 / :853
     if (vis.glob_dirty) visited_clear(vis, lane);
-    if (fail || nS == 0) { if (lane == 0) sl->fail = 1; return; }
+    if (fail || (nS == 0 && del_id == kEmpty)) { if (lane == 0) sl->fail = 1; return; }
+    if (nS == 0) return;                                     // an empty re-selection: the commit computes it itself
     if (lane == 0) { sp->w_dist = nolog.n_dist; sp->w_ids = nolog.n_ids; }
     const uint32_t bound = (uint32_t)(m.S[nS - 1] >> 32);
     for (uint32_t i = lane; i < nS; i += 64) sp->S[i] = key_id(m.S[i]);
     // reads: row e itself, and the rows of econn's members
     if (lane == 0 && log0 < kOccMaxReads) reads[log0] = OccRead{e, occ_meta(lc, OCC_SHRINK_ROW, k, true), 0u};
     for (uint32_t i = lane; i < tot; i += 64)
-        if (log0 + 1 + i < kOccMaxReads) reads[log0 + 1 + i] = OccRead{m.aux[i], occ_meta(lc, OCC_SHRINK_NB, k, true), bound};
+        if (log0 + 1 + i < kOccMaxReads) reads[log0 + 1 + i] = OccRead{m.aux[i], occ_meta(lc, OCC_SHRINK_NB, k, nS >= mmax), bound};
+    // (an insert's shrink always fills S -- its row is over-full; a delete's re-selection may not: then any id that
+    // appears in a member's row would be selected, whatever its distance: "not full" = everything matters)
     __threadfence();
     if (lane == 0) { sp->bound = bound; sp->nS = nS; }
 }
@@ -667,6 +672,181 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
         for (int i = 0; i < 8; ++i) ob.ctl->prof[i] += prof[i];
     }
 #undef OCC_T
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// HNSW.NODE.DEL through the same machinery (core.rs:414-475, 824-863): every neighbour n of the deleted node
+// re-selects its links from its two-hop neighbourhood with the node ignored -- ~33 select_neighbors one after the
+// other on one wavefront in k_delete_exact.  Here they are LISTED (k_occ_del_list), computed speculatively against
+// the graph as it stands, one wave each (k_occ_shrinks with del_id), and applied in the reference's order by one
+// wave that validates each result against the row changes the delete itself has journalled so far and recomputes
+// the stale ones (k_occ_del_commit).  Same rules as the insert's speculative shrinks: a change of n's own row, or a
+// change of a member's row by an id no farther than the last selected, makes the result stale.  A node with more
+// than kOccMaxShr neighbours over all its layers (or a read log that does not fit) is left to k_delete_exact.
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE, int T>
+__global__ __launch_bounds__(64, 1) void k_occ_del_list(GraphView g, OccBufs ob, uint32_t id)
+{
+    const int lane = threadIdx.x;
+    const uint32_t slot = id % ob.W;
+    OccSlot *sl = &ob.slots[slot];
+    OccShr *shr = ob.shr + (size_t)slot * kOccMaxShr;
+    const uint32_t l = g.levels[id];
+    uint32_t n_shr = 0, log_n = 0;
+    bool fail = false;
+    for (uint32_t lc = 0; lc <= l && !fail; ++lc) {              // core.rs:434
+        const uint32_t stride = lc ? g.strideU : g.stride0;
+        const uint32_t *drow = row_ptr(g, id, lc);
+        uint32_t dcnt = drow[0];
+        if (dcnt > stride - 1) dcnt = stride - 1;
+        if (n_shr + dcnt > kOccMaxShr) { fail = true; break; }   // (kOccMaxShr <= 64: one pass of the wave per layer)
+        const bool on = (uint32_t)lane < dcnt;
+        const uint32_t n = on ? drow[1 + lane] : 0u;
+        uint32_t cnt = on ? row_ptr(g, n, lc)[0] : 0u;
+        if (cnt > stride - 1) cnt = stride - 1;
+        if (__ballot(on && cnt > kAuxWords)) { fail = true; break; }
+        // log ranges: running sum of (1 + cnt) in stored order (core.rs:829)
+        uint32_t incl = on ? cnt + 1 : 0u;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (on) {
+            OccShr *sp = &shr[n_shr + lane];
+            sp->lc = lc; sp->e = n; sp->nS = 0; sp->bound = 0; sp->log0 = log_n + incl - (cnt + 1); sp->cnt = cnt;
+        }
+        log_n += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        n_shr += dcnt;
+    }
+    if (log_n > kOccMaxReads) fail = true;
+    __threadfence();
+    if (lane == 0) {
+        sl->node = id; sl->snap = ob.ctl->nJ; sl->epoch = ob.ctl->epoch;
+        sl->n_reads = log_n < kOccMaxReads ? log_n : kOccMaxReads;
+        sl->n_shr = fail ? 0u : n_shr; sl->top = l; sl->fail = fail ? 1u : 0u;
+        sl->planned = 1;
+    }
+}
+
+template <int MODE, int T, int R>
+__global__ __launch_bounds__(64, 1) void k_occ_del_commit(GraphView g, OccBufs ob, uint32_t id, uint32_t mlinks, uint32_t lnb,
+                                                       uint32_t lcap, uint32_t *__restrict__ gspill, uint32_t gnb,
+                                                       uint32_t *__restrict__ touched, uint32_t touched_cap)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    OccScratch sc = occ_carve(smem);
+    WaveMem m;
+    Visited vis;
+    carve<R, T, true>(smem + kOccScratchBytes, g.dim, lnb, lcap, m, vis, g.tagcfg);
+    vis.glob = gspill;
+    vis.gnb = gnb;
+    vis.glob_dirty = false;
+    vis.spilled = false;
+    vis.count = 0;
+    vis.bounded = false;
+    vis.lossy = false;
+
+    const uint32_t slot = id % ob.W;
+    OccSlot *sl = &ob.slots[slot];
+    if (!sl->planned || sl->node != id || sl->fail) {           // nothing is touched: k_delete_exact takes it
+        if (lane == 0) ob.ctl->stop = OCC_STOP_SERIAL;
+        return;
+    }
+    const OccRead *reads = ob.reads + (size_t)slot * kOccMaxReads;
+    const OccShr *shr = ob.shr + (size_t)slot * kOccMaxShr;
+    const uint32_t n_shr = sl->n_shr;
+    OccJournal jr;
+    jr.ring = ob.ring;
+    jr.n = ob.ctl->nJ;
+    occ_init_hash(sc, lane);
+    occ_build_hash(sc, reads, sl->n_reads, shr, n_shr, lane);
+    jr.own = sc.own;                                            // the delete's deltas are mirrored in LDS
+    jr.own_base = jr.n;
+    uint32_t checked = jr.n;
+    unsigned long long n_spec = 0, n_fallback = 0, w_dist = 0, w_ids = 0;
+    uint32_t nt = 0;
+    bool fail = false;
+    const uint32_t l = g.levels[id];
+
+    for (uint32_t lc = 0; lc <= l && !fail; ++lc) {              // core.rs:434
+        const uint32_t stride = lc ? g.strideU : g.stride0;
+        const uint32_t mmax = lc ? mlinks : 2 * mlinks;          // core.rs:846
+        uint32_t *maxdeg = lc ? &g.hdr->max_degU : &g.hdr->max_deg0;
+        uint32_t *drow = row_ptr(g, id, lc);                     // not modified while we walk it
+        uint32_t dcnt = drow[0];
+        if (dcnt > stride - 1) dcnt = stride - 1;
+        for (uint32_t kk = 0; kk < dcnt && !fail; ++kk) {        // core.rs:829 stored order
+            const uint32_t n = drow[1 + kk];
+            uint32_t *erow = row_ptr(g, n, lc);
+            uint32_t cnt = erow[0];
+            if (cnt > stride - 1) cnt = stride - 1;
+            int k = -1;
+            {
+                const bool mine = (uint32_t)lane < n_shr && shr[lane].e == n && shr[lane].lc == lc && shr[lane].nS != 0;
+                const uint64_t mb = __ballot(mine);
+                if (mb) k = 63 - __builtin_clzll((unsigned long long)mb);
+            }
+            if (k >= 0 && checked != jr.n) {
+                occ_check_range<MODE, T>(g, m, sc, ob, reads, shr, id, checked, jr.n, lane, true, jr.own_base);
+                checked = jr.n;
+            }
+            for (uint32_t i = lane; i < cnt; i += 64) m.aux[i] = erow[1 + i];
+            __syncthreads();
+            uint32_t nS;
+            if (k >= 0 && !sc.flags[2 + k]) {
+                const uint32_t sv = shr[k].S[lane], sv2 = shr[k].S[64 + lane];
+                nS = shr[k].nS;
+                if ((uint32_t)lane < nS) m.S[lane] = (uint64_t)sv << 1;
+                if (64u + (uint32_t)lane < nS) m.S[64 + lane] = (uint64_t)sv2 << 1;
+                __syncthreads();
+                n_spec += 1;
+                w_dist += shr[k].w_dist;
+                w_ids += shr[k].w_ids;
+            } else {
+                // recompute on the spot (core.rs:832-853)
+                QReg<T> qe;
+                load_query<MODE, T>(g.vec + (size_t)n * g.dim, g.dim, qe, m.qlds, lane);
+                uint32_t nE = 0;
+                for (uint32_t base = 0; base < cnt; base += 64) {
+                    const uint32_t i = base + lane;
+                    const uint32_t nf = cnt - base < 64 ? cnt - base : 64;
+                    if (i < cnt) m.fresh[lane] = m.aux[i];
+                    __syncthreads();
+                    compute_dists<MODE, T>(g, qe, m, nf, lane);
+                    __syncthreads();
+                    const bool have = (uint32_t)lane < nf;
+                    const uint64_t key = have ? pack_key(m.dsc[lane], m.fresh[lane]) : ~0ull;
+                    nE = merge_sorted<R>(m.W, nE, R * 64, key, have, lane);
+                }
+                WorkCtr nolog = {};
+                nS = select_topm<MODE, T>(g, m, vis, qe, m.W, nE, n, mmax, lc, nolog, lane, fail, id);
+                if (fail) break;
+                w_dist += cnt + nolog.n_dist;
+                w_ids += cnt + nolog.n_ids;
+                n_fallback += 1;
+            }
+            // update_node_connections(n, new, old, ignored = node) (core.rs:856)
+            update_connections(g, m, n, erow, cnt, nS, lc, stride, maxdeg, id, touched, touched_cap, nt, lane, &jr);
+        }
+        if (lane == 0) drow[0] = 0;                              // the node is gone (core.rs:419)
+        __threadfence();
+        __syncthreads();
+    }
+    if (fail && lane == 0) atomicOr(&g.hdr->status, ST_VISITED_OVERFLOW);
+    if (vis.glob_dirty) visited_clear(vis, lane);
+    if (lane == 0) {
+        g.hdr->n_touched = nt;
+        atomicAdd(&g.hdr->ctr_insert[0], w_dist);
+        atomicAdd(&g.hdr->ctr_insert[1], w_ids);
+        ob.ctl->head = id + 1;                                   // done (the host's completion test)
+        ob.ctl->nJ = jr.n;
+        ob.ctl->stop = OCC_STOP_NONE;
+        ob.ctl->n_spec += n_spec;
+        ob.ctl->n_fallback += n_fallback;
+        sl->planned = 0;
+    }
 }
 
 } // namespace hnsw

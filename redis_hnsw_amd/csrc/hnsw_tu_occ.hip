@@ -1,5 +1,6 @@
 // hnsw_tu_occ.hip -- the exact-order parallel insert (hnsw_occ.hpp) for one metric variant (HNSW_VARIANT, see
-// hnsw_host.hpp): k_occ_validate, k_occ_plan, k_occ_shrinks, k_occ_commit and the launcher of one round.
+// hnsw_host.hpp): k_occ_validate, k_occ_plan, k_occ_shrinks, k_occ_commit and the launcher of one round; k_occ_del_list,
+// k_occ_del_commit and the launcher of a delete.
 #include "hnsw_host.hpp"
 
 namespace hnsw_host {
@@ -37,12 +38,51 @@ static hnsw_status occ_round_t(hnsw_index *h, const InsertCfg &c, const OccBufs 
         hipLaunchKernelGGL(kp, dim3(count), dim3(64), c.lds, h->stream, gv, ob, head, count, h->efc, h->m, c.lnb, c.lcap, h->d_spill,
                            h->spill_gnb, h->d_plan, h->select_shortcut ? 1u : 0u, h->occ_log_cap);
     hipLaunchKernelGGL(ks, dim3(count * kOccMaxShr), dim3(64), c.lds, h->stream, gv, ob, head, count, h->m, c.lnb, c.lcap, h->d_spill,
-                       h->spill_gnb);
+                       h->spill_gnb, kEmpty);
     hipLaunchKernelGGL(kc, dim3(1), dim3(64), lds_commit, h->stream, gv, ob, end_node, h->m, c.lnb, c.lcap, h->d_spill_one,
                        h->spill_one_gnb, h->d_plan, h->m + 2 + h->occ_slack_extra, h->occ_want_touched ? h->d_touched : nullptr,
                        h->occ_want_touched ? h->touched_cap : 0u);
     HIP_TRY(h, hipGetLastError());
     return HNSW_OK;
+}
+
+// HNSW.NODE.DEL with its re-selections computed speculatively in parallel (k_occ_del_list / k_occ_shrinks / k_occ_del_commit)
+template <int MODE, int T, int R>
+static hnsw_status occ_delete_t(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t id)
+{
+    const size_t lds_commit = kOccScratchBytes + c.lds;
+    auto kl = k_occ_del_list<MODE, T>;
+    auto ks = k_occ_shrinks<MODE, T, R>;
+    auto kd = k_occ_del_commit<MODE, T, R>;
+    {
+        static std::mutex mu;
+        static bool attr_set[16] = {false};
+        std::lock_guard<std::mutex> lock(mu);
+        if (!attr_set[h->device & 15]) {
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+            attr_set[h->device & 15] = true;
+        }
+    }
+    const GraphView gv = view_tag(h, c.tagcfg);
+    hipLaunchKernelGGL(kl, dim3(1), dim3(64), 0, h->stream, gv, ob, id);
+    hipLaunchKernelGGL(ks, dim3(kOccMaxShr), dim3(64), c.lds, h->stream, gv, ob, id, 1u, h->m, c.lnb, c.lcap, h->d_spill, h->spill_gnb, id);
+    hipLaunchKernelGGL(kd, dim3(1), dim3(64), lds_commit, h->stream, gv, ob, id, h->m, c.lnb, c.lcap, h->d_spill_one, h->spill_one_gnb,
+                       h->d_touched, h->touched_cap);
+    HIP_TRY(h, hipGetLastError());
+    return HNSW_OK;
+}
+
+template <int MODE, int T>
+hnsw_status occ_delete_r(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t id)
+{
+    switch (c.R) {
+    case 1: return occ_delete_t<MODE, T, 1>(h, c, ob, id);
+    case 4: return occ_delete_t<MODE, T, 4>(h, c, ob, id);
+    case 8: return occ_delete_t<MODE, T, 8>(h, c, ob, id);
+    case 16: return occ_delete_t<MODE, T, 16>(h, c, ob, id);
+    }
+    return fail(h, HNSW_ERR_INVALID, "bad R");
 }
 
 template <int MODE, int T>
@@ -58,5 +98,6 @@ hnsw_status occ_round_r(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, ui
 }
 
 template hnsw_status occ_round_r<kVarMode, kVarT>(hnsw_index *, const InsertCfg &, const OccBufs &, uint32_t, uint32_t, uint32_t);
+template hnsw_status occ_delete_r<kVarMode, kVarT>(hnsw_index *, const InsertCfg &, const OccBufs &, uint32_t);
 
 } // namespace hnsw_host

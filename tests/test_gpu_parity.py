@@ -672,12 +672,18 @@ def test_hnsw_test_delete_reference_kat(eng):
     index.close()
 
 
-@pytest.mark.parametrize("n,dim,m,ef", [(300, 32, 5, 16), (400, 128, 16, 64), (250, 4, 5, 16)])
-def test_delete_matches_oracle(eng, oracle_mod, n, dim, m, ef):
+@pytest.mark.parametrize("single_window", [1, 0])
+@pytest.mark.parametrize("n,dim,m,ef", [(300, 32, 5, 16), (400, 128, 16, 64), (250, 4, 5, 16), (600, 128, 24, 100)])
+def test_delete_matches_oracle(eng, oracle_mod, n, dim, m, ef, single_window):
+    """HNSW.NODE.DEL with the neighbours' re-selections computed speculatively in parallel and applied in order
+    (the default) and through the one-wave kernel: graphs, update_fn sets, searches and enterpoint re-election
+    equal the oracle's.  (M = 24: rows of up to 48 ids -- nodes with more than 32 neighbours fall back to the
+    one-wave kernel inside the default path.)"""
     V = make_data(n + 60, dim, seed=71)
     lv = oracle_mod.draw_levels(n + 60, m, 4)
     o = oracle_mod.OracleIndex(dim, m, ef)
     gi = eng.Index("foo", dim, m, ef)
+    gi.set_tuning("single_window", single_window)
     o.add_batch(V[:n], lv[:n])
     gi.add_batch(V[:n], levels=lv[:n], mode="exact")
     order = np.random.default_rng(5).permutation(n)[: n // 2]
