@@ -98,7 +98,8 @@ hnsw_status hnsw_add_batch(hnsw_index *h, const float *V, uint32_t n, uint32_t d
                            const int32_t *levels, uint32_t mode);
 
 /* Index::delete_node (core.rs:414-475 -> delete_node_from_neighbors :824-863), executed on the GPU
- * in the reference's serial order.  The id becomes a tombstone (never reused); node_count drops.
+ * in the reference's serial order (the neighbours' re-selections are computed in parallel, then validated
+ * and applied in that order; "single_window" = 0: one after the other).  The id becomes a tombstone (never reused); node_count drops.
  * If the node was the enterpoint, the new one is the smallest id of the highest non-empty layer
  * (the reference takes an arbitrary node of that layer, core.rs:453).  HNSW_ERR_NOT_FOUND if id is
  * not a live node (core.rs:421).  touched as for hnsw_add.                                        */
