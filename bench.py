@@ -609,6 +609,7 @@ def main():
         log("fast GPU build: %.2f s, recall@10 %.4f" % (tfb, fast_build["recall_at_10"]))
     exact_build = None
     single_add = None
+    single_delete = None
     if cfg_is_c2 and extras and world == 1:
         # the reference-order build (hnsw_add_batch mode 0: plans in parallel, validated in-order commits) on a
         # bounded prefix, CHECKED row for row against the oracle's serial build of the same prefix (committed
@@ -659,6 +660,26 @@ def main():
                 raise SystemExit("single_add: the graph after %d hnsw_add calls differs from the oracle's" % NA)
             single_add = dict(workload="HNSW.NODE.ADD: %d single hnsw_add calls (host vectors) on the %d-node reference-order index" % (NA, NE),
                               gpu_ms=round(1e3 * ta, 3), cpu_oracle_ms=round(1e3 * tc, 3), identical=True)
+            # HNSW.NODE.DEL the same way (src/lib.rs:397): single hnsw_delete calls, timed, then checked
+            ND = 100
+            victims = [int(v) for v in np.random.default_rng(17).choice(NE, ND, replace=False)]
+            td = time.time()
+            for v in victims:
+                ie.delete_node("node%d" % v)
+            td = (time.time() - td) / ND
+            tcd = time.time()
+            for v in victims:
+                oa.delete(v)
+            tcd = (time.time() - tcd) / ND
+            ga, gb = oa.export(), ie.export_graph()
+            same = (ga["enterpoint"] == gb["enterpoint"]
+                    and all(np.array_equal(a_, b_) for a_, b_ in zip(ga["row_ptr"], gb["row_ptr"]))
+                    and all(np.array_equal(a_, b_) for a_, b_ in zip(ga["col"], gb["col"])))
+            if not same:
+                raise SystemExit("single_delete: the graph after %d hnsw_delete calls differs from the oracle's" % ND)
+            single_delete = dict(workload="HNSW.NODE.DEL: %d single hnsw_delete calls on the same index" % ND,
+                                 gpu_ms=round(1e3 * td, 3), cpu_oracle_ms=round(1e3 * tcd, 3), identical=True)
+            log("single hnsw_delete: %.3f ms per call (CPU oracle %.3f ms), graphs identical" % (1e3 * td, 1e3 * tcd))
             oa.close()
             log("single hnsw_add: %.3f ms per call (CPU oracle %.3f ms), graphs identical" % (1e3 * ta, 1e3 * tc))
         ie.close()
@@ -929,7 +950,7 @@ def main():
         "recall_at_%d" % k: None if recall is None else round(recall, 4),
         "build_seconds": None if t_build is None else round(t_build, 2),
         "host_buffers_qps": round(host_qps, 1), "host_buffers": host, "single_process_group": group_leg, "device_call": dev_calls,
-        "gpu_fast_build": fast_build, "gpu_exact_build": exact_build, "single_add": single_add,
+        "gpu_fast_build": fast_build, "gpu_exact_build": exact_build, "single_add": single_add, "single_delete": single_delete,
         "clustered": clus,
         "bf16_storage_mode": bf16, "fp8_storage_mode": fp8,
         "c1_single_query": c1,

@@ -177,7 +177,8 @@ __device__ __forceinline__ void occ_check_range(const GraphView &g, const WaveMe
                         sc.hits[3 * p] = (kind == OCC_SHRINK_NB ? 1u + sub : 0u) | (add ? 0x100u : 0u);
                         sc.hits[3 * p + 1] = d.z;
                         sc.hits[3 * p + 2] = sc.rbound[i];
-                    } else sc.flags[0] = 1;                              // too many to evaluate: treat as stale
+                    } else if (kind == OCC_SHRINK_NB) atomicOr(&sc.flags[2 + sub], OCC_WHY_ROW);   // too many to evaluate: that shrink is recomputed
+                    else sc.flags[0] = 1;                                // ... the link plan is treated as stale
                 }
             }
         }

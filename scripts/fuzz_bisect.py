@@ -1,4 +1,5 @@
 """Replay one case of tests/test_gpu_fuzz.py checking the graph after EVERY op; print the first divergence."""
+import os
 import sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -8,7 +9,11 @@ from tests.util import graphs_equal
 from tests.test_gpu_fuzz import CASES, _data
 
 oracle_mod.build()
-case = CASES[int(sys.argv[1])]
+if "," in sys.argv[1]:                              # kind,dim,m,ef,n_ops,seed of a campaign line
+    f = sys.argv[1].split(",")
+    case = (f[0], int(f[1]), int(f[2]), int(f[3]), int(f[4]), int(f[5]))
+else:
+    case = CASES[int(sys.argv[1])]
 kind, dim, m, ef, n_ops, seed = case
 rng = np.random.default_rng(seed)
 pool = _data(kind, 6000, dim, rng)
@@ -48,7 +53,7 @@ for op_i in range(n_ops):
         what = "delete %d (deg0 touched %d) touched_equal=%s" % (i, len(ot), sorted(got) == sorted(ot.tolist()))
         live.remove(i)
     elif r < 0.93:
-        B = int(rng.choice([1, 3, 40])); k = int(rng.choice([1, 5, ef, ef + 7]))
+        B = int(rng.choice([1, 3, 40, 130, 700, 1500] if os.environ.get("STRESS") else [1, 3, 40])); k = int(rng.choice([1, 5, ef, ef + 7]))
         Q = pool[rng.integers(0, pool.shape[0], B)] + (0 if rng.random() < 0.5 else rng.random((B, dim), dtype=np.float32) * np.float32(0.1))
         what = "search"
     else:

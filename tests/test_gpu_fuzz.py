@@ -194,6 +194,12 @@ def test_random_op_sequences_under_non_default_tunings(eng, oracle_mod, kind, di
     # the stress form on the reference's usual shapes: large batches through the pipeline, compressed copy at the end
     ("uniform", 128, 16, 200, 60, 300500, ()),
     ("clustered", 64, 40, 100, 60, 300501, (("pipe_chunk", 64),)),
+    # found by the campaign once HNSW.NODE.DEL speculated its re-selections (1 of 120 cases): on a dense graph (M = 48)
+    # one validation pass met more (reader, id) pairs than its list holds (1024); the overflow marked the LINK PLAN
+    # stale -- which a shrinks-only pass never looks at -- instead of the shrink, so a stale re-selection was applied
+    ("clustered", 128, 48, 200, 40, 800104, ()),
+    # ... and, on a 20-node m = 2 graph: a re-selection that does not fill its list must count every change as relevant
+    ("uniform", 32, 2, 8, 90, 7, ()),
 ])
 def test_stress_sequences_large_m_pipeline_and_compressed_copies(eng, oracle_mod, kind, dim, m, ef, n_ops, seed, tunings):
     test_random_op_sequences_match_the_oracle(eng, oracle_mod, kind, dim, m, ef, n_ops, seed, tunings, stress=True)
