@@ -33,3 +33,23 @@ def test_select_after_search_is_the_head_of_W(tmp_path):
         r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "differing from the m nearest of W: 0" in r.stdout
+
+
+def test_speculated_delete_model_reproduces_the_serial_delete(tmp_path):
+    """tests/experiments/del_model.c: HNSW.NODE.DEL with every neighbour's re-selection computed on the graph as
+    it stands before the delete, then validated against the delete's own journal and applied in the reference's
+    order (what k_occ_del_list / k_occ_shrinks / k_occ_del_commit do on the GPU) gives the serial delete's graph --
+    and does NOT once the rule "a selection that did not fill its list counts every change as relevant" is dropped
+    (m = 2), which is the rule the GPU campaign found missing."""
+    exe = str(tmp_path / "del_model")
+    src = os.path.join(ROOT, "tests", "experiments", "del_model.c")
+    subprocess.check_call(["gcc", "-O2", "-mavx2", "-mfma", "-ffp-contract=off", "-w", "-o", exe, src, "-lm", "-lpthread"])
+    for args in (["1500", "300", "32", "8", "40"], ["800", "400", "16", "2", "8"], ["600", "300", "128", "16", "64"],
+                 ["400", "250", "8", "24", "48"]):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "graphs IDENTICAL" in r.stdout
+        m = re.search(r"speculative result used ([0-9.]+)", r.stdout)
+        assert m and float(m.group(1)) > 0.0
+    r = subprocess.run([exe, "800", "400", "16", "2", "8", "norule"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 1 and "graphs DIFFER" in r.stdout
