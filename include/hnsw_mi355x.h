@@ -81,7 +81,9 @@ const char *hnsw_last_error(const hnsw_index *h); /* valid until the next call o
  * (core.rs:393-405).  touched (may be NULL) receives the ids the reference
  * would pass to update_fn (core.rs:580-584), each once, unordered; *n_touched
  * is their number even when it exceeds touched_cap (only touched_cap are
- * written then: the caller must treat that as an error, not skip the rest).  */
+ * written then: the caller must treat that as an error, not skip the rest --
+ * AFTER recording the new id, because the insert itself is complete whenever
+ * the status is HNSW_OK; UINT32_MAX = the engine could not list them at all). */
 hnsw_status hnsw_add(hnsw_index *h, const float *v, uint32_t dim, int32_t level,
                      uint32_t *out_id, uint32_t *touched, uint32_t touched_cap,
                      uint32_t *n_touched);
@@ -226,7 +228,8 @@ hnsw_status hnsw_group_add_batch(hnsw_group *g, const float *V, uint32_t n, uint
 
 /* Export for IndexRedis/NodeRedis write-through (src/types.rs:62-91,292-309). */
 hnsw_status hnsw_get_info(hnsw_index *h, hnsw_info *info);
-hnsw_status hnsw_get_levels(hnsw_index *h, uint32_t *levels /*[node_count]*/);
+hnsw_status hnsw_get_levels(hnsw_index *h, uint32_t *levels /*[allocated_ids]*/);
+hnsw_status hnsw_get_level(hnsw_index *h, uint32_t id, uint32_t *level);  /* one node's top layer (core.rs:596), O(1) */
 hnsw_status hnsw_get_vector(hnsw_index *h, uint32_t id, float *out /*[dim]*/);
 hnsw_status hnsw_get_neighbors(hnsw_index *h, uint32_t id, uint32_t layer,
                                uint32_t *out, uint32_t cap, uint32_t *n);

@@ -66,6 +66,7 @@ extern "C" {
     // IndexRedis / NodeRedis write-through  src/types.rs:62-91, 292-309
     pub fn hnsw_get_info(h: *mut hnsw_index, info: *mut hnsw_info) -> c_int;
     pub fn hnsw_get_levels(h: *mut hnsw_index, levels: *mut u32) -> c_int;
+    pub fn hnsw_get_level(h: *mut hnsw_index, id: u32, level: *mut u32) -> c_int;
     pub fn hnsw_get_vector(h: *mut hnsw_index, id: u32, out: *mut f32) -> c_int;
     pub fn hnsw_get_neighbors(h: *mut hnsw_index, id: u32, layer: u32, out: *mut u32, cap: u32, n: *mut u32) -> c_int;
     // snapshot: what save_index / load_index may stream instead of one key per node  src/types.rs:176-284

@@ -3,8 +3,10 @@
 //! the engine speaks dense ids.  Error strings are the reference's (core.rs:390, 408, 421, 479), rendered by
 //! error_string() exactly as clients see them today (core.rs:42-46).
 use super::ffi;
+use crate::types::IndexRedis;
 use std::collections::HashMap;
 use std::ffi::CStr;
+use std::sync::Mutex;
 
 #[derive(Debug)]
 pub enum HNSWError {
@@ -72,9 +74,22 @@ pub struct GpuIndex {
     names: Vec<Option<String>>, // id -> "hnsw.{idx}.{node}"; None = deleted (ids are never reused)
     ids: HashMap<String, u32>,  // name -> id
     levels: Vec<u32>,           // id -> top layer (the layer sets of IndexRedis.layers)
+    // where each live id sits in the persisted hnswindex value (IndexRedis.nodes / IndexRedis.layers[level]),
+    // so that HNSW.NODE.ADD / HNSW.NODE.DEL edit that value in O(1) instead of rebuilding it (sync_redis)
+    pos_nodes: Vec<u32>,
+    pos_layer: Vec<u32>,
+    pending: Vec<Change>,       // what the commands since the last sync_redis did
+    // search_knn takes &self (core.rs:477) and the module lets readers in concurrently (try_read, src/lib.rs:474),
+    // but one engine handle serves one caller at a time (staging buffers, stream, error string): readers queue here
+    search_lock: Mutex<()>,
+}
+const NOT_STORED: u32 = u32::MAX;
+enum Change {
+    Added(u32),
+    Removed(u32),
 }
 unsafe impl Send for GpuIndex {}
-unsafe impl Sync for GpuIndex {} // search_knn takes &self (core.rs:477); the module serialises writers with try_write
+unsafe impl Sync for GpuIndex {} // every FFI call that takes &self goes through search_lock; writers hold try_write
 
 impl GpuIndex {
     fn last_error(&self) -> HNSWError {
@@ -99,6 +114,10 @@ impl GpuIndex {
             names: Vec::new(),
             ids: HashMap::new(),
             levels: Vec::new(),
+            pos_nodes: Vec::new(),
+            pos_layer: Vec::new(),
+            pending: Vec::new(),
+            search_lock: Mutex::new(()),
         };
         if st != ffi::HNSW_OK {
             return Err(idx.last_error());
@@ -127,19 +146,71 @@ impl GpuIndex {
         let e = self.info().enterpoint;
         if e < 0 { None } else { self.names[e as usize].clone() }
     }
-    /// IndexRedis.layers: the names of the nodes whose top layer is l  (src/types.rs:73-82)
+    /// IndexRedis.layers: layer l holds the names of the nodes whose TOP layer is l -- a node is in exactly one
+    /// set (core.rs:596 `self.layers[l].insert`, src/types.rs:73-82), which is what delete_node relies on when it
+    /// removes a node from one set and breaks (core.rs:426-430).  Used for replies (HNSW.GET) and for the value
+    /// HNSW.NEW stores; the stored value is kept current by sync_redis, not rebuilt from here.
     pub fn layers(&self) -> Vec<Vec<String>> {
         let top = self.info().max_layer as usize;
         let mut out = vec![Vec::new(); if self.ids.is_empty() { 0 } else { top + 1 }];
         for (id, name) in self.names.iter().enumerate() {
             if let Some(n) = name {
-                let l = self.levels[id] as usize;
-                for layer in out.iter_mut().take(l + 1) {
-                    layer.push(n.clone());
-                }
+                out[self.levels[id] as usize].push(n.clone());
             }
         }
         out
+    }
+
+    /// update_index (src/lib.rs:317-332) without `index.clone().into()`: bring the stored hnswindex value up to date
+    /// with what the commands since the last call did.  The reference re-serialises all names and layer sets on every
+    /// HNSW.NODE.ADD (O(N) per command, O(N^2) per load); here an add appends one name to `nodes` and to the set of its
+    /// top layer, a delete swap-removes the name from both, and the header fields are overwritten.
+    pub fn sync_redis(&mut self, ir: &mut IndexRedis) {
+        let info = self.info();
+        let pending = std::mem::replace(&mut self.pending, Vec::new());
+        for ch in pending {
+            match ch {
+                Change::Added(id) => {
+                    let id = id as usize;
+                    let name = match &self.names[id] {
+                        Some(n) => n.clone(),
+                        None => continue, // added and deleted again before the value was synchronised
+                    };
+                    let l = self.levels[id] as usize;
+                    self.pos_nodes[id] = ir.nodes.len() as u32;
+                    ir.nodes.push(name.clone());
+                    while ir.layers.len() < l + 1 {
+                        ir.layers.push(Vec::new()); // core.rs:590-592
+                    }
+                    self.pos_layer[id] = ir.layers[l].len() as u32;
+                    ir.layers[l].push(name); // core.rs:596
+                }
+                Change::Removed(id) => {
+                    let id = id as usize;
+                    if self.pos_nodes[id] == NOT_STORED {
+                        continue; // never reached the stored value (see Added above)
+                    }
+                    // positions are only ever edited here, so they describe `ir` as it is now
+                    let (p, l, q) = (self.pos_nodes[id] as usize, self.levels[id] as usize, self.pos_layer[id] as usize);
+                    self.pos_nodes[id] = NOT_STORED;
+                    ir.nodes.swap_remove(p);
+                    if p < ir.nodes.len() {
+                        let moved = self.ids[&ir.nodes[p]] as usize;
+                        self.pos_nodes[moved] = p as u32;
+                    }
+                    ir.layers[l].swap_remove(q); // core.rs:426-430: the one set that holds it
+                    if q < ir.layers[l].len() {
+                        let moved = self.ids[&ir.layers[l][q]] as usize;
+                        self.pos_layer[moved] = q as u32;
+                    }
+                }
+            }
+        }
+        ir.node_count = info.node_count as usize;
+        ir.max_layer = info.max_layer as usize;
+        // core.rs:453-466: empty top layers are popped when the enterpoint goes; with no node left there is no layer
+        ir.layers.truncate(if self.ids.is_empty() { 0 } else { info.max_layer as usize + 1 });
+        ir.enterpoint = self.enterpoint();
     }
 
     /// add_node(&mut self, name, data, update_fn)  core.rs:383-412
@@ -159,16 +230,22 @@ impl GpuIndex {
         if st != ffi::HNSW_OK {
             return Err(self.last_error());
         }
-        if nt as usize > touched.len() {
-            return Err(format!("update_fn list of {} ids does not fit the buffer", nt).into());
-        }
+        // status OK = the graph holds the node: record it BEFORE anything else can fail, or names and ids drift apart
         debug_assert_eq!(id as usize, self.names.len());
+        let mut level = 0u32;
+        unsafe { ffi::hnsw_get_level(self.h, id, &mut level) }; // O(1); the level the engine drew (core.rs:601-605)
         self.names.push(Some(name.to_owned()));
         self.ids.insert(name.to_owned(), id);
-        let mut lv = vec![0u32; self.names.len()];
-        unsafe { ffi::hnsw_get_levels(self.h, lv.as_mut_ptr()) };
-        self.levels = lv;
-        for &t in &touched[..(nt as usize).min(touched.len())] {
+        self.levels.push(level);
+        self.pos_nodes.push(NOT_STORED);
+        self.pos_layer.push(NOT_STORED);
+        self.pending.push(Change::Added(id));
+        if nt as usize > touched.len() {
+            // the list is incomplete (u32::MAX: the engine could not produce it): the node keys of this command
+            // cannot all be rewritten -- surface it; the index itself is consistent
+            return Err(format!("update_fn list of {} ids does not fit the buffer", nt).into());
+        }
+        for &t in &touched[..nt as usize] {
             // core.rs:580-584: every node whose links changed is written through (write_node, src/lib.rs:351-353)
             update_fn(self.names[t as usize].clone().unwrap(), NodeView { index: self, id: t });
         }
@@ -186,12 +263,13 @@ impl GpuIndex {
         if st != ffi::HNSW_OK {
             return Err(self.last_error());
         }
+        self.ids.remove(name); // status OK = the node is gone from the graph (see add_node)
+        self.names[id as usize] = None;
+        self.pending.push(Change::Removed(id));
         if nt as usize > touched.len() {
             return Err(format!("update_fn list of {} ids does not fit the buffer", nt).into());
         }
-        self.ids.remove(name);
-        self.names[id as usize] = None;
-        for &t in &touched[..(nt as usize).min(touched.len())] {
+        for &t in &touched[..nt as usize] {
             if let Some(n) = self.names[t as usize].clone() {
                 update_fn(n, NodeView { index: self, id: t }); // core.rs:441-446
             }
@@ -208,6 +286,7 @@ impl GpuIndex {
             return Ok(Vec::new()); // core.rs:481-483
         }
         let (mut ids, mut sims, mut n) = (vec![0u32; k], vec![0f32; k], 0u32);
+        let _one_caller = self.search_lock.lock().unwrap(); // the handle's staging, stream and error string are per call
         let st = unsafe {
             ffi::hnsw_search(self.h, data.as_ptr(), data.len() as u32, k as u32, ids.as_mut_ptr(), sims.as_mut_ptr(), &mut n)
         };
@@ -225,8 +304,13 @@ impl GpuIndex {
 
     /// make_index (src/lib.rs:252-315): rebuild from the per-node keys with ONE upload.
     /// nodes[i] = (key, data, neighbour keys per layer) in the order of IndexRedis.nodes; ids follow that order.
+    /// A node's level is the layer SET it is in (`layers`, src/lib.rs:287-299; core.rs:596), never its row count: the
+    /// reference saves a node that was promoted to enterpoint with l > l_max with rows 0..=l_max only (the loop of
+    /// core.rs:523 starts at min(l_max, l); upper rows appear lazily, core.rs:642), and the first node of an index
+    /// with no row at all (core.rs:393-405).  Missing rows are empty rows.
     pub fn from_keys(name: &str, data_dim: usize, m: usize, ef_construction: usize,
-                     nodes: Vec<(String, Vec<f32>, Vec<Vec<String>>)>, enterpoint: Option<String>)
+                     nodes: Vec<(String, Vec<f32>, Vec<Vec<String>>)>, layers: &[Vec<String>], max_layer: usize,
+                     enterpoint: Option<String>)
                      -> Result<Self, HNSWError> {
         let mut idx = GpuIndex::new(name, data_dim, m, ef_construction)?;
         let n = nodes.len();
@@ -236,14 +320,31 @@ impl GpuIndex {
         for (i, (key, _, _)) in nodes.iter().enumerate() {
             idx.ids.insert(key.clone(), i as u32);
         }
-        let n_layers = nodes.iter().map(|x| x.2.len()).max().unwrap_or(1).max(1);
+        let mut levels = vec![NOT_STORED; n];
+        let mut pos_layer = vec![NOT_STORED; n];
+        for (l, set) in layers.iter().enumerate() {
+            for (q, key) in set.iter().enumerate() {
+                // src/lib.rs:290-293: a name in a layer set that is not a node of the index is an error
+                let i = *idx.ids.get(key).ok_or_else(|| format!("Node: {} does not exist", key))? as usize;
+                levels[i] = l as u32;
+                pos_layer[i] = q as u32;
+            }
+        }
+        if let Some(i) = levels.iter().position(|&l| l == NOT_STORED) {
+            return Err(format!("Node: {} is in no layer set", nodes[i].0).into());
+        }
+        let n_layers = (max_layer + 1).max(layers.len()).max(1);
         let mut vectors = Vec::with_capacity(n * data_dim);
-        let mut levels = vec![0u32; n];
         let mut row_ptr = vec![vec![0u64; n + 1]; n_layers];
         let mut col: Vec<Vec<u32>> = vec![Vec::new(); n_layers];
-        for (i, (_, data, nbrs)) in nodes.iter().enumerate() {
+        for (i, (key, data, nbrs)) in nodes.iter().enumerate() {
+            if data.len() != data_dim {
+                return Err(format!("data dimension: {} does not match Index", data.len()).into());
+            }
             vectors.extend_from_slice(data);
-            levels[i] = nbrs.len().max(1) as u32 - 1;
+            if nbrs.iter().skip(levels[i] as usize + 1).any(|row| !row.is_empty()) {
+                return Err(format!("Node: {} has links above its layer", key).into());
+            }
             for l in 0..n_layers {
                 if let Some(layer) = nbrs.get(l) {
                     for nb in layer {
@@ -257,7 +358,7 @@ impl GpuIndex {
         }
         let ep = match &enterpoint {
             Some(key) => *idx.ids.get(key).ok_or_else(|| format!("Node: {} does not exist", key))? as i64,
-            None => return Ok(idx),
+            None => return Err(HNSWError::Str("an index with nodes has an enterpoint")),
         };
         let rp: Vec<*const u64> = row_ptr.iter().map(|r| r.as_ptr()).collect();
         let cl: Vec<*const u32> = col.iter().map(|c| c.as_ptr()).collect();
@@ -269,6 +370,8 @@ impl GpuIndex {
         }
         idx.names = nodes.into_iter().map(|x| Some(x.0)).collect();
         idx.levels = levels;
+        idx.pos_nodes = (0..n as u32).collect(); // ids follow IndexRedis.nodes
+        idx.pos_layer = pos_layer;
         Ok(idx)
     }
 }

@@ -63,6 +63,7 @@ SIGNATURES = {
     "hnsw_import": (C.c_int, [H, C.c_uint32, fp, u32p, C.c_int64, C.c_uint32, C.POINTER(u64p), C.POINTER(u32p)]),
     "hnsw_get_info": (C.c_int, [H, C.POINTER(Info)]),
     "hnsw_get_levels": (C.c_int, [H, u32p]),
+    "hnsw_get_level": (C.c_int, [H, C.c_uint32, u32p]),
     "hnsw_get_vector": (C.c_int, [H, C.c_uint32, fp]),
     "hnsw_get_neighbors": (C.c_int, [H, C.c_uint32, C.c_uint32, u32p, C.c_uint32, u32p]),
     "hnsw_layer_nnz": (C.c_int, [H, C.c_uint32, u64p]),

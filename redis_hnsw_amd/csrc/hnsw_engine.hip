@@ -991,7 +991,15 @@ hnsw_status hnsw_add(hnsw_index *h, const float *v, uint32_t dim, int32_t level,
     if (s != HNSW_OK) return s;
     if (touched && nt) {
         // the device list may repeat ids (the reference's `updated` is a HashSet, core.rs:522)
-        if (nt > h->touched_cap) return fail(h, HNSW_ERR_CAPACITY, "update_fn list overflow (the insert itself is complete)");
+        // The device list is sized for the operation's worst case before the kernel runs; should it overflow all
+        // the same, the INSERT IS COMPLETE: reporting an error would make every host mirror skip its name / id
+        // bookkeeping for a node the graph already holds.  The call succeeds and *n_touched = UINT32_MAX tells the
+        // caller that the list is unavailable (more than any buffer: it must treat every node as touched).
+        if (nt > h->touched_cap) {
+            h->err = "update_fn list overflow (the insert itself is complete)";
+            if (n_touched) *n_touched = 0xFFFFFFFFu;
+            return HNSW_OK;
+        }
         uint32_t have = std::min(nt, h->touched_cap);
         std::vector<uint32_t> tmp(have);
         if (h->h_ins && have <= h->ins_touched_have) {           // it came back with the header (add_exact)
@@ -1112,7 +1120,11 @@ hnsw_status hnsw_delete(hnsw_index *h, uint32_t id, uint32_t *touched, uint32_t 
     hnsw_status s = delete_exact(h, id, &nt);
     if (s != HNSW_OK) return s;
     if (touched && (nt || !h->purged_owners.empty())) {
-        if (nt > h->touched_cap) return fail(h, HNSW_ERR_CAPACITY, "update_fn list overflow (the delete itself is complete)");
+        if (nt > h->touched_cap) {                           // as in hnsw_add: the delete is complete, the list is not
+            h->err = "update_fn list overflow (the delete itself is complete)";
+            if (n_touched) *n_touched = 0xFFFFFFFFu;
+            return HNSW_OK;
+        }
         uint32_t have = std::min(nt, h->touched_cap);
         std::vector<uint32_t> tmp(have);
         if (have) {
@@ -1434,6 +1446,14 @@ hnsw_status hnsw_get_levels(hnsw_index *h, uint32_t *levels)
 {
     if (!h || !levels) return HNSW_ERR_INVALID;
     std::copy(h->h_levels.begin(), h->h_levels.begin() + h->n, levels);
+    return HNSW_OK;
+}
+
+hnsw_status hnsw_get_level(hnsw_index *h, uint32_t id, uint32_t *level)
+{
+    if (!h || !level) return HNSW_ERR_INVALID;
+    if (id >= h->n) return fail(h, HNSW_ERR_NOT_FOUND, "node id out of range");
+    *level = h->h_levels[id];
     return HNSW_OK;
 }
 

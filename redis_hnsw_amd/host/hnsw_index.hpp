@@ -85,10 +85,12 @@ public:
         std::vector<uint32_t> touched(update_fn ? 65536 : 0);
         check(hnsw_add(h_, data.data(), (uint32_t)data.size(), level, &id, update_fn ? touched.data() : nullptr,
                        (uint32_t)touched.size(), update_fn ? &nt : nullptr));
-        names_.push_back(node);
+        names_.push_back(node);                                        // the insert is complete whenever the status is OK
         ids_[node] = id;
+        if (update_fn && nt > touched.size())
+            throw HNSWError("update_fn list of " + std::to_string(nt) + " ids does not fit the buffer", HNSW_ERR_CAPACITY);
         if (update_fn)                                                 // core.rs:580-584
-            for (uint32_t i = 0; i < nt && i < touched.size(); ++i) update_fn(names_[touched[i]], touched[i]);
+            for (uint32_t i = 0; i < nt; ++i) update_fn(names_[touched[i]], touched[i]);
     }
 
     // delete_node(&mut self, name, update_fn)   core.rs:414-475
@@ -101,8 +103,10 @@ public:
         std::vector<uint32_t> touched(65536);
         check(hnsw_delete(h_, id, touched.data(), (uint32_t)touched.size(), &nt));
         ids_.erase(it);
+        if (update_fn && nt > touched.size())
+            throw HNSWError("update_fn list of " + std::to_string(nt) + " ids does not fit the buffer", HNSW_ERR_CAPACITY);
         if (update_fn)                                                 // core.rs:441-446
-            for (uint32_t i = 0; i < nt && i < touched.size(); ++i) update_fn(names_[touched[i]], touched[i]);
+            for (uint32_t i = 0; i < nt; ++i) update_fn(names_[touched[i]], touched[i]);
     }
     bool contains(const std::string &node) const { return ids_.count(node) != 0; }
 

@@ -303,6 +303,12 @@ class Index:
         self._ids = {nm: j for j, nm in enumerate(self._names) if nm is not None}
         return self
 
+    def level_of(self, i):
+        """top layer of node id i (the layer set core.rs:596 puts it in); O(1)"""
+        l = C.c_uint32(0)
+        self._check(self._lib.hnsw_get_level(self._h, int(i), C.byref(l)))
+        return int(l.value)
+
     def _vector(self, i):
         """the stored vector of node id i (hnsw_get_vector)"""
         out = np.zeros(self.data_dim, dtype=np.float32)

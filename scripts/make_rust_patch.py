@@ -50,11 +50,20 @@ cut("fn make_index(", "fn update_index(",
     "            .ok_or_else(|| format!(\"Node: {} does not exist\", node_name))?;\n"
     "        nodes.push((node_name.to_owned(), nr.data.clone(), nr.neighbors.clone()));\n"
     "    }\n"
-    "    GpuIndex::from_keys(&ir.name, ir.data_dim, ir.m, ir.ef_construction, nodes, ir.enterpoint.clone())\n"
+    "    // levels come from the layer sets and max_layer, as in the loop this replaces (src/lib.rs:287-299)\n"
+    "    GpuIndex::from_keys(&ir.name, ir.data_dim, ir.m, ir.ef_construction, nodes, &ir.layers, ir.max_layer,\n"
+    "                        ir.enterpoint.clone())\n"
     "        .map_err(|e| RedisError::String(e.error_string()))\n"
     "}\n\n")
-sub("            key.set_value::<IndexRedis>(&HNSW_INDEX_REDIS_TYPE, index.clone().into())?;",
-    "            key.set_value::<IndexRedis>(&HNSW_INDEX_REDIS_TYPE, index_redis_of(index))?;")
+# update_index: edit the stored value in place (one name appended / swap-removed + the header fields) instead of
+# re-serialising every name and layer set on every HNSW.NODE.ADD (src/lib.rs:322 `index.clone().into()`, O(N))
+sub("fn update_index(ctx: &Context, index_name: &str, index: &IndexT) -> Result<(), RedisError> {",
+    "fn update_index(ctx: &Context, index_name: &str, index: &mut IndexT) -> Result<(), RedisError> {")
+sub("        Some(_) => {\n            ctx.log_debug(format!(\"update index: {}\", index_name).as_str());\n"
+    "            key.set_value::<IndexRedis>(&HNSW_INDEX_REDIS_TYPE, index.clone().into())?;",
+    "        Some(ir) => {\n            ctx.log_debug(format!(\"update index: {}\", index_name).as_str());\n"
+    "            index.sync_redis(ir); // O(1) per command: GpuIndex::sync_redis")
+sub("    update_index(ctx, &index_name, &index)?;", "    update_index(ctx, &index_name, &mut index)?;", 2)
 # HNSW.NODE.ADD / HNSW.NODE.DEL: the update closure gets a view of the engine's node
 sub("    let up = |name: String, node: Node<f32>| {\n        write_node(ctx, &name, (&node).into()).unwrap();\n    };",
     "    let up = |name: String, node: NodeView| {\n        write_node(ctx, &name, node_redis_of(&node)).unwrap();\n    };", 2)

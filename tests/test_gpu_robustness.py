@@ -182,16 +182,23 @@ def test_snapshot_restored_engine_continues_like_the_oracle(eng, oracle_mod):
 
 def test_rust_shim_call_sequence_in_c(eng):
     """tests/cpp/shim_sequence.c: HNSW.NEW / NODE.ADD / NODE.DEL / SEARCH driven through the C ABI the way the
-    Rust shim of INTEGRATION.md does it, with a stand-in keyspace for the hnswnodet write-through."""
+    Rust shim of INTEGRATION.md does it, with a stand-in keyspace for the hnswnodet write-through -- a
+    REFERENCE-SHAPED one: a node promoted with l > l_max is saved with its pre-promotion rows only (core.rs:523),
+    the hnswindex value keeps each node in the set of its top layer (core.rs:596) and is edited per command the way
+    GpuIndex::sync_redis does it.  The index reloaded from that keyspace (levels from the layer sets, layer count
+    from max_layer, src/lib.rs:287-299) then takes three more multi-level adds and a delete and must hold the
+    oracle's rows, link for link, and give the oracle's answers."""
     import subprocess
     from redis_hnsw_amd import build
     exe = build.build_shim_test()
     import os
-    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "shim_sequence.txt")
-    r = subprocess.run([exe, golden], capture_output=True, text=True, timeout=300)
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    r = subprocess.run([exe, os.path.join(gdir, "shim_sequence.txt"), os.path.join(gdir, "shim_reload.txt")],
+                       capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     # every HNSW.SEARCH answer through the shim's sequence equals the CPU oracle's (names + similarity bits)
     assert "shim_sequence ok" in r.stdout and "60 answers equal to the oracle's golden file" in r.stdout
+    assert "every row and 20 answers equal to the oracle's after 3 more adds and a delete" in r.stdout
 
 
 def test_reference_rdb_layout_round_trip_through_the_engine(eng, oracle_mod):

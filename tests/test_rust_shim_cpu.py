@@ -109,7 +109,77 @@ def test_the_shim_uses_only_declared_entry_points_and_the_patch_is_well_formed()
     assert len(hunks) >= 8
     starts = [int(re.match(r"@@ -(\d+)", h).group(1)) for h in hunks]
     assert starts == sorted(starts)                                   # applies top to bottom
-    for fn in ("GpuIndex::new(", "GpuIndex::from_keys(", "index_redis_of(", "node_redis_of("):
+    for fn in ("GpuIndex::new(", "GpuIndex::from_keys(", "index_redis_of(", "node_redis_of(", "index.sync_redis(ir)"):
         assert any(l.startswith("+") and fn in l for l in diff), fn
     for f in ("build.rs", "Cargo.toml.diff", "README.md"):
         assert os.path.exists(os.path.join(RUST, f))
+
+
+def _rust_fn_body(text, signature_start):
+    """the brace-balanced body of the fn whose text starts with `signature_start`"""
+    a = text.index(signature_start)
+    # the first '{' after the parameter list closes is the body
+    depth_par, j = 0, a
+    while True:
+        c = text[j]
+        if c == "(":
+            depth_par += 1
+        elif c == ")":
+            depth_par -= 1
+            if depth_par == 0:
+                break
+        j += 1
+    i = text.index("{", j)
+    depth, k = 0, i
+    while True:
+        if text[k] == "{":
+            depth += 1
+        elif text[k] == "}":
+            depth -= 1
+            if depth == 0:
+                return text[i:k + 1]
+        k += 1
+
+
+def _no_comments(body):
+    return re.sub(r"//.*", "", body)
+
+
+def test_the_shim_keeps_the_reference_s_layer_sets_and_reload_semantics():
+    """What a reference-written keyspace needs from the shim, checked on the Rust text (no cargo here; the same logic
+    runs in C under -m gpu, tests/cpp/shim_sequence.c):
+      * layers(): a node goes into the set of its TOP layer only (core.rs:596, src/types.rs:73-82) -- round 3's
+        text pushed it into every set 0..=l;
+      * from_keys(): levels come from IndexRedis.layers and the layer count from IndexRedis.max_layer
+        (src/lib.rs:287-299), never from a node's row count (a promoted node is saved with fewer rows than
+        level + 1, core.rs:523, 587-593);
+      * update_index is O(1): sync_redis edits the stored value, it does not rebuild it."""
+    gpu = open(os.path.join(RUST, "src", "hnsw", "gpu_index.rs")).read()
+    layers = _no_comments(_rust_fn_body(gpu, "pub fn layers(&self)"))
+    assert "out[self.levels[id] as usize].push(n.clone())" in layers
+    assert "take(" not in layers and "0..=" not in layers and "for layer in" not in layers
+    fk = _no_comments(_rust_fn_body(gpu, "pub fn from_keys("))
+    sig = gpu[gpu.index("pub fn from_keys("):gpu.index("-> Result<Self, HNSWError>", gpu.index("pub fn from_keys("))]
+    assert "layers: &[Vec<String>]" in sig and "max_layer: usize" in sig
+    assert "nbrs.len()" not in fk and ".len().max(1)" not in fk          # round 3: levels[i] = nbrs.len().max(1) - 1
+    assert re.search(r"for \(l, set\) in layers\.iter\(\)\.enumerate\(\)", fk) and "levels[i] = l as u32" in fk
+    assert "is in no layer set" in fk
+    assert re.search(r"let n_layers = \(max_layer \+ 1\)", fk)
+    assert "ffi::hnsw_import(" in fk and "levels.as_ptr()" in fk
+    # the per-command path is O(1): one level looked up, one name appended / swap-removed
+    add = _no_comments(_rust_fn_body(gpu, "pub fn add_node(&mut self"))
+    assert "ffi::hnsw_get_level(" in add and "hnsw_get_levels" not in add
+    assert add.index("self.names.push(") < add.index("does not fit the buffer")   # bookkeeping before any late error
+    sync = _no_comments(_rust_fn_body(gpu, "pub fn sync_redis(&mut self"))
+    assert "swap_remove" in sync and "ir.nodes.push(" in sync and ".collect()" not in sync and "for (id, name)" not in sync
+    assert "ir.layers[l].push(name)" in sync and "ir.layers.truncate(" in sync
+    # the lib.rs patch hands the layer sets through and no longer re-serialises the index per command
+    diff = open(os.path.join(RUST, "lib_rs.diff")).read()
+    assert "&ir.layers, ir.max_layer" in diff
+    upd = diff[diff.index("+fn update_index("):]
+    upd = upd[:upd.index("@@")]
+    assert "index.sync_redis(ir)" in upd and "+            key.set_value" not in upd
+    assert diff.count("update_index(ctx, &index_name, &mut index)?;") == 2
+    # readers share one engine handle: the FFI search is serialised inside GpuIndex (the header's one-caller rule)
+    search = _no_comments(_rust_fn_body(gpu, "pub fn search_knn(&self"))
+    assert "self.search_lock.lock()" in search and search.index("search_lock.lock()") < search.index("ffi::hnsw_search(")
