@@ -837,7 +837,8 @@ hnsw_status hnsw_create(uint32_t dim, uint32_t m, uint32_t ef_construction, uint
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(h, HNSW_ERR_DEVICE, "no HIP device: this engine has no CPU path");
     if (device < 0 || device >= ndev) return fail(h, HNSW_ERR_DEVICE, "bad device ordinal");
-    HIP_TRY(h, hipSetDevice(device));
+    DeviceScope dev_scope_(device);
+    HIP_TRY(h, dev_scope_.err);
     hipDeviceProp_t prop;
     HIP_TRY(h, hipGetDeviceProperties(&prop, device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !std::getenv("HNSW_ALLOW_ANY_ARCH"))
@@ -872,10 +873,8 @@ hnsw_status hnsw_create(uint32_t dim, uint32_t m, uint32_t ef_construction, uint
 void hnsw_destroy(hnsw_index *h)
 {
     if (!h) return;
-    if (h->stream) {
-        (void)hipSetDevice(h->device);
-        (void)hipStreamSynchronize(h->stream);
-    }
+    DeviceScope dev_scope_(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->d_vec); (void)hipFree(h->d_adj0); (void)hipFree(h->d_adjU);
     (void)hipFree(h->d_upper_base); (void)hipFree(h->d_levels); (void)hipFree(h->d_hdr);
     (void)hipFree(h->d_spill); (void)hipFree(h->d_spill_one); (void)hipFree(h->d_Q); (void)hipFree(h->d_res);
@@ -906,7 +905,7 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
 {
     if (!h || !key) return HNSW_ERR_INVALID;
     if (!std::strcmp(key, "force_restride")) {   // tests: widen both adjacency tables by `value` words now
-        HIP_TRY(h, hipSetDevice(h->device));
+        ON_DEVICE(h);
         return restride(h, h->stride0 + (uint32_t)value, h->strideU + (uint32_t)value);
     }
     if (!std::strcmp(key, "tag_table")) { h->tag_table = value != 0; return HNSW_OK; }
@@ -933,7 +932,7 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
         if (!value || h->fmt == want) return HNSW_OK;
         if (h->fmt) return fail(h, HNSW_ERR_INVALID, "the index is already compressed (the original vectors are gone)");
         if (h->mode != MODE_AVX) return fail(h, HNSW_ERR_INVALID, std::string(key) + " needs dim % 32 == 0 (the AVX2 summation order, metrics.rs:18)");
-        HIP_TRY(h, hipSetDevice(h->device));
+        ON_DEVICE(h);
         HIP_TRY(h, hipDeviceSynchronize());
         const size_t nel = (size_t)h->cap * h->dim, esz = want == FMT_BF16 ? 2 : 1;
         void *dnew = nullptr;
@@ -985,7 +984,7 @@ hnsw_status hnsw_add(hnsw_index *h, const float *v, uint32_t dim, int32_t level,
         return fail(h, HNSW_ERR_DIM_MISMATCH, buf);
     }
     if (!all_finite(v, dim)) return fail(h, HNSW_ERR_INVALID, "non-finite vector component");
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     uint32_t nt = 0;
     hnsw_status s = add_exact(h, v, nullptr, level, out_id, touched != nullptr, &nt);
     if (s != HNSW_OK) return s;
@@ -1031,7 +1030,7 @@ hnsw_status hnsw_add_batch(hnsw_index *h, const float *V, uint32_t n, uint32_t d
     if (n == 0) return HNSW_OK;
     if (mode > 1) return fail(h, HNSW_ERR_INVALID, "mode must be 0 (exact) or 1 (fast)");
     if (!all_finite(V, (size_t)n * dim)) return fail(h, HNSW_ERR_INVALID, "non-finite vector component");
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     hnsw_status s;
     uint32_t done = 0;
     // exact inserts: all of them (mode 0) or the seed prefix of the fast build.  Large exact batches go
@@ -1115,7 +1114,7 @@ hnsw_status hnsw_delete(hnsw_index *h, uint32_t id, uint32_t *touched, uint32_t 
         snprintf(buf, sizeof buf, "Node: %u does not exist", id);
         return fail(h, HNSW_ERR_NOT_FOUND, buf);
     }
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     uint32_t nt = 0;
     hnsw_status s = delete_exact(h, id, &nt);
     if (s != HNSW_OK) return s;
@@ -1153,7 +1152,7 @@ hnsw_status hnsw_search_batch_device(hnsw_index *h, const float *dQ, uint32_t B,
     }
     if (B == 0) return HNSW_OK;
     if (k == 0) return fail(h, HNSW_ERR_INVALID, "k must be >= 1");
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     hipStream_t st = (hipStream_t)stream;
     hnsw_status s0 = ensure_spill(h);
     if (s0 != HNSW_OK) return s0;
@@ -1186,7 +1185,7 @@ hnsw_status hnsw_search_batch(hnsw_index *h, const float *Q, uint32_t B, uint32_
     }
     if (B == 0) return HNSW_OK;
     if (k == 0) return fail(h, HNSW_ERR_INVALID, "k must be >= 1");
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     if (h->n == h->n_dead || h->enterpoint < 0) {
         if (!all_finite(Q, (size_t)B * dim)) return fail(h, HNSW_ERR_INVALID, "non-finite query component");
         for (uint32_t b = 0; b < B; ++b) n_out[b] = 0;
@@ -1233,7 +1232,7 @@ hnsw_status hnsw_import(hnsw_index *h, uint32_t n, const float *vectors, const u
     if (n == 0) return HNSW_OK;
     if (enterpoint < 0 || enterpoint >= (int64_t)n || n_layers == 0 || n_layers > kMaxLayers)
         return fail(h, HNSW_ERR_INVALID, "bad enterpoint / layer count");
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     // Validate everything before any state changes: the blob may come from a file.
     if (!vectors || !levels || !row_ptr || !col) return fail(h, HNSW_ERR_INVALID, "null argument");
     for (uint32_t i = 0; i < n; ++i)
@@ -1331,7 +1330,7 @@ hnsw_status hnsw_import(hnsw_index *h, uint32_t n, const float *vectors, const u
 hnsw_status hnsw_replica_view(hnsw_index *h, hnsw_replica *out)
 {
     if (!h || !out) return HNSW_ERR_INVALID;
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));          // everything the engine enqueued has landed
     std::memset(out, 0, sizeof *out);
     out->n = h->n; out->dim = h->dim; out->upper_used = h->upper_used;
@@ -1356,7 +1355,7 @@ hnsw_status hnsw_replica_prepare(hnsw_index *h, hnsw_replica *r)
         r->stride0 < h->stride0 || r->stride_upper < h->strideU || r->stride0 > kAuxWords || r->stride_upper > kAuxWords ||
         (r->stride0 & 15) || (r->stride_upper & 15) || r->max_degree0 >= r->stride0 || r->max_degree_upper >= r->stride_upper)
         return fail(h, HNSW_ERR_INVALID, "replica: inconsistent header (the source must have the same M)");
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     hnsw_status s;
     if ((s = restride(h, r->stride0, r->stride_upper)) != HNSW_OK) return s;      // the source's row layout
     if ((s = ensure_node_cap(h, r->n)) != HNSW_OK) return s;
@@ -1394,7 +1393,7 @@ hnsw_status hnsw_replica_commit(hnsw_index *h, const hnsw_replica *r, const uint
         r->stride_upper != h->strideU || r->n == 0 || r->n > h->cap || r->upper_used > h->upper_cap)
         return fail(h, HNSW_ERR_INVALID, "hnsw_replica_commit: not the block hnsw_replica_prepare returned");
     if (r->n_dead && !dead) return fail(h, HNSW_ERR_INVALID, "hnsw_replica_commit: tombstones missing");
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIP_TRY(h, hipDeviceSynchronize());                   // whoever filled the tables (a collective's stream) is done
     // the host mirrors the engine keeps: levels, upper slots, tombstones
     h->h_levels.assign(h->cap, 0);
@@ -1461,7 +1460,7 @@ hnsw_status hnsw_get_vector(hnsw_index *h, uint32_t id, float *out)
 {
     if (!h || !out) return HNSW_ERR_INVALID;
     if (id >= h->n) return fail(h, HNSW_ERR_NOT_FOUND, "node id out of range");
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     if (h->fmt) {                                    // the stored (rounded) values, widened by the search kernels' own code
         DevScratch<float> row;
         HIP_TRY(h, row.alloc(h->dim));
@@ -1487,7 +1486,7 @@ hnsw_status hnsw_get_neighbors(hnsw_index *h, uint32_t id, uint32_t layer, uint3
     if (id >= h->n) return fail(h, HNSW_ERR_NOT_FOUND, "node id out of range");
     *n = 0;
     if (layer > h->h_levels[id]) return HNSW_OK; // push_levels: rows above the level are empty
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     const uint32_t stride = layer ? h->strideU : h->stride0;
     const uint32_t *row = layer ? h->d_adjU + (size_t)(h->h_upper_base[id] + layer - 1) * stride
                                 : h->d_adj0 + (size_t)id * stride;
@@ -1522,7 +1521,7 @@ static hnsw_status layer_degrees(hnsw_index *h, uint32_t layer, std::vector<uint
 hnsw_status hnsw_layer_nnz(hnsw_index *h, uint32_t layer, uint64_t *nnz)
 {
     if (!h || !nnz) return HNSW_ERR_INVALID;
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     std::vector<uint32_t> deg;
     hnsw_status s = layer_degrees(h, layer, deg);
     if (s != HNSW_OK) return s;
@@ -1535,7 +1534,7 @@ hnsw_status hnsw_layer_nnz(hnsw_index *h, uint32_t layer, uint64_t *nnz)
 hnsw_status hnsw_export_layer(hnsw_index *h, uint32_t layer, uint64_t *row_ptr, uint32_t *col)
 {
     if (!h || !row_ptr) return HNSW_ERR_INVALID;
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     std::vector<uint32_t> deg;
     hnsw_status s = layer_degrees(h, layer, deg);
     if (s != HNSW_OK) return s;
@@ -1597,7 +1596,7 @@ hnsw_status hnsw_serialize(hnsw_index *h, void *buf, uint64_t cap, uint64_t *wri
     hnsw_status s = hnsw_serialize_size(h, &need);
     if (s != HNSW_OK) return s;
     if (cap < need) return fail(h, HNSW_ERR_INVALID, "snapshot buffer too small");
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     unsigned char *p = static_cast<unsigned char *>(buf);
     SnapHeader hd;
     std::memset(&hd, 0, sizeof hd);
@@ -1698,7 +1697,7 @@ hnsw_status hnsw_deserialize(const void *buf, uint64_t bytes, uint64_t seed, int
 hnsw_status hnsw_get_counters(hnsw_index *h, hnsw_counters *search, hnsw_counters *insert)
 {
     if (!h) return HNSW_ERR_INVALID;
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     DevHeader hd;
     HIP_TRY(h, hipMemcpy(&hd, h->d_hdr, sizeof hd, hipMemcpyDeviceToHost));
     if (search) { search->n_dist = hd.ctr_search[0]; search->n_ids = hd.ctr_search[1]; search->n_expand = hd.ctr_search[2]; search->n_spill = hd.ctr_search[3]; }
@@ -1709,7 +1708,7 @@ hnsw_status hnsw_get_counters(hnsw_index *h, hnsw_counters *search, hnsw_counter
 hnsw_status hnsw_reset_counters(hnsw_index *h)
 {
     if (!h) return HNSW_ERR_INVALID;
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIP_TRY(h, hipDeviceSynchronize());
     HIP_TRY(h, hipMemset((char *)h->d_hdr + offsetof(DevHeader, ctr_search), 0, sizeof(unsigned long long) * 16));
     return HNSW_OK;
@@ -1739,7 +1738,7 @@ hnsw_status hnsw_debug_occ_causes(hnsw_index *h, uint64_t *out8)
 hnsw_status hnsw_debug_phase_cycles(hnsw_index *h, uint64_t *out8)
 {
     if (!h || !out8) return HNSW_ERR_INVALID;
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     DevHeader hd;
     HIP_TRY(h, hipMemcpy(&hd, h->d_hdr, sizeof hd, hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; ++i) out8[i] = hd.prof[i];
@@ -1754,7 +1753,7 @@ __attribute__((constructor)) static void hnsw_library_loaded() { (void)setenv("G
 hnsw_status hnsw_pipeline_info(hnsw_index *h, hnsw_pipeline *out)
 {
     if (!h || !out) return HNSW_ERR_INVALID;
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     hnsw_status s = ensure_pipe(h);
     out->lanes = hnsw_index::kPipe;
     out->overlap = h->pipe_overlap;
@@ -1786,7 +1785,7 @@ hnsw_status hnsw_last_search_kernel_ms(hnsw_index *h, float *ms)
 {
     if (!h || !ms) return HNSW_ERR_INVALID;
     if (!h->ev_valid) return fail(h, HNSW_ERR_INVALID, "no timed search launch yet (hnsw_set_tuning(\"time_launches\", 1) first)");
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIP_TRY(h, hipEventSynchronize(h->ev1));
     HIP_TRY(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
     return HNSW_OK;
@@ -1796,7 +1795,8 @@ hnsw_status hnsw_metric_pairs(int device, const float *a, const float *b, uint32
 {
     if (!a || !b || !sims || dim == 0) return HNSW_ERR_INVALID;
     if (n == 0) return HNSW_OK;
-    if (hipSetDevice(device) != hipSuccess) return HNSW_ERR_DEVICE;
+    DeviceScope dev_scope_(device);
+    if (dev_scope_.err != hipSuccess) return HNSW_ERR_DEVICE;
     float *da = nullptr, *db = nullptr, *ds = nullptr;
     size_t bytes = (size_t)n * dim * 4;
     auto release = [&] { (void)hipFree(da); (void)hipFree(db); (void)hipFree(ds); };

@@ -112,6 +112,21 @@ hnsw_status gfail(hnsw_group *g, hnsw_status s, const std::string &msg)
     return s;
 }
 
+// set the current device for a scope and put the caller's back (this file sits above the C ABI and shares nothing
+// with the engine's translation units)
+struct DeviceScope {
+    int prev = -1, dev;
+    explicit DeviceScope(int d) : dev(d)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); }
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceScope()
+    {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+};
+
 int device_of(hnsw_index *h, const hnsw_replica &view)
 {
     // the device a member's tables live on, from the tables themselves
@@ -137,7 +152,11 @@ hnsw_status make_replica(hnsw_group *g, int dev, uint64_t seed, hnsw_index **out
     hnsw_index *p = g->member[0];
     hnsw_index *r = nullptr;
     hnsw_status s = hnsw_create(g->info.dim, g->info.m, g->info.ef_construction, seed, dev, &r);
-    if (s != HNSW_OK) return gfail(g, s, std::string("group: hnsw_create on device ") + std::to_string(dev) + ": " + (r ? hnsw_last_error(r) : "no handle"));
+    if (s != HNSW_OK) {                                // hnsw_create hands a handle back even when it fails (for the message)
+        const std::string why = r ? hnsw_last_error(r) : "no handle";
+        hnsw_destroy(r);
+        return gfail(g, s, std::string("group: hnsw_create on device ") + std::to_string(dev) + ": " + why);
+    }
     hnsw_replica src;
     if ((s = hnsw_replica_view(p, &src)) != HNSW_OK) { g->err = hnsw_last_error(p); hnsw_destroy(r); return s; }
     if (src.n) {
@@ -146,8 +165,8 @@ hnsw_status make_replica(hnsw_group *g, int dev, uint64_t seed, hnsw_index **out
             // direct xGMI copies when the devices can reach each other (hipMemcpyPeer stages through the host otherwise)
             int can = 0;
             if (hipDeviceCanAccessPeer(&can, dev, pdev) == hipSuccess && can) {
-                (void)hipSetDevice(dev);
-                (void)hipDeviceEnablePeerAccess(pdev, 0);
+                DeviceScope on_dev(dev);                    // peer access is enabled from the device that reads; the caller's
+                (void)hipDeviceEnablePeerAccess(pdev, 0);   // current device is put back when the scope ends
             }
             (void)hipGetLastError();
         }
@@ -273,7 +292,10 @@ hnsw_status hnsw_group_refresh(hnsw_group *g)
         if ((s = make_replica(g, g->device[i], g->seed + 1 + i, &r)) != HNSW_OK) {
             // keep the group usable: an empty stand-in that check_in_step() will report as behind
             g->diverged = true;
-            (void)hnsw_create(g->info.dim, g->info.m, g->info.ef_construction, g->seed, g->device[i], &g->member[i]);
+            if (hnsw_create(g->info.dim, g->info.m, g->info.ef_construction, g->seed, g->device[i], &g->member[i]) != HNSW_OK) {
+                hnsw_destroy(g->member[i]);                 // no half-initialised member: hnsw_group_member() hands out NULL,
+                g->member[i] = nullptr;                     // and every group call refuses until a refresh succeeds
+            }
             return s;
         }
         g->member[i] = r;

@@ -143,6 +143,27 @@ namespace hnsw_host {
 
 using namespace hnsw;
 
+// Every C-ABI entry runs on its index's device and leaves the calling thread's current HIP device as it found it
+// (a Redis module shares its threads with whatever else the process does with HIP).
+struct DeviceScope {
+    int prev = -1, dev;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int d) : dev(d)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); }
+        if (prev != dev) err = hipSetDevice(dev);
+    }
+    ~DeviceScope()
+    {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+#define ON_DEVICE(h)                       \
+    DeviceScope dev_scope_((h)->device);   \
+    HIP_TRY(h, dev_scope_.err)
+
 #define HIP_TRY(h, expr)                                                                       \
     do {                                                                                       \
         hipError_t e_ = (expr);                                                                \

@@ -424,7 +424,16 @@ __global__ __launch_bounds__(64, 1) void k_occ_shrinks(GraphView g, OccBufs ob, 
     const uint32_t nS = select_topm<MODE, T>(g, m, vis, qe, m.W, nE, e, mmax, lc, nolog, lane, fail, del_id); // :568 / :853
     if (vis.glob_dirty) visited_clear(vis, lane);
     if (fail || (nS == 0 && del_id == kEmpty)) { if (lane == 0) sl->fail = 1; return; }
-    if (nS == 0) return;                                     // an empty re-selection: the commit computes it itself
+    if (nS == 0) {
+        // an empty re-selection: the commit computes it itself.  Its share of the read log is hashed with the rest
+        // (k_occ_del_list counts the whole range), so it must not keep entries of an earlier operation: they could
+        // flag unrelated re-selections stale -- harmless for the graph (a stale one is recomputed), but the
+        // speculation's yield and the counters would depend on history.  Row kEmpty matches no journal entry.
+        const OccRead none = OccRead{kEmpty, occ_meta(0, OCC_SHRINK_NB, k, true), 0u};
+        for (uint32_t i = lane; i < tot + 1; i += 64)
+            if (log0 + i < kOccMaxReads) reads[log0 + i] = none;
+        return;
+    }
     if (lane == 0) { sp->w_dist = nolog.n_dist; sp->w_ids = nolog.n_ids; }
     const uint32_t bound = (uint32_t)(m.S[nS - 1] >> 32);
     for (uint32_t i = lane; i < nS; i += 64) sp->S[i] = key_id(m.S[i]);
