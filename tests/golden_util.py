@@ -7,7 +7,35 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def golden_cases():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    """goldens written by the C oracle itself (make_golden.py): they pin stability"""
+    return sorted(n for n in (os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+                  if not n.startswith("transcribed_"))
+
+
+def transcribed_cases():
+    """goldens written by the Python transcription of core.rs (tests/transcription/): they pin FIDELITY -- nothing the
+    oracle or the engine computed went into them"""
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "transcribed_*.npz")))
+
+
+def load_transcribed(name):
+    """-> the case with its inputs regenerated from SURVEY 8d's seeds (vectors default_rng(1), queries default_rng(2),
+    levels floor(-ln U / ln M) from default_rng(7), node 0 at level 0), as make_transcribed_golden.py drew them"""
+    import json
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    n, dim, m, ef, k, nq = [int(x) for x in z["params"]]
+    V = np.random.default_rng(1).random((n, dim), dtype=np.float32)
+    Q = np.random.default_rng(2).random((nq, dim), dtype=np.float32)
+    u = np.maximum(np.random.default_rng(7).random(n), np.finfo(np.float64).tiny)
+    lv = np.floor(-np.log(u) * (1.0 / np.log(float(m)))).astype(np.int64)
+    lv[0] = 0
+    lv = np.minimum(lv, 31).astype(np.int32)
+    L = int(z["max_layer"]) + 1
+    g = dict(levels=lv.astype(np.uint32), enterpoint=int(z["enterpoint"]), max_layer=int(z["max_layer"]),
+             row_ptr=[z["row_ptr_%d" % l] for l in range(L)], col=[z["col_%d" % l] for l in range(L)])
+    return dict(n=n, dim=dim, m=m, ef=ef, k=k, V=V, Q=Q, levels=lv, graph=g, ids=z["ids"], sims_bits=z["sims_bits"],
+                n_out=z["n_out"], search_counters=z["search_counters"], insert_counters=z["insert_counters"],
+                stats=json.loads(bytes(z["stats"]).decode()))
 
 
 def load_golden(name):

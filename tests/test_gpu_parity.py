@@ -450,7 +450,7 @@ def test_cpp_host_mirror_runs_reference_tests():
 
 
 # ---- committed golden vectors -------------------------------------------------------
-from tests.golden_util import golden_cases, load_golden  # noqa: E402
+from tests.golden_util import golden_cases, load_golden, load_transcribed, transcribed_cases  # noqa: E402
 
 
 @pytest.mark.parametrize("name", golden_cases())
@@ -470,6 +470,30 @@ def test_engine_reproduces_golden(eng, name):
     ids, sims, n_out = gi.search_batch(c["Q"], c["k"])
     assert np.array_equal(ids, c["ids"]) and np.array_equal(_bits(sims), c["sims_bits"])
     assert np.array_equal(n_out, c["n_out"])
+    sc, _ = gi.counters()
+    assert [sc.n_dist, sc.n_ids, sc.n_expand] == c["search_counters"].tolist()
+    gi.close()
+
+
+@pytest.mark.parametrize("name", transcribed_cases())
+def test_engine_reproduces_the_transcription(eng, name):
+    """The independent witness (tests/transcription/: core.rs transcribed into Python, nothing of the oracle in it):
+    HNSW.NODE.ADD on the GPU builds the transcription's graph row for row -- through the windowed batch form AND, for
+    a prefix, one hnsw_add per call -- and HNSW.SEARCH gives its ids, similarity bits and work counters."""
+    c = load_transcribed(name)
+    gi = eng.Index("t", c["dim"], c["m"], c["ef"])
+    gi.set_tuning("select_shortcut", 0)              # the reference's full select_neighbors: its counters are the file's
+    n_single = 300
+    for i in range(n_single):                        # the command's shape (src/lib.rs:356)
+        gi.add_node("node%d" % i, c["V"][i], level=int(c["levels"][i]))
+    gi.add_batch(c["V"][n_single:], names=["node%d" % i for i in range(n_single, c["n"])],
+                 levels=c["levels"][n_single:], mode="exact")
+    ok, why = graphs_equal(c["graph"], gi.export_graph())
+    assert ok, why
+    gi.reset_counters()
+    ids, sims, n_out = gi.search_batch(c["Q"], c["k"])
+    assert np.array_equal(n_out, c["n_out"]) and np.array_equal(ids, c["ids"])
+    assert np.array_equal(_bits(sims), c["sims_bits"])
     sc, _ = gi.counters()
     assert [sc.n_dist, sc.n_ids, sc.n_expand] == c["search_counters"].tolist()
     gi.close()
