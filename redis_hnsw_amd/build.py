@@ -19,6 +19,7 @@ _COMMON = ["hnsw_host.hpp", "hnsw_device.hpp", "hnsw_insert.hpp", "hnsw_occ.hpp"
 UNITS = [
     ("hnsw_engine.hip", [None], ["hnsw_kernels.hpp", "hnsw_search_lean.hpp", "hnsw_plan_lean.hpp", "hnsw_insert_host.inc"]),
     ("hnsw_tu_lean.hip", [0, 1, 2, 3, 4, 5], ["hnsw_search_lean.hpp"]),
+    ("hnsw_tu_duo.hip", [0, 1], ["hnsw_search_lean.hpp", "hnsw_search_duo.hpp"]),
     ("hnsw_tu_search.hip", [0, 1, 2, 3, 4, 5], ["hnsw_kernels.hpp"]),
     ("hnsw_tu_insert.hip", [0, 1, 2, 3], []),
     ("hnsw_tu_occ.hip", [0, 1, 2, 3], []),

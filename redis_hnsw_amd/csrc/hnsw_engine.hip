@@ -453,6 +453,14 @@ hnsw_status try_launch_lean(hnsw_index *h, const float *dQ, uint32_t B, uint32_t
         else return HNSW_OK;
     }
     const bool wide = h->stride0 > 64 || h->strideU > 64;   // rows of 64..127 ids: two row words per lane
+    h->last_search_duo = false;
+    if (h->duo && h->fmt == FMT_F32 && (uint64_t)B * std::max(h->cur_conc, 1u) <= h->duo_max && idbits - 11 <= 14) {
+        // few enough queries in flight that each can have two SIMDs: a walker wave and a W-keeper wave per query
+        const uint32_t db2 = idbits - 11 > 13 ? 2u : 3u;
+        hnsw_status s2 = wide ? launch_duo_v<true>(h, R, db2, dQ, B, k, idbits, d_ids, d_sims, d_nout, st, done)
+                              : launch_duo_v<false>(h, R, db2, dQ, B, k, idbits, d_ids, d_sims, d_nout, st, done);
+        if (s2 != HNSW_OK || *done) { h->last_search_duo = *done; return s2; }
+    }
 #define LEAN_GO(VEC)                                                                                                          \
     return wide ? launch_lean_v<VEC, true>(h, R, bb, db, dQ, B, k, idbits, per_cu, d_ids, d_sims, d_nout, st, done)          \
                 : launch_lean_v<VEC, false>(h, R, bb, db, dQ, B, k, idbits, per_cu, d_ids, d_sims, d_nout, st, done)
@@ -960,6 +968,8 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
     if (!std::strcmp(key, "occ_log_cap")) { h->occ_log_cap = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), kOccMaxReads); return HNSW_OK; }
     if (!std::strcmp(key, "occ_min_batch")) { h->occ_min_batch = (uint32_t)std::max<int64_t>(value, 1); return HNSW_OK; }
     if (!std::strcmp(key, "lean")) { h->lean = value != 0; return HNSW_OK; }
+    if (!std::strcmp(key, "duo")) { h->duo = value != 0; return HNSW_OK; }
+    if (!std::strcmp(key, "duo_max")) { h->duo_max = (uint32_t)std::max<int64_t>(value, 0); return HNSW_OK; }
     if (!std::strcmp(key, "grid_stride")) { h->grid_stride = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "query_in_lds")) {     // dims 128 / 768 normally keep the query in registers (T = dim/32)
         if (h->mode == MODE_AVX && !h->fmt) h->T = value ? 0 : ((h->dim == 128 || h->dim == 768) ? (int)(h->dim / 32) : 0);
@@ -1770,7 +1780,7 @@ hnsw_status hnsw_pipeline_info(hnsw_index *h, hnsw_pipeline *out)
 hnsw_status hnsw_debug_last_search_path(hnsw_index *h, uint32_t *lean)
 {
     if (!h || !lean) return HNSW_ERR_INVALID;
-    *lean = h->last_search_lean ? 1u : 0u;
+    *lean = (h->last_search_lean ? 1u : 0u) | (h->last_search_duo ? 2u : 0u);   // bit 1: its two-wave form
     return HNSW_OK;
 }
 

@@ -123,6 +123,9 @@ struct hnsw_index {
     bool select_shortcut = true;     // select_neighbors after search_level = the head of W (hnsw_insert.hpp); 0 = the full extension
     bool plan_lean = true;           // dim-128 insert plans (single adds, the windowed exact build) search with the specialised routine (hnsw_plan_lean.hpp)
     bool lean = true;                // dim-128 searches use the specialised kernel (hnsw_search_lean.hpp) when its preconditions hold
+    bool duo = true;                 // ... in its two-wave form (hnsw_search_duo.hpp) when at most duo_max queries are in flight
+    uint32_t duo_max = 1024;         // 4 workgroups of two waves per CU: every query gets two SIMD slots
+    bool last_search_duo = false;
     size_t lds_reserve = 0;          // LDS a kernel needs besides the wave's own share (the OCC kernels' validation scratch)
     bool grid_stride = false;        // specialised kernel: cap the grid at the resident waves and walk the batch grid-stride (tuning, for comparison)
     bool visited_bounded = true;     // k_search: a full LDS visited table stops recording (exact results)
@@ -241,6 +244,10 @@ template <class VEC, bool WIDE>
 hnsw_status launch_lean_v(hnsw_index *h, int R, uint32_t bb, uint32_t db, const float *dQ, uint32_t B, uint32_t k,
                           uint32_t idbits, uint32_t per_cu, uint32_t *d_ids, float *d_sims, uint32_t *d_nout,
                           hipStream_t st, bool *done);
+// hnsw_tu_duo.hip: the two-wave form (a walker and a W-keeper wavefront per query, hnsw_search_duo.hpp), f32 rows
+template <bool WIDE>
+hnsw_status launch_duo_v(hnsw_index *h, int R, uint32_t db, const float *dQ, uint32_t B, uint32_t k, uint32_t idbits,
+                         uint32_t *d_ids, float *d_sims, uint32_t *d_nout, hipStream_t st, bool *done);
 // hnsw_tu_insert.hip
 template <int MODE, int T>
 hnsw_status launch_insert_r(hnsw_index *h, const InsertCfg &c, bool plan, uint32_t first, uint32_t count);

@@ -215,7 +215,15 @@ class Index:
         f.restype, f.argtypes = C.c_int, [_capi.H, _capi.u32p]
         v = C.c_uint32(0)
         self._check(f(self._h, C.byref(v)))
-        return bool(v.value)
+        return bool(v.value & 1)
+
+    def last_search_was_duo(self):
+        """development aid: did the latest search launch use the two-wave form (a walker and a W-keeper wave per query)"""
+        f = self._lib.hnsw_debug_last_search_path
+        f.restype, f.argtypes = C.c_int, [_capi.H, _capi.u32p]
+        v = C.c_uint32(0)
+        self._check(f(self._h, C.byref(v)))
+        return bool(v.value & 2)
 
     def lean_blocker(self):
         """development aid: why the specialised dim-128 kernel cannot serve this index ('' = it can)"""

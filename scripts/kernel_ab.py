@@ -71,6 +71,18 @@ for i in range(3):
     got_s = outs[i][1][7:39].cpu().numpy().view(np.uint32)
     ok = ok and np.array_equal(got_i, want[0]) and np.array_equal(got_s, want[1].view(np.uint32))
 print("parity (96 queries, ids + sim bits):", ok)
+# the lone launch's shape (two waves per query when "duo" is on): all 1024 answers and the work counters
+ix.reset_counters()
+launch(0, 0)
+torch.cuda.synchronize()
+was_duo = ix.last_search_was_duo()
+sc, _ = ix.counters()
+want = o.search_batch(Q[:B], k, threads=8)
+ok1 = (np.array_equal(outs[0][0][:B].cpu().numpy().view(np.uint32), want[0])
+       and np.array_equal(outs[0][1][:B].cpu().numpy().view(np.uint32), want[1].view(np.uint32))
+       and np.array_equal(outs[0][2][:B].cpu().numpy().view(np.uint32), want[2]))
+print("lone launch: two-wave form %s, 1024 answers identical: %s, counters (dist, ids, expand) %s oracle %s" % (
+    was_duo, ok1, [sc.n_dist, sc.n_ids, sc.n_expand], [want[3].n_dist, want[3].n_ids, want[3].n_expand]))
 # C1
 n1, m1 = 10_000, 5
 lv1 = draw_levels(n1, m1, 7)
@@ -78,6 +90,9 @@ o1 = oracle.OracleIndex(dim, m1, ef)
 o1.add_batch(V[:n1], lv1)
 g1 = Index("c1", dim, m1, ef)
 g1.import_graph(o1.export())
+for kv in os.environ.get("HNSW_TUNING", "").split(","):
+    if kv:
+        g1.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
 same = all([r.id for r in g1.search_knn(q, k)] == o1.search(q, k)[0].tolist() for q in Q[:40])
 for q in Q[:50]:
     g1.search_knn(q, k)
@@ -85,7 +100,7 @@ t0 = time.perf_counter()
 for q in Q[:400]:
     g1.search_knn(q, k)
 c1 = (time.perf_counter() - t0) / 400
-print("c1     %.1f us / query, identical: %s" % (1e6 * c1, same))
+print("c1     %.1f us / query, identical: %s, two-wave form: %s" % (1e6 * c1, same, g1.last_search_was_duo()))
 g1.set_tuning("time_launches", 1)
 ks = []
 for q in Q[:100]:

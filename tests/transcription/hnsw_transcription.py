@@ -98,7 +98,8 @@ class Node:                                              # core.rs:96-100, 179
 
 class Heap:
     """BinaryHeap<SimPair> (reverse=False: pops the LARGEST sim) / BinaryHeap<Reverse<SimPair>> (reverse=True: the
-    smallest).  SimPair orders by sim only (core.rs:292-300)."""
+    smallest).  SimPair orders by sim only (core.rs:292-300); equal similarities pop first-in first-out (heapq with an
+    insertion counter) -- ONE of the orders Rust leaves open.  ties = "fifo"."""
     __slots__ = ("h", "reverse", "owner")
 
     def __init__(self, owner, reverse=False, items=None):
@@ -106,11 +107,14 @@ class Heap:
         self.h = list(items) if items is not None else []
 
     def clone(self):
-        return Heap(self.owner, self.reverse, self.h)
+        return type(self)(self.owner, self.reverse, self.h)
+
+    def _key(self, sim, node):
+        self.owner.seq += 1
+        return ((sim if self.reverse else -sim), self.owner.seq, sim, node)
 
     def push(self, sim, node):
-        self.owner.seq += 1
-        heapq.heappush(self.h, ((sim if self.reverse else -sim), self.owner.seq, sim, node))
+        heapq.heappush(self.h, self._key(sim, node))
 
     def _tie_check(self):
         # the root's children are the only entries that can equal it without being below another equal entry
@@ -139,8 +143,97 @@ class Heap:
         return [(e[2], e[3]) for e in self.h]
 
 
+class TotalHeap(Heap):
+    """ties = "total": the order the C oracle and the engine use wherever the reference compares similarities -- larger
+    sim first, then the SMALLER id (tie order).  Not Rust's; a total order, so that the result does
+    not depend on any heap's internals."""
+    __slots__ = ()
+
+    def _key(self, sim, node):
+        return ((sim, -node.idx, sim, node) if self.reverse else (-sim, node.idx, sim, node))
+
+
+class RustHeap:
+    """ties = "rust": std::collections::BinaryHeap itself -- the array, sift_up (stops at a parent that is >= the
+    element) and pop = swap the last element to the root, sift_down_to_bottom (always towards the greater child, the
+    RIGHT one when the two are equal) and sift_up from there -- restated from the standard library's published source
+    (library/alloc/src/collections/binary_heap.rs, unchanged in this respect since 2015).  Elements compare by sim only
+    (core.rs:292-300), so this reproduces which of two equal similarities the reference's binary pops, evicts or
+    iterates first.  `into_vec` / iteration (core.rs:670-673, :786) = the array as it is."""
+    __slots__ = ("sims", "nodes", "reverse", "owner")
+
+    def __init__(self, owner, reverse=False, items=None):
+        self.owner, self.reverse = owner, reverse
+        if items is None:
+            self.sims, self.nodes = [], []
+        else:
+            self.sims, self.nodes = list(items[0]), list(items[1])
+
+    def clone(self):
+        return RustHeap(self.owner, self.reverse, (self.sims, self.nodes))
+
+    def _sift_up(self, start, pos):
+        sims, nodes, rev = self.sims, self.nodes, self.reverse
+        es, en = sims[pos], nodes[pos]
+        while pos > start:
+            parent = (pos - 1) // 2
+            ps = sims[parent]
+            if (ps <= es) if rev else (es <= ps):            # hole.element() <= hole.get(parent)
+                break
+            sims[pos], nodes[pos] = ps, nodes[parent]
+            pos = parent
+        sims[pos], nodes[pos] = es, en
+        return pos
+
+    def push(self, sim, node):
+        self.sims.append(sim)
+        self.nodes.append(node)
+        self._sift_up(0, len(self.sims) - 1)
+
+    def pop(self):
+        sims, nodes, rev = self.sims, self.nodes, self.reverse
+        s, n = sims.pop(), nodes.pop()
+        if sims:
+            s, sims[0] = sims[0], s
+            n, nodes[0] = nodes[0], n
+            # sift_down_to_bottom(0)
+            end = len(sims)
+            pos = 0
+            es, en = sims[0], nodes[0]
+            child = 1
+            while child <= end - 2 and end >= 2:
+                a, b = sims[child], sims[child + 1]
+                if (b <= a) if rev else (a <= b):            # hole.get(child) <= hole.get(child + 1)
+                    child += 1
+                sims[pos], nodes[pos] = sims[child], nodes[child]
+                pos = child
+                child = 2 * pos + 1
+            if child == end - 1:
+                sims[pos], nodes[pos] = sims[child], nodes[child]
+                pos = child
+            sims[pos], nodes[pos] = es, en
+            self._sift_up(0, pos)
+        return s, n
+
+    def peek(self):
+        return self.sims[0], self.nodes[0]
+
+    def __len__(self):
+        return len(self.sims)
+
+    def is_empty(self):
+        return not self.sims
+
+    def pairs(self):
+        return list(zip(self.sims, self.nodes))
+
+    @property
+    def h(self):                                         # (sim, node) view for the tie census of select_neighbors
+        return [(None, None, s, n) for s, n in zip(self.sims, self.nodes)]
+
+
 class Index:                                             # core.rs:302-347
-    def __init__(self, data_dim, m, ef_construction, data, levels, metric="reference"):
+    def __init__(self, data_dim, m, ef_construction, data, levels, metric="reference", ties="fifo"):
         self.data_dim = data_dim
         self.m = m
         self.m_max = m                                   # :335
@@ -160,12 +253,26 @@ class Index:                                             # core.rs:302-347
             self.rows_metric = sim_func_avx_euc_rows
         else:
             self.rows_metric = sim_func_euc_rows
+        self.tie_mode = ties
+        self.HeapT = {"fifo": Heap, "total": TotalHeap, "rust": RustHeap}[ties]
         self.seq = 0
         self.ties = {"heap_order": 0, "accept_657": 0, "select_733": 0}
         self.n_dist_insert = 0                           # mfunc calls at core.rs:550, 621, 652, 711 during inserts
         self.n_ids_insert = 0                            # neighbour ids scanned at core.rs:646, 699-700, 547
         self.n_expand_insert = 0
         self.n_dist = self.n_ids = self.n_expand = 0     # the counters of the call in progress
+
+    # the reference compares similarities only (core.rs:635, 657, 733); ties = "total" applies the oracle's / the
+    # engine's (sim, smaller id) order there as well
+    def nearer(self, asim, anode, bsim, bnode):
+        if self.tie_mode == "total":
+            return asim > bsim or (asim == bsim and anode.idx < bnode.idx)
+        return asim > bsim
+
+    def farther(self, asim, anode, bsim, bnode):
+        if self.tie_mode == "total":
+            return asim < bsim or (asim == bsim and anode.idx > bnode.idx)
+        return asim < bsim
 
     def mfunc_rows(self, v1, nodes):
         if not nodes:
@@ -212,7 +319,7 @@ class Index:                                             # core.rs:302-347
             while not neighbors.is_empty():              # :540-574, nearest first
                 _, e = neighbors.pop()
                 eneighbors = e.neighbors[lc]
-                econn = Heap(self)
+                econn = self.HeapT(self)
                 sims = self.mfunc_rows(self.data[e.idx], eneighbors)             # :549-553
                 self.n_dist += len(eneighbors)
                 self.n_ids += len(eneighbors)
@@ -235,14 +342,14 @@ class Index:                                             # core.rs:302-347
         v = {ep}
         qsim = self.mfunc_rows(query, [ep])[0]           # :621
         self.n_dist += 1
-        c = Heap(self)
-        w = Heap(self, reverse=True)
+        c = self.HeapT(self)
+        w = self.HeapT(self, reverse=True)
         c.push(qsim, ep)
         w.push(qsim, ep)
         while not c.is_empty():
             csim, cnode = c.pop()
-            fsim, _ = w.peek()
-            if csim < fsim:                              # :635
+            fsim, fnode = w.peek()
+            if self.farther(csim, cnode, fsim, fnode):   # :635  cpair.sim < fpair.sim
                 break
             cnode.push_levels(level)                     # :642
             neighbors = cnode.neighbors[level]
@@ -259,21 +366,21 @@ class Index:                                             # core.rs:302-347
                     self.n_dist += 1
                     if esim == fsim and len(w) >= ef and fnode is not neighbor:
                         self.ties["accept_657"] += 1     # a total order on (sim, id) could answer differently here
-                    if esim > fsim or len(w) < ef:       # :657
+                    if self.nearer(esim, neighbor, fsim, fnode) or len(w) < ef:       # :657  esim > fpair.sim
                         c.push(esim, neighbor)
                         w.push(esim, neighbor)
                         if len(w) > ef:
                             w.pop()
-        res = Heap(self)                                 # :670-674
+        res = self.HeapT(self)                           # :670-674
         for sim, node in w.pairs():
             res.push(sim, node)
         return res
 
     # ---- core.rs:677-757 (both flags are true at every call site, :528-529, 565-566, 850-851)
     def select_neighbors(self, query, c, m, lc, ignored_node):
-        r = Heap(self)
+        r = self.HeapT(self)
         w = c.clone()
-        wd = Heap(self)
+        wd = self.HeapT(self)
         ccopy = c.clone()                                # :690-696
         v = set()
         while not ccopy.is_empty():
@@ -298,7 +405,7 @@ class Index:                                             # core.rs:302-347
             esim, enode = w.pop()
             if enode is query or (ignored_node is not None and enode is ignored_node):
                 continue
-            if r.is_empty() or esim > r.peek()[0]:       # :733 -- r.peek() is r's LARGEST sim: only the first passes
+            if r.is_empty() or self.nearer(esim, enode, *r.peek()):   # :733 -- r.peek() is r's NEAREST: only the first passes
                 r.push(esim, enode)
             else:
                 wd.push(esim, enode)
@@ -370,7 +477,7 @@ class Index:                                             # core.rs:302-347
     def delete_node_from_neighbors(self, node, lc):
         for n in list(node.neighbors[lc]):
             nneighbors = n.neighbors[lc]
-            nconn = Heap(self)
+            nconn = self.HeapT(self)
             sims = self.mfunc_rows(self.data[n.idx], nneighbors)
             for j, nn in enumerate(nneighbors):
                 nconn.push(sims[j], nn)

@@ -44,15 +44,15 @@ def inputs(n, dim, m, nq):
     return V, Q, draw_levels(n, m, 7)
 
 
-def run(name, metric="reference"):
+def run(name, metric="reference", ties="fifo"):
     n, dim, m, ef, k, nq = CASES[name]
     V, Q, lv = inputs(n, dim, m, nq)
-    idx = Index(dim, m, ef, V, lv, metric=metric)
+    idx = Index(dim, m, ef, V, lv, metric=metric, ties=ties)
     t0 = time.time()
     for i in range(n):
         idx.add_node("node%d" % i, i)
         if i % 1000 == 999:
-            print("  %s[%s]: %d inserted, %.0f s" % (name, metric, i + 1, time.time() - t0), flush=True)
+            print("  %s[%s,%s]: %d inserted, %.0f s" % (name, metric, ties, i + 1, time.time() - t0), flush=True)
     build_ties = dict(idx.ties)
     nodes = [idx.nodes["node%d" % i] for i in range(n)]
     levels = np.zeros(n, dtype=np.int32)
@@ -90,7 +90,7 @@ def run(name, metric="reference"):
         hit += len(set(np.argsort(d, kind="stable")[:k].tolist()) & set(ids[qi, :n_out[qi]].tolist()))
     deg0 = np.diff(out["row_ptr_0"].astype(np.int64))
     degU = np.concatenate([np.diff(out["row_ptr_%d" % l].astype(np.int64)) for l in range(1, idx.max_layer + 1)] or [np.zeros(1, np.int64)])
-    stats = dict(case=name, metric=metric, dist_per_insert=idx.n_dist_insert / (n - 1), dist_per_query=sc[0] / nq,
+    stats = dict(case=name, metric=metric, ties=ties, dist_per_insert=idx.n_dist_insert / (n - 1), dist_per_query=sc[0] / nq,
                  expansions_per_query=sc[2] / nq, recall_at_k=hit / (nq * k),
                  level_histogram=np.bincount(lv).tolist(), max_degree_layer0=int(deg0.max()),
                  nodes_over_m_max_0=int((deg0 > 2 * m).sum()), mean_degree_layer0=float(deg0.mean()),
@@ -102,15 +102,21 @@ def run(name, metric="reference"):
 
 
 def main():
-    for name in (sys.argv[1:] or list(CASES)):
-        metric = "reference"
-        if name.endswith(":f64"):
-            name, metric = name[:-4], "f64"
-        out, stats = run(name, metric)
+    """case[:ties][:f64] ...   ties = rust (default: std's BinaryHeap itself), total (the oracle's (sim, id) order), fifo"""
+    for arg in (sys.argv[1:] or list(CASES)):
+        parts = arg.split(":")
+        name, metric, ties = parts[0], "reference", "rust"
+        for p in parts[1:]:
+            if p == "f64":
+                metric = "f64"
+            else:
+                ties = p
+        out, stats = run(name, metric, ties)
         print(json.dumps(stats), flush=True)
         if metric == "reference":
-            np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **out)
-            print("wrote", name, os.path.getsize(os.path.join(GOLDEN, name + ".npz")), "bytes")
+            fn = name + ("" if ties == "rust" else "_" + ties)
+            np.savez_compressed(os.path.join(GOLDEN, fn + ".npz"), **out)
+            print("wrote", fn, os.path.getsize(os.path.join(GOLDEN, fn + ".npz")), "bytes")
         else:   # the float64 model: summary figures only (profiles/), never a golden
             with open(os.path.join(os.path.dirname(os.path.dirname(HERE)), "profiles", "r4_%s_f64_model.json" % name), "w") as f:
                 json.dump(stats, f, indent=1)
