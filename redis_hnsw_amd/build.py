@@ -23,7 +23,8 @@ UNITS = [
     ("hnsw_tu_search.hip", [0, 1, 2, 3, 4, 5], ["hnsw_kernels.hpp"]),
     ("hnsw_tu_insert.hip", [0, 1, 2, 3], []),
     ("hnsw_tu_occ.hip", [0, 1, 2, 3], []),
-    ("hnsw_tu_planlean.hip", [0, 1], ["hnsw_plan_lean.hpp", "hnsw_search_lean.hpp"]),
+    ("hnsw_tu_planlean.hip", [0, 1], ["hnsw_plan_lean.hpp", "hnsw_search_lean.hpp", "hnsw_search_duo.hpp"]),
+    ("hnsw_tu_planduo.hip", [0, 1], ["hnsw_plan_lean.hpp", "hnsw_search_lean.hpp", "hnsw_search_duo.hpp"]),
     ("hnsw_group.hip", [None], []),                   # one process, several GPUs: host code above the C ABI
 ]
 SOURCES = [u[0] for u in UNITS]

@@ -421,8 +421,10 @@ hnsw_status launch_occ_plan_lean(hnsw_index *h, const InsertCfg &c, const OccBuf
     const uint32_t idbits = plan_lean_idbits(h, c);
     if (!idbits) return HNSW_OK;
     *done = true;
-    return (h->stride0 > 64 || h->strideU > 64) ? launch_occ_plan_lean_v<true>(h, c, ob, head, count, idbits)
-                                                : launch_occ_plan_lean_v<false>(h, c, ob, head, count, idbits);
+    const bool wide = h->stride0 > 64 || h->strideU > 64;
+    if (h->plan_duo && count <= h->plan_duo_max)
+        return wide ? launch_occ_plan_duo_v<true>(h, c, ob, head, count, idbits) : launch_occ_plan_duo_v<false>(h, c, ob, head, count, idbits);
+    return wide ? launch_occ_plan_lean_v<true>(h, c, ob, head, count, idbits) : launch_occ_plan_lean_v<false>(h, c, ob, head, count, idbits);
 }
 
 // returns HNSW_OK and sets *done when the specialised kernel was launched
@@ -969,6 +971,8 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
     if (!std::strcmp(key, "occ_min_batch")) { h->occ_min_batch = (uint32_t)std::max<int64_t>(value, 1); return HNSW_OK; }
     if (!std::strcmp(key, "lean")) { h->lean = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "duo")) { h->duo = value != 0; return HNSW_OK; }
+    if (!std::strcmp(key, "plan_duo")) { h->plan_duo = value != 0; return HNSW_OK; }
+    if (!std::strcmp(key, "plan_duo_max")) { h->plan_duo_max = (uint32_t)std::max<int64_t>(value, 0); return HNSW_OK; }
     if (!std::strcmp(key, "duo_max")) { h->duo_max = (uint32_t)std::max<int64_t>(value, 0); return HNSW_OK; }
     if (!std::strcmp(key, "grid_stride")) { h->grid_stride = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "query_in_lds")) {     // dims 128 / 768 normally keep the query in registers (T = dim/32)

@@ -126,6 +126,8 @@ struct hnsw_index {
     bool duo = true;                 // ... in its two-wave form (hnsw_search_duo.hpp) when at most duo_max queries are in flight
     uint32_t duo_max = 1024;         // 4 workgroups of two waves per CU: every query gets two SIMD slots
     bool last_search_duo = false;
+    bool plan_duo = true;            // insert plans (always lone chains) run in the two-wave form when at most plan_duo_max are launched at once
+    uint32_t plan_duo_max = 256;     // one two-wave workgroup per CU
     size_t lds_reserve = 0;          // LDS a kernel needs besides the wave's own share (the OCC kernels' validation scratch)
     bool grid_stride = false;        // specialised kernel: cap the grid at the resident waves and walk the batch grid-stride (tuning, for comparison)
     bool visited_bounded = true;     // k_search: a full LDS visited table stops recording (exact results)
@@ -260,6 +262,11 @@ template <bool WIDE>
 hnsw_status launch_plan_lean_v(hnsw_index *h, const InsertCfg &c, uint32_t first, uint32_t count, uint32_t idbits);
 template <bool WIDE>
 hnsw_status launch_occ_plan_lean_v(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t head, uint32_t count, uint32_t idbits);
+// hnsw_tu_planduo.hip: the same plans with a second wavefront keeping W for their layer searches
+template <bool WIDE>
+hnsw_status launch_plan_duo_v(hnsw_index *h, const InsertCfg &c, uint32_t first, uint32_t count, uint32_t idbits);
+template <bool WIDE>
+hnsw_status launch_occ_plan_duo_v(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t head, uint32_t count, uint32_t idbits);
 // hnsw_engine.hip: 0 when the specialised plan cannot serve this index, else the id-hash width to launch it with
 uint32_t plan_lean_idbits(const hnsw_index *h, const InsertCfg &c);
 size_t plan_lean_lds(int R);

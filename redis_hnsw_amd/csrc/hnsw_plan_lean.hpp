@@ -11,26 +11,43 @@
 //
 // LDS: the insert kernels' carve-up (W, S, fresh, dsc, aux, the general visited table -- select_neighbors and the
 // shrinks still use it), then the specialised routine's Wbuf and its 32 KB tag table.
+//
+// DUO = true: the two-wave form (hnsw_search_duo.hpp).  The workgroup has a second wavefront that does nothing but
+// keep W for the layer searches of this plan (core.rs:524) -- a plan is always a lone chain, so the split that
+// serves lone queries serves every plan.  Everything else is the first wave's, exactly as in the one-wave kernel; the
+// translation unit that instantiates the DUO kernels (hnsw_tu_planduo.hip) turns the block-level synchronisations
+// of the shared insert code into wave-level ones, so that the keeper takes no part in them and the only s_barriers
+// the walker executes are the two of each hand-over.
 #pragma once
 #include "hnsw_occ.hpp"
 #include "hnsw_search_lean.hpp"
+#include "hnsw_search_duo.hpp"
 
 namespace hnsw {
 
 constexpr int kPlanLeanBB = 11;                       // one plan per workgroup: the largest tag table (12 288 ids before it stops recording)
 template <int R>
-constexpr size_t plan_lean_bytes() { return LeanW<R>::kBytes + ((size_t)16 << kPlanLeanBB); }
+constexpr size_t plan_lean_bytes() { return LeanW<R>::kBytes + ((size_t)16 << kPlanLeanBB) + kDuoBoxBytes; }
 
-template <int R, int DB, bool WIDE, bool LOG>
+template <int R, int DB, bool WIDE, bool LOG, bool DUO = false>
 struct PlanLean {
     using VEC = VecF32<4>;
     uint64_t *Wbuf;
+    DuoBox *box;
+    DuoSeq seq;
     TagSet<kPlanLeanBB, DB> ts;
     typename VEC::Q q;
 
+    static __device__ __forceinline__ uint64_t *wbuf_of(unsigned char *lds) { return reinterpret_cast<uint64_t *>(lds); }
+    static __device__ __forceinline__ DuoBox *box_of(unsigned char *lds)
+    {
+        return reinterpret_cast<DuoBox *>(lds + LeanW<R>::kBytes + ((size_t)16 << kPlanLeanBB));
+    }
     __device__ __forceinline__ void init(unsigned char *lds, uint32_t idbits, const QReg<4> &qr)
     {
-        Wbuf = reinterpret_cast<uint64_t *>(lds);
+        Wbuf = wbuf_of(lds);
+        box = box_of(lds);
+        seq.n = 0;
         ts.tab = reinterpret_cast<uint32_t *>(lds + LeanW<R>::kBytes);
         ts.idbits = idbits;
         ts.lcap = (1u << kPlanLeanBB) * 6u;
@@ -50,21 +67,44 @@ struct PlanLean {
     // search_level(ef) (core.rs:524): W sorted in Wbuf[0..nW), expanded bits set
     __device__ __forceinline__ uint32_t search(const GraphView &g, uint32_t ep, uint32_t ef, uint32_t lc, WorkCtr &ctr, int lane)
     {
+        if constexpr (DUO) {
+            const uint32_t nW = duo_walk<VEC, kPlanLeanBB, DB, WIDE, LOG>(g, Wbuf, box, seq, ts, q, ep, ef, lc, ctr, lane);
+            if (nW != kEmpty) return nW;                    // else: the table stopped recording, the walker redoes it alone
+        }
         return search_level_lean<VEC, R, kPlanLeanBB, DB, WIDE, LOG>(g, Wbuf, ts, q, ep, ef, lc, ctr, lane, &g.hdr->ctr_search[3]);
+    }
+    // no more searches: the keeper leaves (DUO only)
+    __device__ __forceinline__ void finish(int lane)
+    {
+        if constexpr (DUO) duo_send(box, seq, ~0ull, false, ~0ull, DUO_EXIT, lane);
+    }
+    // the second wavefront of a DUO plan: W's keeper for every layer search of the plan
+    static __device__ __forceinline__ void keep(const GraphView &g, unsigned char *lds, uint32_t ef, int lane)
+    {
+        DuoSeq ks = {0};
+        WorkCtr kc = {};
+        while (duo_keep<R, WIDE>(g, wbuf_of(lds), box_of(lds), ef, ks, lane, kc)) {}
     }
 };
 
 // ---------------------------------------------------------------------------
 // k_insert_plan with the specialised search: one wave per new node.
 // ---------------------------------------------------------------------------
-template <int R, int DB, bool WIDE>
-__global__ __launch_bounds__(64, 1) void k_insert_plan_lean(GraphView g, uint32_t first_id, uint32_t count, uint32_t ef,
+template <int R, int DB, bool WIDE, bool DUO = false>
+__global__ __launch_bounds__(DUO ? 128 : 64, 1) void k_insert_plan_lean(GraphView g, uint32_t first_id, uint32_t count, uint32_t ef,
                                                          uint32_t mlinks, uint32_t lnb, uint32_t lcap, uint32_t *__restrict__ gspill,
                                                          uint32_t gnb, uint32_t *__restrict__ plan, uint32_t shortcut,
                                                          uint32_t lean_off, uint32_t idbits)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    if constexpr (DUO) {
+        if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= 64) {
+            // one keeper session per node of the grid-stride loop below
+            for (uint32_t s = blockIdx.x; s < count; s += gridDim.x) PlanLean<R, DB, WIDE, false, true>::keep(g, smem + lean_off, ef, lane);
+            return;
+        }
+    }
     WaveMem m;
     Visited vis;
     carve<R, 4, true>(smem, g.dim, lnb, lcap, m, vis, g.tagcfg);
@@ -85,7 +125,7 @@ __global__ __launch_bounds__(64, 1) void k_insert_plan_lean(GraphView g, uint32_
         const uint32_t l = g.levels[id];
         QReg<4> qr;
         load_query<MODE_AVX, 4>(g.vec + (size_t)id * g.dim, g.dim, qr, m.qlds, lane);
-        PlanLean<R, DB, WIDE, false> pl_;
+        PlanLean<R, DB, WIDE, false, DUO> pl_;
         pl_.init(smem + lean_off, idbits, qr);
         m.W = pl_.Wbuf;                                     // the search leaves W there; select_* read it through m.W
         bool fail = false;
@@ -108,6 +148,7 @@ __global__ __launch_bounds__(64, 1) void k_insert_plan_lean(GraphView g, uint32_
             __syncthreads();
         }
         if (fail && lane == 0) atomicOr(&g.hdr->status, ST_VISITED_OVERFLOW);
+        pl_.finish(lane);
     }
     if (vis.glob_dirty) visited_clear(vis, lane);
     if (lane == 0) {
@@ -120,19 +161,25 @@ __global__ __launch_bounds__(64, 1) void k_insert_plan_lean(GraphView g, uint32_
 // ---------------------------------------------------------------------------
 // k_occ_plan with the specialised search (read log included): one wave per window node without a valid plan.
 // ---------------------------------------------------------------------------
-template <int R, int DB, bool WIDE>
-__global__ __launch_bounds__(64, 1) void k_occ_plan_lean(GraphView g, OccBufs ob, uint32_t first_node, uint32_t count, uint32_t ef,
+template <int R, int DB, bool WIDE, bool DUO = false>
+__global__ __launch_bounds__(DUO ? 128 : 64, 1) void k_occ_plan_lean(GraphView g, OccBufs ob, uint32_t first_node, uint32_t count, uint32_t ef,
                                                       uint32_t mlinks, uint32_t lnb, uint32_t lcap, uint32_t *__restrict__ gspill,
                                                       uint32_t gnb, uint32_t *__restrict__ plan, uint32_t shortcut, uint32_t log_cap,
                                                       uint32_t lean_off, uint32_t idbits)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const uint32_t id = first_node + blockIdx.x;
     if (blockIdx.x >= count) return;
     const uint32_t slot = id % ob.W;
     OccSlot *sl = &ob.slots[slot];
-    if (sl->planned && sl->node == id) return;
+    if (sl->planned && sl->node == id) return;              // (both waves of a DUO plan take the same way out)
+    if constexpr (DUO) {
+        if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= 64) {
+            PlanLean<R, DB, WIDE, true, true>::keep(g, smem + lean_off, ef, lane);
+            return;
+        }
+    }
 
     WaveMem m;
     Visited vis;
@@ -158,7 +205,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_plan_lean(GraphView g, OccBufs ob
 
     QReg<4> qr;
     load_query<MODE_AVX, 4>(g.vec + (size_t)id * g.dim, g.dim, qr, m.qlds, lane);
-    PlanLean<R, DB, WIDE, true> pl_;
+    PlanLean<R, DB, WIDE, true, DUO> pl_;
     pl_.init(smem + lean_off, idbits, qr);
     m.W = pl_.Wbuf;
     bool fail = false;
@@ -196,6 +243,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_plan_lean(GraphView g, OccBufs ob
         ep = wnearest;                                      // core.rs:576
         __syncthreads();
     }
+    pl_.finish(lane);
     __threadfence();
     __syncthreads();
     occ_plan_finish(g, ob, sl, shr, pl0, ctr, id, top, mlinks, log_cap, snap, epoch, fail, vis, lane);

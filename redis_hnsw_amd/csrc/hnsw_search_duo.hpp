@@ -33,12 +33,13 @@
 
 namespace hnsw {
 
-constexpr uint32_t DUO_INIT = 1u, DUO_FIN = 2u, DUO_ABORT = 4u;
+constexpr uint32_t DUO_INIT = 1u, DUO_FIN = 2u, DUO_ABORT = 4u, DUO_EXIT = 8u;
 
 struct DuoBox {
     uint64_t key[64];          // walker -> keeper: lane l's accepted key of this chunk, ~0 = none
     uint64_t nkey;             // walker -> keeper: the candidate the walker expands next (mark it expanded), ~0 = none
-    uint32_t flags;            // DUO_INIT: reset W first; DUO_FIN: this search is over (write W out)
+    uint32_t flags;            // DUO_INIT: reset W first (nkey's low word = the layer); DUO_FIN: this search is over (write W out);
+                               // DUO_EXIT (alone): no more searches, the keeper leaves
     uint32_t mseq;             // messages sent so far (polled forms)
     uint64_t worst;            // keeper -> walker: W's ef-th key (~0 while W is not full)  core.rs:651
     uint64_t rkey;             // keeper -> walker: W's first unexpanded entry, ~0 = none
@@ -151,14 +152,15 @@ __device__ __forceinline__ void duo_reply(DuoBox *box, DuoSeq &seq, int lane)
 }
 
 // ---- the keeper ------------------------------------------------------------------------------------------
-// Serves ONE search_level: from its DUO_INIT message to its DUO_FIN.  Leaves W sorted in Wbuf[0 .. nW).
+// Serves ONE search_level: from its DUO_INIT message to its DUO_FIN.  Leaves W sorted in Wbuf[0 .. nW) and returns
+// true; returns false if the first message was DUO_EXIT instead.
 template <int R, bool WIDE>
-__device__ __forceinline__ void duo_keep(const GraphView &g, uint32_t lc, uint64_t *Wbuf, DuoBox *box, uint32_t ef, DuoSeq &seq,
-                                         int lane, WorkCtr &ctr)
+__device__ __forceinline__ bool duo_keep(const GraphView &g, uint64_t *Wbuf, DuoBox *box, uint32_t ef, DuoSeq &seq, int lane,
+                                         WorkCtr &ctr)
 {
     PH_T0();
     DuoBoxLds vb = duo_lds(box);
-    const uint32_t stride = lc ? g.strideU : g.stride0;
+    uint32_t lc = 0, stride = g.stride0;
     uint64_t w[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) w[r] = ~0ull;
@@ -172,15 +174,18 @@ __device__ __forceinline__ void duo_keep(const GraphView &g, uint32_t lc, uint64
         const uint64_t nkv = vb->nkey;
         const uint32_t fl = __builtin_amdgcn_readfirstlane(vb->flags);
         const uint64_t nk = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(nkv >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)nkv);
+        if (fl & DUO_EXIT) return false;
         if (fl & DUO_INIT) {
 #pragma unroll
             for (int r = 0; r < R; ++r) w[r] = ~0ull;
             nW = 0;
             worst = ~0ull;
+            lc = (uint32_t)nk;
+            stride = lc ? g.strideU : g.stride0;
         }
         if (!(fl & DUO_ABORT)) {
             bool take = kk != ~0ull;
-            if (nk != ~0ull) {
+            if (nk != ~0ull && !(fl & DUO_INIT)) {
                 // core.rs:631 pop: the chosen candidate is in W or among these keys; ids are unique, the chosen key is
                 // unexpanded: its low word (id << 1) identifies it, adding the match sets bit 0
                 const uint32_t nlo = (uint32_t)nk;
@@ -197,7 +202,7 @@ __device__ __forceinline__ void duo_keep(const GraphView &g, uint32_t lc, uint64
             if (lane == 0) vb->nW = nW + (warm == 0x9E3779B9u && lane == 64 ? 1u : 0u);   // (keeps the prefetches alive)
             PH_MARK(ctr, 6);
             duo_reply(box, seq, lane);
-            return;
+            return true;
         }
         uint64_t rkey;
         int r2, l2;
@@ -248,7 +253,7 @@ __device__ __forceinline__ uint32_t duo_walk(const GraphView &g, uint64_t *Wbuf,
         ctr.n_dist += 1;
         ckey = pack_key(d, ep);
     }
-    duo_send(box, seq, ckey | 1ull, lane == 0, ~0ull, DUO_INIT, lane);   // core.rs:627-628, popped right away (:631)
+    duo_send(box, seq, ckey | 1ull, lane == 0, (uint64_t)lc, DUO_INIT, lane);   // core.rs:627-628, popped right away (:631)
 
     const uint32_t log_start = ctr.log_n;
     PH_T0();
@@ -420,7 +425,7 @@ __global__ __launch_bounds__(128, 2) void k_search_duo(GraphView g, const float 
             if (nW == kEmpty)
                 nW = search_level_lean<VEC, R, BB, DB, WIDE>(g, Wbuf, vis, qr, ep, ef, 0, ctr, lane, &g.hdr->ctr_search[3]);
         } else {
-            duo_keep<R, WIDE>(g, 0u, Wbuf, box, ef, seq, lane, ctr);
+            (void)duo_keep<R, WIDE>(g, Wbuf, box, ef, seq, lane, ctr);
         }
         __syncthreads();
         if (walker) {
