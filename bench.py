@@ -42,6 +42,36 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec -- the roofline'
 HBM_MEASURED_GBS = 6300.0  # same guide: what a streaming copy sustains from DRAM on this part
 FIXTURES = {(1_000_000, 128, 16, 200): os.path.join(ROOT, "data", "c2_ref_graph_1m.npz")}
 FIXTURE_50K = os.path.join(ROOT, "data", "c2_ref_graph_50k.npz")
+# the reference's own work counters of the C2 build at several prefix sizes (tests/fixtures/make_ref_counters.py)
+REF_INSERT_COUNTERS = os.path.join(ROOT, "data", "c2_ref_insert_counters.json")
+# BASELINE.json's configurations by name (bench.py --workload c3); c1 is timed inside every default run (c1_single_query)
+WORKLOADS = {
+    "c1": dict(nodes=10_000, dim=128, m=5, ef=200, k=10, batch=1),
+    "c2": dict(nodes=1_000_000, dim=128, m=16, ef=200, k=10, batch=1024),
+    "c3": dict(nodes=1_000_000, dim=768, m=32, ef=400, k=100, batch=4096),
+    "c4": dict(nodes=10_000_000, dim=128, m=16, ef=200, k=10, batch=1024),
+    "c5": dict(nodes=1_000_000, dim=128, m=16, ef=200, k=10, batch=1024, graph="exact"),
+}
+
+
+def insert_roofline(n_dist, n_ids, n_inserts, seconds, dim, source):
+    """SURVEY 8d, per insert: bytes = n_dist_ins x 4 dim + n_ids_ins x 4 with the REFERENCE's counts (metric calls at
+    core.rs:550, 621, 652, 711; ids scanned), over the time the engine took"""
+    by = float(n_dist) * 4 * dim + float(n_ids) * 4
+    gbs = by / max(seconds, 1e-12) / 1e9
+    return dict(bound="hbm", achieved=round(gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 5),
+                algorithmic_bytes_per_insert=int(by / max(n_inserts, 1)), n_dist_per_insert=round(n_dist / max(n_inserts, 1), 1),
+                n_ids_per_insert=round(n_ids / max(n_inserts, 1), 1), counts=source,
+                note="an insert is a chain of dependent expansions on a few wavefronts: latency-bound by construction, the "
+                     "fraction says how far from a bandwidth-bound stream it is")
+
+
+def ref_insert_counters(prefix):
+    try:
+        ent = json.load(open(REF_INSERT_COUNTERS))["prefixes"][str(prefix)]
+        return ent["n_dist"], ent["n_ids"]
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def draw_levels(n, m, seed=7):
@@ -206,6 +236,9 @@ def measure_traffic(argv, log):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="a BASELINE.json configuration by name: sets --nodes/--dim/--m/--ef/--k/--batch (and, for c5, "
+                         "--graph exact: the index is BUILT on the GPU in the reference's insert order before it is queried)")
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--nodes", type=int, default=1_000_000)
@@ -229,6 +262,13 @@ def main():
     ap.add_argument("--verify-gather", action="store_true",
                     help="N>1: rank 0 re-runs every rank's first batch on its own replica and compares with the gathered result")
     args = ap.parse_args()
+    if args.workload:
+        for key, val in WORKLOADS[args.workload].items():
+            if key == "graph":
+                if args.graph == "auto":
+                    args.graph = val
+            else:
+                setattr(args, key, val)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args)
 
@@ -553,7 +593,8 @@ def main():
         torch.cuda.synchronize()
         msl = e0.elapsed_time(e1) / reps
         byl = B * (n_dist_q * 4 * dim + n_ids_q * 4 + 4 * dim + 8 * k)
-        lone = dict(batch=B, launches_in_flight=1, kernel_ms=round(msl, 4), value=round(B / msl * 1e3, 1), unit="queries/s",
+        lone = dict(batch=B, launches_in_flight=1, two_wave_kernel=bool(index.last_search_was_duo()),
+                    kernel_ms=round(msl, 4), value=round(B / msl * 1e3, 1), unit="queries/s",
                     achieved=round(byl / (msl * 1e-3) / 1e9, 1), frac=round(byl / (msl * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
         log("lone %d-query launches: %.3f ms each, %.0f GB/s" % (B, msl, lone["achieved"]))
 
@@ -602,7 +643,11 @@ def main():
         gotf = d_ids.cpu().numpy().astype(np.int64)
         gtf = brute_force_gt(torch, V_dev, myQ[:B], k)
         del V_dev
+        rc = ref_insert_counters(N)
         fast_build = dict(build_seconds=round(tfb, 2), inserts_per_s=round(N / tfb, 1),
+                          roofline=None if rc is None else insert_roofline(
+                              rc[0], rc[1], N, tfb, dim, "the oracle's serial build of the same %d vectors (data/c2_ref_insert_counters.json); "
+                              "the batched build itself evaluates about half of them" % N),
                           recall_at_10=round(sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(gotf, gtf)) / (B * k), 4),
                           note="hnsw_add_batch mode 1 (batched GPU build, BASELINE config 5): not the reference's insert order")
         ifast.close()
@@ -631,8 +676,11 @@ def main():
             why = "levels, enterpoint and every adjacency row of every layer in stored order == the CPU oracle's serial build"
             if not identical:
                 raise SystemExit("gpu_exact_build: the GPU's reference-order graph differs from the oracle's fixture")
+        rc = ref_insert_counters(NE)
         exact_build = dict(nodes=NE, build_seconds=round(te, 2), inserts_per_s=round(NE / te, 1), identical=identical,
                            checked_against=why,
+                           roofline=None if rc is None else insert_roofline(
+                               rc[0], rc[1], NE, te, dim, "the oracle's serial build of the same %d-node prefix (data/c2_ref_insert_counters.json)" % NE),
                            note="hnsw_add_batch mode 0 on the first 50 k nodes (the rate grows with the index; the whole 1 M "
                                 "build: profiles/r3_c5_exact_build_1m.json)")
         # HNSW.NODE.ADD as the Redis command issues it (src/lib.rs:356: one add_node per call): single hnsw_add
@@ -648,10 +696,13 @@ def main():
             from oracle import oracle as _orc                # checker only, after the timed region
             want["vectors"] = V[:NE]
             oa = _orc.OracleIndex.from_graph(dim, M, ef, want)
+            c0_ = oa.insert_counters()
+            c0_ = (c0_.n_dist, c0_.n_ids)
             tc = time.time()
             for i in range(NA):
                 oa.add(extra_v[i], int(extra_l[i]))
             tc = (time.time() - tc) / NA
+            c1_ = oa.insert_counters()
             ga, gb = oa.export(), ie.export_graph()
             same = (ga["enterpoint"] == gb["enterpoint"] and np.array_equal(ga["levels"], gb["levels"])
                     and all(np.array_equal(a_, b_) for a_, b_ in zip(ga["row_ptr"], gb["row_ptr"]))
@@ -659,7 +710,9 @@ def main():
             if not same:
                 raise SystemExit("single_add: the graph after %d hnsw_add calls differs from the oracle's" % NA)
             single_add = dict(workload="HNSW.NODE.ADD: %d single hnsw_add calls (host vectors) on the %d-node reference-order index" % (NA, NE),
-                              gpu_ms=round(1e3 * ta, 3), cpu_oracle_ms=round(1e3 * tc, 3), identical=True)
+                              gpu_ms=round(1e3 * ta, 3), cpu_oracle_ms=round(1e3 * tc, 3), identical=True,
+                              roofline=insert_roofline(c1_.n_dist - c0_[0], c1_.n_ids - c0_[1], NA, ta * NA, dim,
+                                                       "the oracle making the same %d inserts on the same graph" % NA))
             # HNSW.NODE.DEL the same way (src/lib.rs:397): single hnsw_delete calls, timed, then checked
             ND = 100
             victims = [int(v) for v in np.random.default_rng(17).choice(NE, ND, replace=False)]
@@ -842,10 +895,12 @@ def main():
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             want = dict(nodes=N, dim=dim, M=M, ef=ef, k=k, batch=B, graph=mode, streams=S)
-            for ent in tj["entries"]:
-                if all(ent["config"].get(kk) == vv for kk, vv in want.items()):
+            for ent in tj.get("entries", []):
+                cfg_e = ent.get("config") or {}
+                if cfg_e and all(cfg_e.get(kk) == vv for kk, vv in want.items()) and "k_search_hbm_bytes_per_launch" in ent:
                     traffic = ent["k_search_hbm_bytes_per_launch"]
                     traffic_source = "profiles/traffic.json@%s (not measured in this run)" % ent.get("commit", "?")
+                    break
         except (OSError, ValueError, KeyError, TypeError):
             pass
     roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
@@ -874,6 +929,8 @@ def main():
     # ---- CPU baseline: the oracle (C restatement of the Rust path), bounded sample -------
     cpu = None
     c1 = None
+    c2s = None
+    cfg_name_early = {(1_000_000, 128, 16, 200): "C2", (1_000_000, 768, 32, 400): "C3", (10_000_000, 128, 16, 200): "C4"}.get((N, dim, M, ef), "this")
     if not args.no_cpu_baseline and world == 1:   # timed at N=1 only: the other ranks would idle in the barrier
         from oracle import oracle
         graph["vectors"] = V
@@ -906,6 +963,25 @@ def main():
                    all_cores=dict(value=round(reps * B / tN, 1), cores=cores, visible_cpus=os.cpu_count(),
                                   sample="%d passes over the batch, persistent workers with per-thread scratch; "
                                          "cores = affinity mask capped by the cgroup CPU quota" % reps))
+        # ---- one HNSW.SEARCH per call on THIS index (the command's shape, src/lib.rs:484), beside the oracle's
+        c2s = None
+        if extras:
+            Q1 = Qall[:200]
+            for q in Q1[:20]:
+                index.search_knn(q, k)
+            same = all([r.id for r in index.search_knn(q, k)] == o.search(q, k)[0].tolist() for q in Q1[:20])
+            tq = time.perf_counter()
+            for q in Q1:
+                index.search_knn(q, k)
+            t_g = (time.perf_counter() - tq) / len(Q1)
+            tq = time.perf_counter()
+            for q in Q1:
+                o.search(q, k)
+            t_c = (time.perf_counter() - tq) / len(Q1)
+            c2s = dict(workload="%s index, one query per hnsw_search call (host buffers)" % cfg_name_early,
+                       gpu_us=round(1e6 * t_g, 1), cpu_oracle_us=round(1e6 * t_c, 1), identical=bool(same),
+                       two_wave_kernel=bool(index.last_search_was_duo()))
+            log("one query per call on this index: %.1f us (CPU oracle %.1f us), identical: %s" % (1e6 * t_g, 1e6 * t_c, same))
         o.close()
         # ---- C1 (BASELINE config 1): 10k x 128, M=5, ef=200, k=10, ONE query per call (the shape of a
         # HNSW.SEARCH command): hnsw_search latency, host buffers in and out, beside the oracle's
@@ -931,7 +1007,8 @@ def main():
                 o1.search(q, k)
             t_c = (time.perf_counter() - tq) / len(Q1)
             c1 = dict(workload="C1: 10k x 128, M=5, ef=200, k=10, one query per hnsw_search call (host buffers)",
-                      gpu_us=round(1e6 * t_g, 1), cpu_oracle_us=round(1e6 * t_c, 1), identical=bool(same))
+                      gpu_us=round(1e6 * t_g, 1), cpu_oracle_us=round(1e6 * t_c, 1), identical=bool(same),
+                      two_wave_kernel=bool(g1.last_search_was_duo()))
             g1.close(); o1.close()
 
     known = {(1_000_000, 128, 16, 200, 10, 1024): "C2", (1_000_000, 768, 32, 400, 100, 4096): "C3",
@@ -962,7 +1039,7 @@ def main():
         "gpu_fast_build": fast_build, "gpu_exact_build": exact_build, "single_add": single_add, "single_delete": single_delete,
         "clustered": clus,
         "bf16_storage_mode": bf16, "fp8_storage_mode": fp8,
-        "c1_single_query": c1,
+        "c1_single_query": c1, "single_query_on_this_index": c2s,
         "setup_seconds": round(time.time() - t0, 1),
         "roofline": roofline,
         "cpu_baseline": cpu,

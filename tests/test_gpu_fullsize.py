@@ -164,3 +164,27 @@ def test_exact_gpu_build_equals_the_committed_reference_order_fixture(eng):
     ok, why = graphs_equal(want, gi.export_graph())
     assert ok, why
     gi.close()
+
+
+FIXTURE_1M = os.path.join(ROOT, "data", "c2_ref_graph_1m.npz")
+
+
+@pytest.mark.skipif(not os.path.exists(FIXTURE_1M), reason="data/c2_ref_graph_1m.npz is missing")
+def test_exact_build_1m_equals_the_fixture(eng):
+    """BASELINE config 5 at FULL size: HNSW.NODE.ADD of all 1 M x 128 vectors on the GPU in the reference's insert
+    order (hnsw_add_batch mode 0: plans in parallel, validated in-order commits) == the CPU oracle's serial build of
+    the same vectors and levels (data/c2_ref_graph_1m.npz, 4 243 s on one core): levels, enterpoint and every adjacency
+    row of every layer in stored order.  The longest test of the suite (a few minutes)."""
+    import time
+    from bench import draw_levels, load_graph_fixture
+    N, dim, M, ef = 1_000_000, 128, 16, 200
+    V = np.random.default_rng(1).random((N, dim), dtype=np.float32)
+    want, _ = load_graph_fixture(FIXTURE_1M, V)
+    gi = eng.Index("exact1m", dim, M, ef)
+    t0 = time.time()
+    gi.add_batch(V, levels=draw_levels(N, M, 7), mode="exact")
+    dt = time.time() - t0
+    print("exact GPU build of 1 M nodes: %.1f s = %.0f inserts/s" % (dt, N / dt))
+    ok, why = graphs_equal(want, gi.export_graph())
+    assert ok, why
+    gi.close()
