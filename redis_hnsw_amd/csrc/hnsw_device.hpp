@@ -1256,8 +1256,12 @@ __device__ __forceinline__ uint32_t search_level(const GraphView &g, const WaveM
                                                  WorkCtr &ctr, int lane, bool &fail)
 {
     static_assert(FMT == FMT_F32 || MODE == MODE_AVX, "compressed storage: AVX2 summation order only (dim % 32 == 0)");
-    if constexpr (MODE == MODE_AVX) return search_level_v2<MODE, T, R, FMT>(g, m, vis, qr, ep, ef, lc, ctr, lane, fail);
-    else return search_level_v1<MODE, T, R>(g, m, vis, qr, ep, ef, lc, ctr, lane, fail);
+    // W in registers up to 16 slices of 64 keys (ef <= 1024); beyond that (R = 64: ef up to 4096) W stays in LDS
+    if constexpr (MODE == MODE_AVX && R <= 16) return search_level_v2<MODE, T, R, FMT>(g, m, vis, qr, ep, ef, lc, ctr, lane, fail);
+    else {
+        static_assert(FMT == FMT_F32 || R <= 16, "compressed storage with ef_construction > 1024 is not built");
+        return search_level_v1<MODE, T, R>(g, m, vis, qr, ep, ef, lc, ctr, lane, fail);
+    }
 }
 
 } // namespace hnsw

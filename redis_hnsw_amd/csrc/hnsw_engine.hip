@@ -220,6 +220,7 @@ int pick_R(uint32_t need)
     if (need <= 256) return 4;
     if (need <= 512) return 8;
     if (need <= 1024) return 16;
+    if (need <= 4096) return 64;                 // W in LDS (search_level_v1): the slow, exact form for what nobody runs in production
     return 0;
 }
 
@@ -841,8 +842,8 @@ hnsw_status hnsw_create(uint32_t dim, uint32_t m, uint32_t ef_construction, uint
     *out = nullptr;
     hnsw_index *h = new hnsw_index();
     *out = h; // returned even on failure so the caller can read hnsw_last_error()
-    if (dim == 0 || m < 2 || m > 64 || ef_construction == 0 || ef_construction > 1024)
-        return fail(h, HNSW_ERR_INVALID, "supported: dim >= 1, 2 <= M <= 64, 1 <= EFCON <= 1024");
+    if (dim == 0 || m < 2 || m > 64 || ef_construction == 0 || ef_construction > 4096)
+        return fail(h, HNSW_ERR_INVALID, "supported: dim >= 1, 2 <= M <= 64, 1 <= EFCON <= 4096");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(h, HNSW_ERR_DEVICE, "no HIP device: this engine has no CPU path");
@@ -942,6 +943,7 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
         if (!value || h->fmt == want) return HNSW_OK;
         if (h->fmt) return fail(h, HNSW_ERR_INVALID, "the index is already compressed (the original vectors are gone)");
         if (h->mode != MODE_AVX) return fail(h, HNSW_ERR_INVALID, std::string(key) + " needs dim % 32 == 0 (the AVX2 summation order, metrics.rs:18)");
+        if (h->efc > 1024) return fail(h, HNSW_ERR_INVALID, std::string(key) + " serves ef_construction <= 1024");
         ON_DEVICE(h);
         HIP_TRY(h, hipDeviceSynchronize());
         const size_t nel = (size_t)h->cap * h->dim, esz = want == FMT_BF16 ? 2 : 1;

@@ -37,6 +37,7 @@ hnsw_status launch_insert_r(hnsw_index *h, const InsertCfg &c, bool plan, uint32
     case 4: return plan ? launch_plan_t<MODE, T, 4>(h, c, first, count) : launch_commit_t<MODE, T, 4>(h, c, first);
     case 8: return plan ? launch_plan_t<MODE, T, 8>(h, c, first, count) : launch_commit_t<MODE, T, 8>(h, c, first);
     case 16: return plan ? launch_plan_t<MODE, T, 16>(h, c, first, count) : launch_commit_t<MODE, T, 16>(h, c, first);
+    case 64: return plan ? launch_plan_t<MODE, T, 64>(h, c, first, count) : launch_commit_t<MODE, T, 64>(h, c, first);
     }
     return fail(h, HNSW_ERR_INVALID, "bad R");
 }

@@ -81,6 +81,7 @@ hnsw_status occ_delete_r(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, u
     case 4: return occ_delete_t<MODE, T, 4>(h, c, ob, id);
     case 8: return occ_delete_t<MODE, T, 8>(h, c, ob, id);
     case 16: return occ_delete_t<MODE, T, 16>(h, c, ob, id);
+    case 64: return occ_delete_t<MODE, T, 64>(h, c, ob, id);
     }
     return fail(h, HNSW_ERR_INVALID, "bad R");
 }
@@ -93,6 +94,7 @@ hnsw_status occ_round_r(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, ui
     case 4: return occ_round_t<MODE, T, 4>(h, c, ob, head, count, end_node);
     case 8: return occ_round_t<MODE, T, 8>(h, c, ob, head, count, end_node);
     case 16: return occ_round_t<MODE, T, 16>(h, c, ob, head, count, end_node);
+    case 64: return occ_round_t<MODE, T, 64>(h, c, ob, head, count, end_node);
     }
     return fail(h, HNSW_ERR_INVALID, "bad R");
 }

@@ -42,8 +42,9 @@ hnsw_status launch_search_r(hnsw_index *h, int R, const float *dQ, uint32_t B, u
     case 4: return launch_search_t<MODE, T, 4, FMT_F32>(h, dQ, B, k, d_ids, d_sims, d_nout, st);
     case 8: return launch_search_t<MODE, T, 8, FMT_F32>(h, dQ, B, k, d_ids, d_sims, d_nout, st);
     case 16: return launch_search_t<MODE, T, 16, FMT_F32>(h, dQ, B, k, d_ids, d_sims, d_nout, st);
+    case 64: return launch_search_t<MODE, T, 64, FMT_F32>(h, dQ, B, k, d_ids, d_sims, d_nout, st);
     }
-    return fail(h, HNSW_ERR_INVALID, "ef_construction > 1024 is not supported");
+    return fail(h, HNSW_ERR_INVALID, "ef_construction > 4096 is not supported");
 }
 
 // compressed storage (bf16 / fp8 rows): any dim % 32 == 0, query pieces in LDS (T = 0)
@@ -57,7 +58,7 @@ hnsw_status launch_search_fmt(hnsw_index *h, int R, const float *dQ, uint32_t B,
     case 8: return launch_search_t<MODE_AVX, 0, 8, FMT>(h, dQ, B, k, d_ids, d_sims, d_nout, st);
     case 16: return launch_search_t<MODE_AVX, 0, 16, FMT>(h, dQ, B, k, d_ids, d_sims, d_nout, st);
     }
-    return fail(h, HNSW_ERR_INVALID, "ef_construction > 1024 is not supported");
+    return fail(h, HNSW_ERR_INVALID, "compressed storage serves ef_construction <= 1024");
 }
 
 #if HNSW_VARIANT == 4

@@ -630,6 +630,40 @@ def test_wide_rows_and_large_ef(eng, oracle_mod, n, dim, m, ef, k):
     gi.close()
 
 
+@pytest.mark.parametrize("n,dim,m,ef,k", [(2000, 32, 8, 2000, 50), (1500, 128, 16, 3000, 10), (1200, 12, 5, 1500, 20)])
+def test_ef_construction_beyond_1024(eng, oracle_mod, n, dim, m, ef, k):
+    """The reference takes any EFCON (core.rs:322-347, src/lib.rs:39-56).  Beyond 1024 the engine keeps W in LDS
+    instead of registers (up to 4096: the slow, exact form): HNSW.NODE.ADD one call at a time and as a batch,
+    HNSW.NODE.DEL and HNSW.SEARCH against the oracle -- graphs row for row, answers and counters bit for bit.
+    ef larger than the index (every search returns the whole graph) and the scalar metric order included."""
+    V = make_data(n, dim, seed=83)
+    lv = oracle_mod.draw_levels(n, m, 6)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch(V, lv)
+    gi = eng.Index("bigef", dim, m, ef)
+    n1 = 40
+    for i in range(n1):
+        gi.add_node("node%d" % i, V[i], level=int(lv[i]))
+    gi.add_batch(V[n1:], names=["node%d" % i for i in range(n1, n)], levels=lv[n1:], mode="exact")
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    for v in (3, 77, 500):
+        o.delete(v)
+        gi.delete_node("node%d" % v)
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    Q = make_data(24, dim, seed=2)
+    gi.reset_counters()
+    ids, sims, n_out = gi.search_batch(Q, k)
+    oids, osims, on, oct = o.search_batch(Q, k)
+    assert np.array_equal(n_out, on)
+    valid = np.arange(k)[None, :] < on[:, None]
+    assert np.array_equal(ids[valid], oids[valid]) and np.array_equal(_bits(sims)[valid], _bits(osims)[valid])
+    sc, _ = gi.counters()
+    assert (sc.n_dist, sc.n_ids, sc.n_expand) == (oct.n_dist, oct.n_ids, oct.n_expand)
+    gi.close()
+
+
 def test_restride_keeps_the_graph(eng, oracle_mod):
     """widening the adjacency tables (what the engine does when degrees approach the row capacity)
     in the middle of an exact build must not change anything"""
