@@ -23,6 +23,7 @@ UNITS = [
     ("hnsw_tu_search.hip", [0, 1, 2, 3, 4, 5], ["hnsw_kernels.hpp"]),
     ("hnsw_tu_insert.hip", [0, 1, 2, 3], []),
     ("hnsw_tu_occ.hip", [0, 1, 2, 3], []),
+    ("hnsw_tu_occteam.hip", [0, 1, 2, 3], []),
     ("hnsw_tu_planlean.hip", [0, 1], ["hnsw_plan_lean.hpp", "hnsw_search_lean.hpp", "hnsw_search_duo.hpp"]),
     ("hnsw_tu_planduo.hip", [0, 1], ["hnsw_plan_lean.hpp", "hnsw_search_lean.hpp", "hnsw_search_duo.hpp"]),
     ("hnsw_group.hip", [None], []),                   # one process, several GPUs: host code above the C ABI
@@ -88,7 +89,7 @@ def _compile_and_link(lib_path, obj_dir, force=False, extra_flags=(), workers=No
                 raise RuntimeError("%s\n%s%s" % (" ".join(cmd), p.stdout[-4000:], p.stderr[-8000:]))
             return obj
         # the heaviest units first (OCC, insert), so the pool drains evenly
-        todo.sort(key=lambda j: ("occ" not in j[0], "insert" not in j[0]))
+        todo.sort(key=lambda j: ("occ" not in j[0], "insert" not in j[0]))   # (occ, occteam first)
         with concurrent.futures.ThreadPoolExecutor(max_workers=workers) as ex:
             list(ex.map(run, todo))
     objs = [obj for obj, _, _ in jobs]

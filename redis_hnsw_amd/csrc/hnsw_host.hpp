@@ -126,6 +126,7 @@ struct hnsw_index {
     bool duo = true;                 // ... in its two-wave form (hnsw_search_duo.hpp) when at most duo_max queries are in flight
     uint32_t duo_max = 1024;         // 4 workgroups of two waves per CU: every query gets two SIMD slots
     bool last_search_duo = false;
+    bool commit_team = true;         // the commit kernels run with three helper wavefronts (hnsw_tu_occteam.hip)
     bool plan_duo = true;            // insert plans (always lone chains) run in the two-wave form when at most plan_duo_max are launched at once
     uint32_t plan_duo_max = 256;     // one two-wave workgroup per CU
     size_t lds_reserve = 0;          // LDS a kernel needs besides the wave's own share (the OCC kernels' validation scratch)
@@ -262,6 +263,12 @@ template <bool WIDE>
 hnsw_status launch_plan_lean_v(hnsw_index *h, const InsertCfg &c, uint32_t first, uint32_t count, uint32_t idbits);
 template <bool WIDE>
 hnsw_status launch_occ_plan_lean_v(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t head, uint32_t count, uint32_t idbits);
+// hnsw_tu_occteam.hip: the commit kernels with three helper wavefronts sharing every recomputed select_neighbors
+// (*done stays false when the CU's LDS has no room for the helpers: the caller launches the one-wave kernel)
+template <int MODE, int T>
+hnsw_status occ_commit_team_r(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t end_node, bool *done);
+template <int MODE, int T>
+hnsw_status occ_del_commit_team_r(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t id, bool *done);
 // hnsw_tu_planduo.hip: the same plans with a second wavefront keeping W for their layer searches
 template <bool WIDE>
 hnsw_status launch_plan_duo_v(hnsw_index *h, const InsertCfg &c, uint32_t first, uint32_t count, uint32_t idbits);

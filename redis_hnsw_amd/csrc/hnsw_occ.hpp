@@ -484,20 +484,173 @@ __global__ __launch_bounds__(64, 1) void k_occ_validate(GraphView g, OccBufs ob,
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// A recomputed select_neighbors (core.rs:544-568 / :832-853) spread over the commit workgroup's wavefronts.
+// The committing wave is one wavefront walking the reference's order; what it cannot take from a speculative
+// record it recomputes on the spot -- about one select_neighbors per commit at 1 M nodes, ~60 us of one lone wave's
+// instruction stream, a third of the commit.  select_neighbors returns the m nearest of a POOL (the candidates and
+// their neighbours, core.rs:685-721: a set, whatever the order it is visited in), so the pool splits: wave w of the
+// team takes every (1 + HW)-th candidate of econn, runs the SAME select_topm on that share with a visited set of its
+// own, and the committing wave merges the shares' results -- the m nearest of the union of the shares' m nearest are
+// the m nearest of the pool.  An id reachable through two shares is evaluated twice and shows up as two equal keys
+// (same id, same distance): the merge drops keys it already holds.  The result is the one-wave result, key for key.
+// Helpers sleep at the workgroup barrier between tasks.  Built only in the translation unit that turns the shared
+// code's block-level synchronisations into wave-level ones (hnsw_tu_occteam.hip), like the two-wave plans.
+// ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t TEAM_SELECT = 1u, TEAM_EXIT = 2u;
+constexpr uint32_t kTeamCand = 256;                   // a share of econn: a row holds at most 1 023 ids, a team has >= 4 waves
+struct TeamTask {
+    uint32_t op, e, lc, mmax, nE, ignored, pad0, pad1;
+    uint32_t nS[4], fail[4], n_dist[4], n_ids[4];
+};
+struct TeamCfg {                                      // helper LDS layout (the same for every helper), set by the host
+    uint32_t hbytes;                                  // bytes per helper
+    uint32_t lnb, lcap, tagcfg;                       // its visited table
+    uint32_t gnb;                                     // HBM spill buckets per helper
+};
+__host__ __device__ inline size_t team_fixed_bytes(int T, uint32_t dim)
+{
+    return (size_t)kTeamCand * 8 + 64 * 4 + 64 * 4 + kSelMax * 8 + (T == 0 ? (((size_t)dim * 4 + 15) & ~(size_t)15) : 0);
+}
+__device__ __forceinline__ void team_bar()
+{
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+template <int T>
+__device__ __forceinline__ void team_carve(unsigned char *p, uint32_t dim, const TeamCfg &tc, WaveMem &m, Visited &vis)
+{
+    m.W = reinterpret_cast<uint64_t *>(p); p += (size_t)kTeamCand * 8;
+    m.fresh = reinterpret_cast<uint32_t *>(p); p += 64 * 4;
+    m.dsc = reinterpret_cast<float *>(p); p += 64 * 4;
+    m.S = reinterpret_cast<uint64_t *>(p); p += kSelMax * 8;
+    m.aux = nullptr;
+    m.qlds = reinterpret_cast<float *>(p);
+    if (T == 0) p += ((size_t)dim * 4 + 15) & ~(size_t)15;
+    vis.lds = reinterpret_cast<uint32_t *>(p);
+    vis.lnb = tc.lnb;
+    vis.lcap = tc.lcap;
+    vis.tag_bb = tc.tagcfg & 0xFFu;
+    vis.idbits = tc.tagcfg >> 8;
+    vis.glob_dirty = false;
+    vis.spilled = false;
+    vis.count = 0;
+    vis.bounded = false;
+    vis.lossy = false;
+}
+// this wave's share of econn (sorted nearest first in W0[0..nE)): every nw-th candidate, starting at `wave`
+__device__ __forceinline__ uint32_t team_share(uint64_t *dst, const uint64_t *W0, uint32_t nE, uint32_t wave, uint32_t nw, int lane)
+{
+    const uint32_t n = nE > wave ? (nE - wave + nw - 1) / nw : 0u;
+    for (uint32_t i = lane; i < n; i += 64) dst[i] = W0[i * nw + wave];
+    __syncthreads();
+    return n;
+}
+
+// a helper wavefront of the commit workgroup: serves TEAM_SELECT tasks until TEAM_EXIT
+template <int MODE, int T>
+__device__ __forceinline__ void team_helper(const GraphView &g, volatile TeamTask *task, const uint64_t *W0, unsigned char *hmem,
+                                            const TeamCfg &tc, uint32_t *hspill, uint32_t wave, uint32_t nw, int lane)
+{
+    WaveMem m;
+    Visited vis;
+    team_carve<T>(hmem, g.dim, tc, m, vis);
+    vis.glob = hspill + (size_t)(wave - 1) * tc.gnb * 8;
+    vis.gnb = tc.gnb;
+    for (;;) {
+        team_bar();                                         // a task is posted
+        const uint32_t op = __builtin_amdgcn_readfirstlane(task->op);
+        if (op == TEAM_EXIT) break;
+        const uint32_t e = __builtin_amdgcn_readfirstlane(task->e), lc = __builtin_amdgcn_readfirstlane(task->lc);
+        const uint32_t mmax = __builtin_amdgcn_readfirstlane(task->mmax), nE = __builtin_amdgcn_readfirstlane(task->nE);
+        const uint32_t ignored = __builtin_amdgcn_readfirstlane(task->ignored);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the committing wave has rewritten rows since the last task
+        const uint32_t n = team_share(m.W, W0, nE, wave, nw, lane);
+        uint32_t nS = 0;
+        bool fail = false;
+        WorkCtr c = {};
+        if (n) {
+            QReg<T> qe;
+            load_query<MODE, T>(g.vec + (size_t)e * g.dim, g.dim, qe, m.qlds, lane);
+            nS = select_topm<MODE, T>(g, m, vis, qe, m.W, n, e, mmax, lc, c, lane, fail, ignored);
+        }
+        if (lane == 0) {
+            task->nS[wave] = nS;
+            task->fail[wave] = fail ? 1u : 0u;
+            task->n_dist[wave] = c.n_dist;
+            task->n_ids[wave] = c.n_ids;
+        }
+        team_bar();                                         // the results are there
+    }
+    if (vis.glob_dirty) visited_clear(vis, lane);
+}
+
+// the committing wave's side: econn is sorted in m.W[0..nE); result in m.S[0..nS)
+template <int MODE, int T>
+__device__ __forceinline__ uint32_t team_select(const GraphView &g, const WaveMem &m, Visited &vis, const QReg<T> &qe, uint32_t nE,
+                                                uint32_t e, uint32_t mmax, uint32_t lc, WorkCtr &ctr, int lane, bool &fail,
+                                                uint32_t ignored, volatile TeamTask *task, uint64_t *W0sub, unsigned char *hmem0,
+                                                const TeamCfg &tc, uint32_t nw)
+{
+    if (lane == 0) {
+        task->op = TEAM_SELECT; task->e = e; task->lc = lc; task->mmax = mmax; task->nE = nE; task->ignored = ignored;
+    }
+    fence_own_writes();                                     // the rows this wave has rewritten, before the helpers read them
+    team_bar();
+    const uint32_t n0 = team_share(W0sub, m.W, nE, 0u, nw, lane);
+    uint32_t nS = n0 ? select_topm<MODE, T>(g, m, vis, qe, W0sub, n0, e, mmax, lc, ctr, lane, fail, ignored) : 0u;
+    team_bar();
+    for (uint32_t w = 1; w < nw; ++w) {
+        const uint32_t nSw = __builtin_amdgcn_readfirstlane(task->nS[w]);
+        fail |= __builtin_amdgcn_readfirstlane(task->fail[w]) != 0u;
+        ctr.n_dist += __builtin_amdgcn_readfirstlane(task->n_dist[w]);
+        ctr.n_ids += __builtin_amdgcn_readfirstlane(task->n_ids[w]);
+        const uint64_t *Sw = reinterpret_cast<const uint64_t *>(hmem0 + (size_t)(w - 1) * tc.hbytes + (size_t)kTeamCand * 8 + 64 * 4 + 64 * 4);
+        for (uint32_t base = 0; base < nSw; base += 64) {
+            const bool have = base + (uint32_t)lane < nSw;
+            const uint64_t key = have ? Sw[base + lane] : ~0ull;
+            // already held (the same id reached through another share)?  m.S is sorted: lower bound, then compare
+            uint32_t lo = 0, hi = nS;
+            while (__ballot(have && lo < hi)) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const uint64_t mv = (have && lo < hi) ? m.S[mid] : 0ull;
+                if (have && lo < hi) { if (mv < key) lo = mid + 1; else hi = mid; }
+            }
+            const bool dup = have && lo < nS && m.S[lo] == key;
+            const uint64_t worst = nS == mmax ? m.S[mmax - 1] : ~0ull;
+            __syncthreads();
+            nS = merge_S(m.S, nS, mmax, key, have && !dup && key < worst, lane);
+        }
+    }
+    return nS;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // commit: one wave, strictly in id order
 // ---------------------------------------------------------------------------------------------------------
-template <int MODE, int T, int R>
-__global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, uint32_t end_node, uint32_t mlinks, uint32_t lnb,
+// HW > 0: the workgroup has HW helper wavefronts that share every recomputed select_neighbors with the committing
+// wave (team_select above); LDS after the committing wave's own carve-up: [TeamTask][its share of econn][helpers].
+template <int MODE, int T, int R, int HW = 0>
+__global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit(GraphView g, OccBufs ob, uint32_t end_node, uint32_t mlinks, uint32_t lnb,
                                                    uint32_t lcap, uint32_t *__restrict__ gspill, uint32_t gnb,
                                                    const uint32_t *__restrict__ plan, uint32_t slack,
-                                                   uint32_t *__restrict__ touched, uint32_t touched_cap)
+                                                   uint32_t *__restrict__ touched, uint32_t touched_cap,
+                                                   uint32_t own_lds = 0, TeamCfg tc = TeamCfg{}, uint32_t *__restrict__ hspill = nullptr)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     OccScratch sc = occ_carve(smem);
     WaveMem m;
     Visited vis;
     carve<R, T, true>(smem + kOccScratchBytes, g.dim, lnb, lcap, m, vis, g.tagcfg);
+    volatile TeamTask *task = reinterpret_cast<volatile TeamTask *>(smem + kOccScratchBytes + own_lds);
+    uint64_t *W0sub = reinterpret_cast<uint64_t *>(smem + kOccScratchBytes + own_lds + sizeof(TeamTask));
+    unsigned char *hmem0 = smem + kOccScratchBytes + own_lds + sizeof(TeamTask) + (size_t)kTeamCand * 8;
+    if constexpr (HW > 0) {
+        const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 6;
+        if (wave > 0) {
+            team_helper<MODE, T>(g, task, m.W, hmem0 + (size_t)(wave - 1) * tc.hbytes, tc, hspill, wave, 1u + HW, lane);
+            return;
+        }
+    }
     vis.glob = gspill;
     vis.gnb = gnb;
     vis.glob_dirty = false;
@@ -630,7 +783,10 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
                         nE = merge_sorted<R>(m.W, nE, R * 64, key, have, lane);
                     }
                     WorkCtr nolog = {};
-                    nS = select_topm<MODE, T>(g, m, vis, qe, m.W, nE, e, mmax, lc, nolog, lane, fail);
+                    if constexpr (HW > 0)
+                        nS = team_select<MODE, T>(g, m, vis, qe, nE, e, mmax, lc, nolog, lane, fail, kEmpty, task, W0sub, hmem0, tc, 1u + HW);
+                    else
+                        nS = select_topm<MODE, T>(g, m, vis, qe, m.W, nE, e, mmax, lc, nolog, lane, fail);
                     if (fail) break;
                     w_dist += cnt + nolog.n_dist;
                     w_ids += cnt + nolog.n_ids;
@@ -662,6 +818,10 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit(GraphView g, OccBufs ob, u
         occ_clear_hash(sc, sl->n_reads, lane);
         n_commit += 1;
         head += 1;
+    }
+    if constexpr (HW > 0) {
+        if (lane == 0) task->op = TEAM_EXIT;
+        team_bar();
     }
     if (vis.glob_dirty) visited_clear(vis, lane);
     if (lane == 0) {
@@ -739,17 +899,28 @@ __global__ __launch_bounds__(64, 1) void k_occ_del_list(GraphView g, OccBufs ob,
     }
 }
 
-template <int MODE, int T, int R>
-__global__ __launch_bounds__(64, 1) void k_occ_del_commit(GraphView g, OccBufs ob, uint32_t id, uint32_t mlinks, uint32_t lnb,
+template <int MODE, int T, int R, int HW = 0>
+__global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_del_commit(GraphView g, OccBufs ob, uint32_t id, uint32_t mlinks, uint32_t lnb,
                                                        uint32_t lcap, uint32_t *__restrict__ gspill, uint32_t gnb,
-                                                       uint32_t *__restrict__ touched, uint32_t touched_cap)
+                                                       uint32_t *__restrict__ touched, uint32_t touched_cap,
+                                                       uint32_t own_lds = 0, TeamCfg tc = TeamCfg{}, uint32_t *__restrict__ hspill = nullptr)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     OccScratch sc = occ_carve(smem);
     WaveMem m;
     Visited vis;
     carve<R, T, true>(smem + kOccScratchBytes, g.dim, lnb, lcap, m, vis, g.tagcfg);
+    volatile TeamTask *task = reinterpret_cast<volatile TeamTask *>(smem + kOccScratchBytes + own_lds);
+    uint64_t *W0sub = reinterpret_cast<uint64_t *>(smem + kOccScratchBytes + own_lds + sizeof(TeamTask));
+    unsigned char *hmem0 = smem + kOccScratchBytes + own_lds + sizeof(TeamTask) + (size_t)kTeamCand * 8;
+    if constexpr (HW > 0) {
+        const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 6;
+        if (wave > 0) {
+            team_helper<MODE, T>(g, task, m.W, hmem0 + (size_t)(wave - 1) * tc.hbytes, tc, hspill, wave, 1u + HW, lane);
+            return;
+        }
+    }
     vis.glob = gspill;
     vis.gnb = gnb;
     vis.glob_dirty = false;
@@ -762,6 +933,10 @@ __global__ __launch_bounds__(64, 1) void k_occ_del_commit(GraphView g, OccBufs o
     OccSlot *sl = &ob.slots[slot];
     if (!sl->planned || sl->node != id || sl->fail) {           // nothing is touched: k_delete_exact takes it
         if (lane == 0) ob.ctl->stop = OCC_STOP_SERIAL;
+        if constexpr (HW > 0) {
+            if (lane == 0) task->op = TEAM_EXIT;
+            team_bar();
+        }
         return;
     }
     const OccRead *reads = ob.reads + (size_t)slot * kOccMaxReads;
@@ -831,7 +1006,10 @@ __global__ __launch_bounds__(64, 1) void k_occ_del_commit(GraphView g, OccBufs o
                     nE = merge_sorted<R>(m.W, nE, R * 64, key, have, lane);
                 }
                 WorkCtr nolog = {};
-                nS = select_topm<MODE, T>(g, m, vis, qe, m.W, nE, n, mmax, lc, nolog, lane, fail, id);
+                if constexpr (HW > 0)
+                    nS = team_select<MODE, T>(g, m, vis, qe, nE, n, mmax, lc, nolog, lane, fail, id, task, W0sub, hmem0, tc, 1u + HW);
+                else
+                    nS = select_topm<MODE, T>(g, m, vis, qe, m.W, nE, n, mmax, lc, nolog, lane, fail, id);
                 if (fail) break;
                 w_dist += cnt + nolog.n_dist;
                 w_ids += cnt + nolog.n_ids;
@@ -845,6 +1023,10 @@ __global__ __launch_bounds__(64, 1) void k_occ_del_commit(GraphView g, OccBufs o
         __syncthreads();
     }
     if (fail && lane == 0) atomicOr(&g.hdr->status, ST_VISITED_OVERFLOW);
+    if constexpr (HW > 0) {
+        if (lane == 0) task->op = TEAM_EXIT;
+        team_bar();
+    }
     if (vis.glob_dirty) visited_clear(vis, lane);
     if (lane == 0) {
         g.hdr->n_touched = nt;

@@ -39,9 +39,16 @@ static hnsw_status occ_round_t(hnsw_index *h, const InsertCfg &c, const OccBufs 
                            h->spill_gnb, h->d_plan, h->select_shortcut ? 1u : 0u, h->occ_log_cap);
     hipLaunchKernelGGL(ks, dim3(count * kOccMaxShr), dim3(64), c.lds, h->stream, gv, ob, head, count, h->m, c.lnb, c.lcap, h->d_spill,
                        h->spill_gnb, kEmpty);
-    hipLaunchKernelGGL(kc, dim3(1), dim3(64), lds_commit, h->stream, gv, ob, end_node, h->m, c.lnb, c.lcap, h->d_spill_one,
-                       h->spill_one_gnb, h->d_plan, h->m + 2 + h->occ_slack_extra, h->occ_want_touched ? h->d_touched : nullptr,
-                       h->occ_want_touched ? h->touched_cap : 0u);
+    bool team = false;
+    if (h->commit_team) {
+        HIP_TRY(h, hipGetLastError());
+        hnsw_status ts = occ_commit_team_r<MODE, T>(h, c, ob, end_node, &team);
+        if (ts != HNSW_OK) return ts;
+    }
+    if (!team)
+        hipLaunchKernelGGL(kc, dim3(1), dim3(64), lds_commit, h->stream, gv, ob, end_node, h->m, c.lnb, c.lcap, h->d_spill_one,
+                           h->spill_one_gnb, h->d_plan, h->m + 2 + h->occ_slack_extra, h->occ_want_touched ? h->d_touched : nullptr,
+                           h->occ_want_touched ? h->touched_cap : 0u, 0u, TeamCfg{}, (uint32_t *)nullptr);
     HIP_TRY(h, hipGetLastError());
     return HNSW_OK;
 }
@@ -67,8 +74,15 @@ static hnsw_status occ_delete_t(hnsw_index *h, const InsertCfg &c, const OccBufs
     const GraphView gv = view_tag(h, c.tagcfg);
     hipLaunchKernelGGL(kl, dim3(1), dim3(64), 0, h->stream, gv, ob, id);
     hipLaunchKernelGGL(ks, dim3(kOccMaxShr), dim3(64), c.lds, h->stream, gv, ob, id, 1u, h->m, c.lnb, c.lcap, h->d_spill, h->spill_gnb, id);
-    hipLaunchKernelGGL(kd, dim3(1), dim3(64), lds_commit, h->stream, gv, ob, id, h->m, c.lnb, c.lcap, h->d_spill_one, h->spill_one_gnb,
-                       h->d_touched, h->touched_cap);
+    bool team = false;
+    if (h->commit_team) {
+        HIP_TRY(h, hipGetLastError());
+        hnsw_status ts = occ_del_commit_team_r<MODE, T>(h, c, ob, id, &team);
+        if (ts != HNSW_OK) return ts;
+    }
+    if (!team)
+        hipLaunchKernelGGL(kd, dim3(1), dim3(64), lds_commit, h->stream, gv, ob, id, h->m, c.lnb, c.lcap, h->d_spill_one, h->spill_one_gnb,
+                           h->d_touched, h->touched_cap, 0u, TeamCfg{}, (uint32_t *)nullptr);
     HIP_TRY(h, hipGetLastError());
     return HNSW_OK;
 }

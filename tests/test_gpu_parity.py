@@ -475,7 +475,7 @@ def test_engine_reproduces_golden(eng, name):
     gi.close()
 
 
-@pytest.mark.parametrize("name", transcribed_cases())
+@pytest.mark.parametrize("name", transcribed_cases("exact"))
 def test_engine_reproduces_the_transcription(eng, name):
     """The independent witness (tests/transcription/: core.rs transcribed into Python, nothing of the oracle in it):
     HNSW.NODE.ADD on the GPU builds the transcription's graph row for row -- through the windowed batch form AND, for
