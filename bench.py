@@ -259,6 +259,9 @@ def main():
     ap.add_argument("--no-clustered", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational legs (large batch, fast build, C1)")
     ap.add_argument("--graph", "--build", dest="graph", default="auto", choices=["auto", "reference", "exact", "fast"])
+    ap.add_argument("--dry", action="store_true",
+                    help="stop after the index is in place on every rank (replication over RCCL for N > 1) and the 64-query "
+                         "identity check: a two-minute proof of the multi-GPU path before a long run; prints one JSON line")
     ap.add_argument("--verify-gather", action="store_true",
                     help="N>1: rank 0 re-runs every rank's first batch on its own replica and compares with the gathered result")
     args = ap.parse_args()
@@ -403,6 +406,33 @@ def main():
         if not same:
             raise SystemExit("index replication: a replica answers differently from rank 0")
 
+    def peer_report():
+        """what this rank's device can reach directly (xGMI peer access), for the N > 1 line"""
+        nd = torch.cuda.device_count()
+        if one_device or nd < 2:
+            return None
+        try:
+            return [int(d) for d in range(nd) if d != local_rank and torch.cuda.can_device_access_peer(local_rank, d)]
+        except (RuntimeError, AssertionError):
+            return None
+
+    if args.dry:
+        info = index.info()
+        mine = dict(rank=rank, device=local_rank, nodes=int(info.node_count), hbm_bytes=int(info.hbm_bytes), peers=peer_report())
+        objs = [mine]
+        if world > 1:
+            objs = [None] * world
+            dist.all_gather_object(objs, mine)
+        if rank == 0:
+            print(json.dumps({"dry": True, "n_gpus": world, "graph": mode, "collective_backend": backend if world > 1 else None,
+                              "rccl_world": world if (world > 1 and backend == "nccl") else None,
+                              "index_replication": replication, "ranks": objs,
+                              "setup_seconds": round(time.time() - t0, 1)}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     # N > 1: the gather of step i runs on its own stream while later steps search
     if world > 1:
         comm_stream = torch.cuda.Stream()
@@ -469,8 +499,9 @@ def main():
     if world > 1:
         # what every rank saw (the driver computes efficiency from `value`; these show the spread behind it)
         objs = [None] * world
-        dist.all_gather_object(objs, dict(rank=rank, seconds=t_local, qps=B * args.steps / t_local))
-        per_rank = dict(qps=[round(o_["qps"], 1) for o_ in objs],
+        dist.all_gather_object(objs, dict(rank=rank, seconds=t_local, qps=B * args.steps / t_local, peers=peer_report()))
+        per_rank = dict(qps=[round(o_["qps"], 1) for o_ in objs], seconds=[round(o_["seconds"], 5) for o_ in objs],
+                        peer_access=[o_["peers"] for o_ in objs],
                         ms_per_step_min=round(1e3 * min(o_["seconds"] for o_ in objs) / args.steps, 4),
                         ms_per_step_max=round(1e3 * max(o_["seconds"] for o_ in objs) / args.steps, 4))
         # the per-step exchange as an RCCL all-gather of the packed [2,B,k] block vs the alternative
@@ -903,6 +934,10 @@ def main():
                     break
         except (OSError, ValueError, KeyError, TypeError):
             pass
+    if per_rank is not None and args.steps:
+        # every rank's own roofline fraction: its steps' algorithmic bytes (rank 0's per-query figure; the ranks' queries
+        # are draws of the same distribution) over its own wall time of the timed region
+        per_rank["roofline_frac"] = [round(bytes_per_launch * args.steps / sec_ / 1e9 / HBM_PEAK_GBS, 4) for sec_ in per_rank["seconds"]]
     roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_source,
                     peak_hbm_spec=HBM_PEAK_GBS, hbm_measured_copy=HBM_MEASURED_GBS,

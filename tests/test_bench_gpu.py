@@ -37,6 +37,17 @@ def test_bench_spawns_two_ranks_and_gather_matches_unsharded():
     assert out["topk_exchange"]["allgather_us"] > 0 and out["topk_exchange"]["d2h_to_pinned_us"] > 0
     assert out["scaling"] == "weak" and out["value"] > 0
     assert out["roofline"]["bound"] == "hbm"
+    # first-contact evidence for a real multi-GPU node: every rank's own roofline fraction and what its device reaches
+    assert len(out["per_rank"]["roofline_frac"]) == 2 and all(f > 0 for f in out["per_rank"]["roofline_frac"])
+    assert len(out["per_rank"]["peer_access"]) == 2
+
+
+def test_bench_dry_run_proves_the_replication_path_in_seconds():
+    """`--dry`: stop after the index is on every rank and the replicas answered 64 queries identically"""
+    out = _run(["--gpus", "2", "--dry"])
+    assert out["dry"] is True and out["n_gpus"] == 2
+    assert out["index_replication"]["replicas_answer_identically"] is True
+    assert [r["rank"] for r in out["ranks"]] == [0, 1] and all(r["nodes"] == 20000 for r in out["ranks"])
 
 
 def test_bench_single_rank_line_has_the_contract_fields():
