@@ -20,7 +20,6 @@ UNITS = [
     ("hnsw_engine.hip", [None], ["hnsw_kernels.hpp", "hnsw_search_lean.hpp", "hnsw_plan_lean.hpp", "hnsw_insert_host.inc"]),
     ("hnsw_tu_lean.hip", [0, 1, 2, 3, 4, 5], ["hnsw_search_lean.hpp"]),
     ("hnsw_tu_duo.hip", [0, 1], ["hnsw_search_lean.hpp", "hnsw_search_duo.hpp"]),
-    ("hnsw_tu_trio.hip", [0, 1], ["hnsw_search_lean.hpp", "hnsw_search_duo.hpp", "hnsw_search_trio.hpp"]),
     ("hnsw_tu_search.hip", [0, 1, 2, 3, 4, 5], ["hnsw_kernels.hpp"]),
     ("hnsw_tu_insert.hip", [0, 1, 2, 3], []),
     ("hnsw_tu_occ.hip", [0, 1, 2, 3], []),

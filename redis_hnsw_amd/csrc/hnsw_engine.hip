@@ -457,14 +457,6 @@ hnsw_status try_launch_lean(hnsw_index *h, const float *dQ, uint32_t B, uint32_t
     }
     const bool wide = h->stride0 > 64 || h->strideU > 64;   // rows of 64..127 ids: two row words per lane
     h->last_search_duo = false;
-    h->last_search_trio = false;
-    if (h->trio && h->duo && h->fmt == FMT_F32 && (uint64_t)B * std::max(h->cur_conc, 1u) <= h->trio_max && idbits - 11 <= 14) {
-        // the loneliest shapes: a third wavefront per query owns the visited set
-        const uint32_t db3 = idbits - 11 > 13 ? 2u : 3u;
-        hnsw_status s3 = wide ? launch_trio_v<true>(h, R, db3, dQ, B, k, idbits, d_ids, d_sims, d_nout, st, done)
-                              : launch_trio_v<false>(h, R, db3, dQ, B, k, idbits, d_ids, d_sims, d_nout, st, done);
-        if (s3 != HNSW_OK || *done) { h->last_search_trio = *done; h->last_search_duo = *done; return s3; }
-    }
     if (h->duo && h->fmt == FMT_F32 && (uint64_t)B * std::max(h->cur_conc, 1u) <= h->duo_max && idbits - 11 <= 14) {
         // few enough queries in flight that each can have two SIMDs: a walker wave and a W-keeper wave per query
         const uint32_t db2 = idbits - 11 > 13 ? 2u : 3u;
@@ -984,8 +976,6 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
     if (!std::strcmp(key, "plan_duo")) { h->plan_duo = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "commit_team")) { h->commit_team = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "plan_duo_max")) { h->plan_duo_max = (uint32_t)std::max<int64_t>(value, 0); return HNSW_OK; }
-    if (!std::strcmp(key, "trio")) { h->trio = value != 0; return HNSW_OK; }
-    if (!std::strcmp(key, "trio_max")) { h->trio_max = (uint32_t)std::max<int64_t>(value, 0); return HNSW_OK; }
     if (!std::strcmp(key, "duo_max")) { h->duo_max = (uint32_t)std::max<int64_t>(value, 0); return HNSW_OK; }
     if (!std::strcmp(key, "grid_stride")) { h->grid_stride = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "query_in_lds")) {     // dims 128 / 768 normally keep the query in registers (T = dim/32)
@@ -1797,7 +1787,7 @@ hnsw_status hnsw_pipeline_info(hnsw_index *h, hnsw_pipeline *out)
 hnsw_status hnsw_debug_last_search_path(hnsw_index *h, uint32_t *lean)
 {
     if (!h || !lean) return HNSW_ERR_INVALID;
-    *lean = (h->last_search_lean ? 1u : 0u) | (h->last_search_duo ? 2u : 0u) | (h->last_search_trio ? 4u : 0u);   // bit 1: a multi-wave form, bit 2: three waves
+    *lean = (h->last_search_lean ? 1u : 0u) | (h->last_search_duo ? 2u : 0u);   // bit 1: its two-wave form
     return HNSW_OK;
 }
 

@@ -126,9 +126,6 @@ struct hnsw_index {
     bool duo = true;                 // ... in its two-wave form (hnsw_search_duo.hpp) when at most duo_max queries are in flight
     uint32_t duo_max = 1024;         // 4 workgroups of two waves per CU: every query gets two SIMD slots
     bool last_search_duo = false;
-    bool trio = true;                // ... and in its three-wave form (hnsw_search_trio.hpp) when at most trio_max are
-    uint32_t trio_max = 512;         // (two three-wave workgroups per CU)
-    bool last_search_trio = false;
     bool commit_team = true;         // the commit kernels run with three helper wavefronts (hnsw_tu_occteam.hip)
     bool plan_duo = true;            // insert plans (always lone chains) run in the two-wave form when at most plan_duo_max are launched at once
     uint32_t plan_duo_max = 256;     // one two-wave workgroup per CU
@@ -254,10 +251,6 @@ hnsw_status launch_lean_v(hnsw_index *h, int R, uint32_t bb, uint32_t db, const 
 template <bool WIDE>
 hnsw_status launch_duo_v(hnsw_index *h, int R, uint32_t db, const float *dQ, uint32_t B, uint32_t k, uint32_t idbits,
                          uint32_t *d_ids, float *d_sims, uint32_t *d_nout, hipStream_t st, bool *done);
-// hnsw_tu_trio.hip: the three-wave form (walker, W-keeper, visited-set wavefront per query, hnsw_search_trio.hpp)
-template <bool WIDE>
-hnsw_status launch_trio_v(hnsw_index *h, int R, uint32_t db, const float *dQ, uint32_t B, uint32_t k, uint32_t idbits,
-                          uint32_t *d_ids, float *d_sims, uint32_t *d_nout, hipStream_t st, bool *done);
 // hnsw_tu_insert.hip
 template <int MODE, int T>
 hnsw_status launch_insert_r(hnsw_index *h, const InsertCfg &c, bool plan, uint32_t first, uint32_t count);

@@ -225,14 +225,6 @@ class Index:
         self._check(f(self._h, C.byref(v)))
         return bool(v.value & 2)
 
-    def last_search_was_trio(self):
-        """development aid: ... and in its three-wave form (a third wavefront owns the visited set)"""
-        f = self._lib.hnsw_debug_last_search_path
-        f.restype, f.argtypes = C.c_int, [_capi.H, _capi.u32p]
-        v = C.c_uint32(0)
-        self._check(f(self._h, C.byref(v)))
-        return bool(v.value & 4)
-
     def lean_blocker(self):
         """development aid: why the specialised dim-128 kernel cannot serve this index ('' = it can)"""
         f = self._lib.hnsw_debug_lean_blocker
