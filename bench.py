@@ -629,6 +629,33 @@ def main():
                     achieved=round(byl / (msl * 1e-3) / 1e9, 1), frac=round(byl / (msl * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
         log("lone %d-query launches: %.3f ms each, %.0f GB/s" % (B, msl, lone["achieved"]))
 
+    # ---- host memory in, host memory out (PCIe both ways; never `value`): hnsw_search_batch pipelines a large
+    # batch itself -- pinned staging, H2D / kernel / D2H of different chunks overlapped on the engine's lanes
+    Qh = Qall[:8 * B]
+    index.search_batch(Qh, k)
+    per_call8 = []
+    for _ in range(6):
+        tc0 = time.perf_counter()
+        hb_ids, _, _ = index.search_batch(Qh, k)
+        per_call8.append(time.perf_counter() - tc0)
+    host_qps = Qh.shape[0] / float(np.median(per_call8))
+    index.search_batch(Qall[:B], k)
+    per_call = []
+    for _ in range(6):
+        tc0 = time.perf_counter()
+        index.search_batch(Qall[:B], k)
+        per_call.append(time.perf_counter() - tc0)
+    host_qps_1024 = B / float(np.median(per_call))
+    host = dict(batch=int(Qh.shape[0]), value=round(host_qps, 1), unit="queries/s", one_batch_of_1024=round(host_qps_1024, 1),
+                per_call_ms=[round(1e3 * x, 3) for x in per_call8], per_call_ms_1024=[round(1e3 * x, 3) for x in per_call],
+                note="hnsw_search_batch from pageable host memory, results back in host memory, one call at a time; the rates are "
+                     "batch / MEDIAN call time of six calls (every call is listed: one call in a run can stall for several ms on "
+                     "the host side)")
+    log("host buffers: %.0f QPS at B=%d (%s ms), %.0f at B=%d (%s ms)" % (
+        host_qps, Qh.shape[0], " ".join("%.2f" % (1e3 * x) for x in per_call8), host_qps_1024, B,
+        " ".join("%.2f" % (1e3 * x) for x in per_call)))
+    pipe = index.pipeline_info()
+
     # ---- one hnsw_search_batch_device CALL per size, calls back to back on one stream: the engine splits a call
     # into 1024-query chunks over its own lanes and joins them back, so every call pays its own drain
     big = None
@@ -845,33 +872,6 @@ def main():
                 bf16 = ent
             else:
                 fp8 = ent
-
-    # ---- host memory in, host memory out (PCIe both ways; never `value`): hnsw_search_batch pipelines a large
-    # batch itself -- pinned staging, H2D / kernel / D2H of different chunks overlapped on the engine's lanes
-    Qh = Qall[:8 * B]
-    index.search_batch(Qh, k)
-    per_call8 = []
-    for _ in range(6):
-        tc0 = time.perf_counter()
-        hb_ids, _, _ = index.search_batch(Qh, k)
-        per_call8.append(time.perf_counter() - tc0)
-    host_qps = Qh.shape[0] / float(np.median(per_call8))
-    index.search_batch(Qall[:B], k)
-    per_call = []
-    for _ in range(6):
-        tc0 = time.perf_counter()
-        index.search_batch(Qall[:B], k)
-        per_call.append(time.perf_counter() - tc0)
-    host_qps_1024 = B / float(np.median(per_call))
-    host = dict(batch=int(Qh.shape[0]), value=round(host_qps, 1), unit="queries/s", one_batch_of_1024=round(host_qps_1024, 1),
-                per_call_ms=[round(1e3 * x, 3) for x in per_call8], per_call_ms_1024=[round(1e3 * x, 3) for x in per_call],
-                note="hnsw_search_batch from pageable host memory, results back in host memory, one call at a time; the rates are "
-                     "batch / MEDIAN call time of six calls (every call is listed: one call in a run can stall for several ms on "
-                     "the host side)")
-    log("host buffers: %.0f QPS at B=%d (%s ms), %.0f at B=%d (%s ms)" % (
-        host_qps, Qh.shape[0], " ".join("%.2f" % (1e3 * x) for x in per_call8), host_qps_1024, B,
-        " ".join("%.2f" % (1e3 * x) for x in per_call)))
-    pipe = index.pipeline_info()
 
     # ---- one process, every visible GPU (SURVEY 8e "one process, 8 devices"; what a Redis module would use): the
     # C ABI's hnsw_group_* layer -- replicas by peer copies, the host batch split over the members, one host thread
