@@ -17,7 +17,8 @@ _COMMON = ["hnsw_host.hpp", "hnsw_device.hpp", "hnsw_insert.hpp", "hnsw_occ.hpp"
            os.path.join("..", "..", "include", "hnsw_mi355x.h")]
 # (source, variants, headers besides _COMMON)
 UNITS = [
-    ("hnsw_engine.hip", [None], ["hnsw_kernels.hpp", "hnsw_search_lean.hpp", "hnsw_plan_lean.hpp", "hnsw_insert_host.inc"]),
+    ("hnsw_engine.hip", [None], ["hnsw_kernels.hpp", "hnsw_search_lean.hpp", "hnsw_search_duo.hpp", "hnsw_plan_lean.hpp", "hnsw_insert_host.inc",
+                                 "hnsw_pipeline.inc", "hnsw_transfer.inc", "hnsw_snapshot.inc"]),
     ("hnsw_tu_lean.hip", [0, 1, 2, 3, 4, 5], ["hnsw_search_lean.hpp"]),
     ("hnsw_tu_duo.hip", [0, 1], ["hnsw_search_lean.hpp", "hnsw_search_duo.hpp"]),
     ("hnsw_tu_search.hip", [0, 1, 2, 3, 4, 5], ["hnsw_kernels.hpp"]),

@@ -509,272 +509,8 @@ hnsw_status launch_search(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k
     return s != HNSW_OK ? s : note_search(h, st);
 }
 
-// ---- the engine's own search pipeline --------------------------------------------------------------------
-// A batch larger than one chunk is split into chunks that run round-robin on kPipe lanes: lane 0 is the stream
-// the call is ordered on (the engine's for the host-buffer form, the caller's for the _device form), lanes
-// 1.. are engine-owned streams.  Several chunks in flight keep the chip's 2048 wave slots full while the long
-// queries of a chunk drain; in the host-buffer form a lane's H2D copy, kernel and D2H copy also
-// overlap the other lanes', and the host stages chunk i+1 into pinned memory while chunk i runs.
-// Lanes only overlap if each sits on a hardware queue of its own.  The HIP runtime hands new streams distinct
-// queues until GPU_MAX_HW_QUEUES (default 4) are in use and multiplexes after that; the library asks for 8 in
-// its load-time constructor (effective when it is loaded before the runtime starts), and -- because that cannot
-// be relied on -- MEASURES the overlap when the lanes are created: a spin kernel on one lane against the same
-// kernel on all lanes at once.  Lanes that serialise are re-created with distinct stream priorities (each
-// priority level has its own queue pool) and measured again; what was found is reported by
-// hnsw_pipeline_info(), printed once on stderr when the lanes still serialise, and fatal under
-// HNSW_REQUIRE_OVERLAP=1.
-__global__ void k_spin(unsigned long long ticks)
-{
-    const unsigned long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
-}
+#include "hnsw_pipeline.inc"   // the engine's own search pipeline (lanes, overlap probe, pinned staging)
 
-hnsw_status pipe_probe(hnsw_index *h, float *ratio)
-{
-    auto lane = [&](uint32_t l) { return l == 0 ? h->stream : h->pipe_st[l]; };
-    auto run = [&](uint32_t nl, double *secs) -> hnsw_status {
-        for (uint32_t l = 0; l < hnsw_index::kPipe; ++l) HIP_TRY(h, hipStreamSynchronize(lane(l)));
-        const auto t0 = std::chrono::steady_clock::now();
-        for (uint32_t l = 0; l < nl; ++l) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, lane(l), 20000ull);   // 200 us at 100 MHz
-        HIP_TRY(h, hipGetLastError());
-        for (uint32_t l = 0; l < nl; ++l) HIP_TRY(h, hipStreamSynchronize(lane(l)));
-        *secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        return HNSW_OK;
-    };
-    double t1 = 0, tn = 0, scratch = 0;
-    hnsw_status s;
-    if ((s = run(hnsw_index::kPipe, &scratch)) != HNSW_OK) return s;   // first launch loads the code object
-    if ((s = run(1, &t1)) != HNSW_OK || (s = run(hnsw_index::kPipe, &tn)) != HNSW_OK) return s;
-    *ratio = (float)(tn / std::max(t1, 1e-9));
-    return HNSW_OK;
-}
-
-hnsw_status ensure_pipe(hnsw_index *h)
-{
-    if (h->pipe_overlap >= 0) return HNSW_OK;
-    for (uint32_t l = 1; l < hnsw_index::kPipe; ++l) {
-        HIP_TRY(h, hipStreamCreateWithFlags(&h->pipe_st[l], hipStreamNonBlocking));
-        HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_done[l], hipEventDisableTiming));
-    }
-    HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_done[0], hipEventDisableTiming));
-    HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_fork, hipEventDisableTiming));
-    float ratio = 0.f;
-    hnsw_status s = pipe_probe(h, &ratio);
-    if (s != HNSW_OK) return s;
-    if (ratio > 1.6f) {
-        // the lanes share a hardware queue: one stream per priority level instead
-        int least = 0, greatest = 0;
-        HIP_TRY(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
-        if (least != greatest) {
-            for (uint32_t l = 1; l < hnsw_index::kPipe; ++l) {
-                HIP_TRY(h, hipStreamDestroy(h->pipe_st[l]));
-                h->pipe_st[l] = nullptr;
-                HIP_TRY(h, hipStreamCreateWithPriority(&h->pipe_st[l], hipStreamNonBlocking, l == 1 ? greatest : least));
-            }
-            h->pipe_prio = true;
-            if ((s = pipe_probe(h, &ratio)) != HNSW_OK) return s;
-        }
-    }
-    h->pipe_probe_ratio = ratio;
-    h->pipe_overlap = ratio <= 1.6f ? 1 : 0;
-    if (!h->pipe_overlap) {
-        static bool warned = false;
-        if (!warned) {
-            warned = true;
-            fprintf(stderr, "libhnsw_mi355x: the search pipeline's %u streams do not overlap (probe ratio %.2f): hardware queues are "
-                            "shared -- export GPU_MAX_HW_QUEUES=8 before the HIP runtime starts; batched searches run at about "
-                            "2/3 of their throughput until then\n", hnsw_index::kPipe, (double)ratio);
-        }
-        if (std::getenv("HNSW_REQUIRE_OVERLAP"))
-            return fail(h, HNSW_ERR_DEVICE, "search pipeline streams share a hardware queue (HNSW_REQUIRE_OVERLAP is set)");
-    }
-    return HNSW_OK;
-}
-
-hnsw_status ensure_pipe_stage(hnsw_index *h, uint32_t chunk, uint32_t k)
-{
-    const size_t nq = (size_t)chunk * h->dim, nr = 2 * (size_t)chunk * k + chunk;
-    if (nq <= h->pipe_q_words && nr <= h->pipe_r_words) return HNSW_OK;
-    const size_t wq = std::max(nq, h->pipe_q_words), wr = std::max(nr, h->pipe_r_words);
-    for (uint32_t l = 0; l < hnsw_index::kPipe; ++l) {
-        hipStream_t st = l == 0 ? h->stream : h->pipe_st[l];
-        HIP_TRY(h, hipStreamSynchronize(st));
-        dev_free(h, h->pipe_dq[l], h->pipe_q_words);
-        dev_free(h, h->pipe_dres[l], h->pipe_r_words);
-        if (h->pipe_hq[l]) (void)hipHostFree(h->pipe_hq[l]);
-        if (h->pipe_hres[l]) (void)hipHostFree(h->pipe_hres[l]);
-        h->pipe_hq[l] = nullptr; h->pipe_hres[l] = nullptr;
-    }
-    h->pipe_q_words = h->pipe_r_words = 0;
-    hnsw_status s;
-    for (uint32_t l = 0; l < hnsw_index::kPipe; ++l) {
-        if ((s = dev_alloc(h, &h->pipe_dq[l], wq)) != HNSW_OK || (s = dev_alloc(h, &h->pipe_dres[l], wr)) != HNSW_OK) return s;
-        HIP_TRY(h, hipHostMalloc((void **)&h->pipe_hq[l], wq * 4, hipHostMallocDefault));
-        HIP_TRY(h, hipHostMalloc((void **)&h->pipe_hres[l], wr * 4, hipHostMallocDefault));
-    }
-    h->pipe_q_words = wq;
-    h->pipe_r_words = wr;
-    // A stream's first LARGE copy sets up its copy path (measured: 5-6 ms per lane at the first 512 KB H2D copy, in
-    // the middle of the first large batch otherwise; a 256-byte copy does not trigger it): one full-size copy in
-    // each direction per lane now, once per handle.
-    if (!h->pipe_copy_warm) {
-        for (uint32_t l = 0; l < hnsw_index::kPipe; ++l) {
-            hipStream_t st = l == 0 ? h->stream : h->pipe_st[l];
-            HIP_TRY(h, hipMemcpyAsync(h->pipe_dq[l], h->pipe_hq[l], wq * 4, hipMemcpyHostToDevice, st));
-            HIP_TRY(h, hipMemcpyAsync(h->pipe_hres[l], h->pipe_dres[l], wr * 4, hipMemcpyDeviceToHost, st));
-        }
-        for (uint32_t l = 0; l < hnsw_index::kPipe; ++l) HIP_TRY(h, hipStreamSynchronize(l == 0 ? h->stream : h->pipe_st[l]));
-        h->pipe_copy_warm = true;
-    }
-    return HNSW_OK;
-}
-
-// chunk sizes: as few chunks of <= pipe_chunk queries as cover the batch, equal to within one query
-inline uint32_t pipe_chunks(const hnsw_index *h, uint32_t B, uint32_t *per)
-{
-    const uint32_t n = (B + h->pipe_chunk - 1) / h->pipe_chunk;
-    *per = (B + n - 1) / n;
-    return n;
-}
-
-// copy while checking: the host entry points refuse non-finite components (see all_finite)
-bool copy_finite(float *dst, const float *src, size_t n)
-{
-    uint32_t bad = 0;
-    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
-    uint32_t *d32 = reinterpret_cast<uint32_t *>(dst);
-    for (size_t i = 0; i < n; ++i) {
-        const uint32_t u = s32[i];
-        d32[i] = u;
-        bad |= ((u & 0x7F800000u) == 0x7F800000u) ? 1u : 0u;
-    }
-    return bad == 0;
-}
-
-// hnsw_search_batch for B > kPinnedBatch: chunks through pinned staging on the lanes, copies and kernels overlapped
-hnsw_status search_batch_pipelined(hnsw_index *h, const float *Q, uint32_t B, uint32_t k, uint32_t *ids, float *sims,
-                                   uint32_t *n_out)
-{
-    hnsw_status s;
-    if ((s = ensure_pipe(h)) != HNSW_OK) return s;
-    uint32_t per = 0;
-    const uint32_t nch = pipe_chunks(h, B, &per);
-    if ((s = ensure_pipe_stage(h, per, k)) != HNSW_OK) return s;
-    const uint32_t lanes = std::min(nch, hnsw_index::kPipe);
-    auto lane_st = [&](uint32_t l) { return l == 0 ? h->stream : h->pipe_st[l]; };
-    // Whatever a launch may still enqueue on the engine's stream must be there BEFORE the other lanes take their
-    // dependency on it: the HBM visited tables are (re)allocated and filled on h->stream when the index has grown
-    // (or on the very first search), and a chunk on lane 1 that started under that fill read and lost visited
-    // marks -- duplicate ids in its answers (found by scripts/fuzz_search.py; launch_search's own call is a no-op then)
-    if ((s = ensure_spill(h)) != HNSW_OK) return s;
-    // the graph was written on the engine's stream: the other lanes start after it
-    if (lanes > 1) {
-        HIP_TRY(h, hipEventRecord(h->ev_sync, h->stream));
-        for (uint32_t l = 1; l < lanes; ++l) HIP_TRY(h, hipStreamWaitEvent(h->pipe_st[l], h->ev_sync, 0));
-    }
-    h->pipe_inflight = lanes;
-    struct Restore { hnsw_index *h; ~Restore() { h->pipe_inflight = 1; } } restore{h};
-    bool overflow = false;
-    const bool trace = std::getenv("HNSW_PIPE_TRACE") != nullptr;
-    const auto tr0 = std::chrono::steady_clock::now();
-    auto tr = [&](const char *what, uint32_t c) {
-        if (trace) fprintf(stderr, "[pipe %8.1f us] %s %u\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count(), what, c);
-    };
-    auto collect = [&](uint32_t c) -> hnsw_status {       // chunk c's results: pinned -> the caller's buffers
-        const uint32_t l = c % hnsw_index::kPipe, off = c * per, cb = std::min(per, B - off);
-        tr("wait", c);
-        HIP_TRY(h, hipEventSynchronize(h->pipe_done[l]));
-        tr("done", c);
-        const uint32_t *r = h->pipe_hres[l];
-        const size_t nk = (size_t)cb * k;
-        std::memcpy(ids + (size_t)off * k, r, nk * 4);
-        std::memcpy(sims + (size_t)off * k, r + nk, nk * 4);
-        std::memcpy(n_out + off, r + 2 * nk, (size_t)cb * 4);
-        for (uint32_t b = 0; b < cb; ++b) overflow |= n_out[off + b] == kEmpty;
-        return HNSW_OK;
-    };
-    for (uint32_t c = 0; c < nch; ++c) {
-        const uint32_t l = c % hnsw_index::kPipe, off = c * per, cb = std::min(per, B - off);
-        if (c >= hnsw_index::kPipe && (s = collect(c - hnsw_index::kPipe)) != HNSW_OK) return s;   // frees lane l's staging
-        const size_t nq = (size_t)cb * h->dim, nk = (size_t)cb * k;
-        tr("stage", c);
-        if (!copy_finite(h->pipe_hq[l], Q + (size_t)off * h->dim, nq)) {
-            for (uint32_t d = 0; d < lanes; ++d) (void)hipStreamSynchronize(lane_st(d));
-            return fail(h, HNSW_ERR_INVALID, "non-finite query component");
-        }
-        hipStream_t st = lane_st(l);
-        tr("enqueue", c);
-        HIP_TRY(h, hipMemcpyAsync(h->pipe_dq[l], h->pipe_hq[l], nq * 4, hipMemcpyHostToDevice, st));
-        tr("h2d", c);
-        uint32_t *d_ids = h->pipe_dres[l], *d_nout = h->pipe_dres[l] + 2 * nk;
-        float *d_sims = reinterpret_cast<float *>(h->pipe_dres[l] + nk);
-        if ((s = launch_search(h, h->pipe_dq[l], cb, k, d_ids, d_sims, d_nout, st)) != HNSW_OK) return s;
-        tr("launched", c);
-        HIP_TRY(h, hipMemcpyAsync(h->pipe_hres[l], h->pipe_dres[l], (2 * nk + cb) * 4, hipMemcpyDeviceToHost, st));
-        tr("d2h", c);
-        HIP_TRY(h, hipEventRecord(h->pipe_done[l], st));
-        tr("enqueued", c);
-    }
-    for (uint32_t c = nch > hnsw_index::kPipe ? nch - hnsw_index::kPipe : 0; c < nch; ++c)
-        if ((s = collect(c)) != HNSW_OK) return s;
-    if (overflow) return fail(h, HNSW_ERR_CAPACITY, "visited-set spill table overflow");
-    return HNSW_OK;
-}
-
-// hnsw_search_batch_device for large batches: chunks on the caller's stream (lane 0) and the engine's lanes,
-// joined back into the caller's stream before returning (nothing is synchronised)
-hnsw_status search_device_pipelined(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t *d_ids, float *d_sims,
-                                    uint32_t *d_nout, hipStream_t st)
-{
-    hnsw_status s;
-    if ((s = ensure_pipe(h)) != HNSW_OK) return s;
-    uint32_t per = 0;
-    const uint32_t nch = pipe_chunks(h, B, &per);
-    const uint32_t lanes = std::min(nch, hnsw_index::kPipe);
-    HIP_TRY(h, hipEventRecord(h->pipe_fork, st));        // inputs are ready in `st` order; so is the graph (ev_sync above)
-    for (uint32_t l = 1; l < lanes; ++l) HIP_TRY(h, hipStreamWaitEvent(h->pipe_st[l], h->pipe_fork, 0));
-    h->pipe_inflight = lanes;
-    struct Restore { hnsw_index *h; ~Restore() { h->pipe_inflight = 1; } } restore{h};
-    for (uint32_t c = 0; c < nch; ++c) {
-        const uint32_t l = c % hnsw_index::kPipe, off = c * per, cb = std::min(per, B - off);
-        if ((s = launch_search(h, dQ + (size_t)off * h->dim, cb, k, d_ids + (size_t)off * k, d_sims + (size_t)off * k,
-                               d_nout + off, l == 0 ? st : h->pipe_st[l])) != HNSW_OK)
-            return s;
-    }
-    for (uint32_t l = 1; l < lanes; ++l) {
-        HIP_TRY(h, hipEventRecord(h->pipe_done[l], h->pipe_st[l]));
-        HIP_TRY(h, hipStreamWaitEvent(st, h->pipe_done[l], 0));
-    }
-    return HNSW_OK;
-}
-
-// Staging of the host-buffer entry points: queries in, one result block [ids B*k][sims B*k][n_out B] out
-// (a single copy back), and a pinned host mirror for small batches -- a HNSW.SEARCH command is one query,
-// where the pageable-memory staging the runtime would do costs more than the transfers themselves.
-hnsw_status ensure_stage(hnsw_index *h, uint32_t B, uint32_t k)
-{
-    size_t nq = (size_t)B * h->dim, nr = 2 * (size_t)B * k + B;
-    hnsw_status s;
-    if (nq > h->stage_q) {
-        dev_free(h, h->d_Q, h->stage_q);
-        if ((s = dev_alloc(h, &h->d_Q, nq)) != HNSW_OK) return s;
-        h->stage_q = nq;
-    }
-    if (nr > h->stage_r) {
-        dev_free(h, h->d_res, h->stage_r);
-        if ((s = dev_alloc(h, &h->d_res, nr)) != HNSW_OK) return s;
-        h->stage_r = nr;
-    }
-    const size_t pin_words = nq + nr;
-    if (pin_words > h->pinned_words) {
-        if (h->h_pinned) (void)hipHostFree(h->h_pinned);
-        h->h_pinned = nullptr;
-        h->pinned_words = 0;
-        HIP_TRY(h, hipHostMalloc((void **)&h->h_pinned, pin_words * 4, hipHostMallocDefault));
-        h->pinned_words = pin_words;
-    }
-    return HNSW_OK;
-}
 
 hnsw_status push_header(hnsw_index *h)
 {
@@ -1239,477 +975,8 @@ hnsw_status hnsw_search(hnsw_index *h, const float *q, uint32_t dim, uint32_t k,
     return hnsw_search_batch(h, q, 1, dim, k, ids, sims, n_out);
 }
 
-hnsw_status hnsw_import(hnsw_index *h, uint32_t n, const float *vectors, const uint32_t *levels,
-                        int64_t enterpoint, uint32_t n_layers, const uint64_t *const *row_ptr,
-                        const uint32_t *const *col)
-{
-    if (!h) return HNSW_ERR_INVALID;
-    if (h->fmt) return fail(h, HNSW_ERR_INVALID, "the index is read-only in compressed (bf16 / fp8) storage mode");
-    if (h->n != 0) return fail(h, HNSW_ERR_INVALID, "hnsw_import needs an empty index");
-    if (n == 0) return HNSW_OK;
-    if (enterpoint < 0 || enterpoint >= (int64_t)n || n_layers == 0 || n_layers > kMaxLayers)
-        return fail(h, HNSW_ERR_INVALID, "bad enterpoint / layer count");
-    ON_DEVICE(h);
-    // Validate everything before any state changes: the blob may come from a file.
-    if (!vectors || !levels || !row_ptr || !col) return fail(h, HNSW_ERR_INVALID, "null argument");
-    for (uint32_t i = 0; i < n; ++i)
-        if (levels[i] >= kMaxLayers) return fail(h, HNSW_ERR_INVALID, "level too large");
-    if (levels[enterpoint] + 1 > n_layers) return fail(h, HNSW_ERR_INVALID, "the enterpoint's level exceeds the layer count");
-    for (uint32_t i = 0; i < n; ++i)
-        if (levels[i] > levels[enterpoint]) return fail(h, HNSW_ERR_INVALID, "a node above the enterpoint's level (core.rs:587-593 keeps the enterpoint on top)");
-    if (!all_finite(vectors, (size_t)n * h->dim)) return fail(h, HNSW_ERR_INVALID, "non-finite vector component");
-    // degrees decide the row strides
-    uint32_t md0 = 0, mdU = 0;
-    for (uint32_t l = 0; l < n_layers; ++l) {
-        if (!row_ptr[l] || (!col[l] && row_ptr[l][n] != 0)) return fail(h, HNSW_ERR_INVALID, "null layer arrays");
-        if (row_ptr[l][0] != 0) return fail(h, HNSW_ERR_INVALID, "row_ptr must start at 0");
-        for (uint32_t i = 0; i < n; ++i) {
-            if (row_ptr[l][i + 1] < row_ptr[l][i]) return fail(h, HNSW_ERR_INVALID, "row_ptr is not monotonic");
-            uint64_t d = row_ptr[l][i + 1] - row_ptr[l][i];
-            if (d > 0 && levels[i] < l) return fail(h, HNSW_ERR_INVALID, "node has links above its level");
-            if (d > kAuxWords - 2) return fail(h, HNSW_ERR_INVALID, "degree > 1022 is not supported");
-            for (uint64_t e = row_ptr[l][i]; e < row_ptr[l][i + 1]; ++e) {
-                if (col[l][e] >= n || col[l][e] == i) return fail(h, HNSW_ERR_INVALID, "neighbour id out of range (or a self link)");
-                if (levels[col[l][e]] < l) return fail(h, HNSW_ERR_INVALID, "link to a node that does not reach this layer");
-            }
-            if (l == 0) md0 = std::max<uint32_t>(md0, (uint32_t)d);
-            else mdU = std::max<uint32_t>(mdU, (uint32_t)d);
-        }
-    }
-    uint32_t ns0 = default_stride(h->m_max0, h->m, md0), nsU = default_stride(h->m_max, h->m, mdU);
-    hnsw_status s;
-    // (re)allocate at the right strides before any data lands
-    if (ns0 > h->stride0 || nsU > h->strideU) {
-        if ((s = restride(h, std::max(ns0, h->stride0), std::max(nsU, h->strideU))) != HNSW_OK) return s;
-    }
-    if ((s = ensure_node_cap(h, n)) != HNSW_OK) return s;
-    h->h_levels.assign(levels, levels + n);
-    h->h_upper_base.assign(n, kNoUpper);
-    h->h_dead.assign(n, 0);
-    h->n_dead = 0;
-    uint32_t used = 0;
-    for (uint32_t i = 0; i < n; ++i)
-        if (levels[i] > 0) { h->h_upper_base[i] = used; used += levels[i]; }
-    if ((s = ensure_upper_cap(h, std::max(used, 1u))) != HNSW_OK) return s;
-    h->upper_used = used;
-    HIP_TRY(h, hipMemcpyAsync(h->d_vec, vectors, (size_t)n * h->dim * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_levels, levels, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_upper_base, h->h_upper_base.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-    for (uint32_t l = 0; l < n_layers; ++l) {
-        uint64_t nnz = row_ptr[l][n];
-        DevScratch<uint64_t> s_rp;
-        DevScratch<uint32_t> s_col;
-        HIP_TRY(h, s_rp.alloc((size_t)n + 1));
-        HIP_TRY(h, s_col.alloc((size_t)nnz));
-        uint64_t *d_rp = s_rp.p;
-        uint32_t *d_col = s_col.p;
-        HIP_TRY(h, hipMemcpyAsync(d_rp, row_ptr[l], (size_t)(n + 1) * 8, hipMemcpyHostToDevice, h->stream));
-        if (nnz) HIP_TRY(h, hipMemcpyAsync(d_col, col[l], (size_t)nnz * 4, hipMemcpyHostToDevice, h->stream));
-        uint32_t blocks = (uint32_t)(((uint64_t)n * 64 + 255) / 256);
-        if (l == 0)
-            hipLaunchKernelGGL(k_import_rows, dim3(blocks), dim3(256), 0, h->stream, h->d_adj0, h->stride0,
-                               (const uint32_t *)nullptr, 0u, h->d_levels, 0u, d_rp, d_col, n);
-        else
-            hipLaunchKernelGGL(k_import_rows, dim3(blocks), dim3(256), 0, h->stream, h->d_adjU, h->strideU,
-                               h->d_upper_base, l - 1, h->d_levels, l, d_rp, d_col, n);
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-    }
-    h->n = n;
-    h->enterpoint = enterpoint;
-    h->max_layer = levels[enterpoint];           // the enterpoint is the top node (core.rs:587-593)
-    h->max_deg0 = md0;
-    h->max_degU = mdU;
-    // Graphs the reference builds are symmetric (core.rs:770-772, 793-795); a fast-built one need not be.
-    // The exact insert / delete kernels must know (a missing back link is an error only on symmetric graphs).
-    {
-        DevScratch<unsigned long long> bad;
-        HIP_TRY(h, bad.alloc(1));
-        HIP_TRY(h, hipMemsetAsync(bad.p, 0, 8, h->stream));
-        const uint32_t blocks = (uint32_t)(((uint64_t)n * 64 + 255) / 256);
-        for (uint32_t l = 0; l < n_layers; ++l) {
-            if (l == 0)
-                hipLaunchKernelGGL(k_count_asymmetric, dim3(blocks), dim3(256), 0, h->stream, h->d_adj0, h->stride0,
-                                   (const uint32_t *)nullptr, 0u, h->d_levels, 0u, n, bad.p);
-            else
-                hipLaunchKernelGGL(k_count_asymmetric, dim3(blocks), dim3(256), 0, h->stream, h->d_adjU, h->strideU,
-                                   h->d_upper_base, l - 1, h->d_levels, l, n, bad.p);
-        }
-        HIP_TRY(h, hipGetLastError());
-        unsigned long long nbad = 0;
-        HIP_TRY(h, hipMemcpyAsync(&nbad, bad.p, 8, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        h->asymmetric = nbad != 0;
-    }
-    return push_header(h);
-}
-
-// ---- replicas: the index tables as device pointers (one-time distribution over RCCL / peer copies) ----------
-hnsw_status hnsw_replica_view(hnsw_index *h, hnsw_replica *out)
-{
-    if (!h || !out) return HNSW_ERR_INVALID;
-    ON_DEVICE(h);
-    HIP_TRY(h, hipStreamSynchronize(h->stream));          // everything the engine enqueued has landed
-    std::memset(out, 0, sizeof *out);
-    out->n = h->n; out->dim = h->dim; out->upper_used = h->upper_used;
-    out->stride0 = h->stride0; out->stride_upper = h->strideU;
-    out->max_layer = h->max_layer; out->max_degree0 = h->max_deg0; out->max_degree_upper = h->max_degU;
-    out->n_dead = h->n_dead; out->asymmetric = h->asymmetric ? 1u : 0u; out->format = (uint32_t)h->fmt;
-    out->enterpoint = h->enterpoint;
-    out->vec_bytes = (uint64_t)h->n * h->dim * (h->fmt == FMT_F32 ? 4 : (h->fmt == FMT_BF16 ? 2 : 1));
-    out->adj0_bytes = (uint64_t)h->n * h->stride0 * 4;
-    out->adj_upper_bytes = (uint64_t)h->upper_used * h->strideU * 4;
-    out->vec = h->d_vec; out->adj0 = h->d_adj0; out->adj_upper = h->d_adjU;
-    out->upper_base = h->d_upper_base; out->levels = h->d_levels;
-    return HNSW_OK;
-}
-
-hnsw_status hnsw_replica_prepare(hnsw_index *h, hnsw_replica *r)
-{
-    if (!h || !r) return HNSW_ERR_INVALID;
-    if (h->n != 0 || h->fmt) return fail(h, HNSW_ERR_INVALID, "hnsw_replica_prepare needs an empty index");
-    if (r->dim != h->dim) return fail(h, HNSW_ERR_DIM_MISMATCH, "replica: data dimension does not match Index");
-    if (r->n == 0 || r->enterpoint >= (int64_t)r->n || r->max_layer >= kMaxLayers || r->n_dead > r->n ||
-        r->stride0 < h->stride0 || r->stride_upper < h->strideU || r->stride0 > kAuxWords || r->stride_upper > kAuxWords ||
-        (r->stride0 & 15) || (r->stride_upper & 15) || r->max_degree0 >= r->stride0 || r->max_degree_upper >= r->stride_upper)
-        return fail(h, HNSW_ERR_INVALID, "replica: inconsistent header (the source must have the same M)");
-    ON_DEVICE(h);
-    hnsw_status s;
-    if ((s = restride(h, r->stride0, r->stride_upper)) != HNSW_OK) return s;      // the source's row layout
-    if ((s = ensure_node_cap(h, r->n)) != HNSW_OK) return s;
-    if ((s = ensure_upper_cap(h, std::max(r->upper_used, 1u))) != HNSW_OK) return s;
-    if (r->format > (uint32_t)FMT_FP8 || (r->format && h->mode != MODE_AVX))
-        return fail(h, HNSW_ERR_INVALID, "replica: unknown storage format (or a compressed source with dim % 32 != 0)");
-    const uint32_t esz = r->format == FMT_F32 ? 4 : (r->format == FMT_BF16 ? 2 : 1);
-    if (r->format) {
-        // the vector matrix of a compressed replica is smaller: swap the f32 allocation for one of the right size
-        void *dnew = nullptr;
-        const size_t nel = (size_t)h->cap * h->dim;
-        HIP_TRY(h, hipMalloc(&dnew, std::max<size_t>(nel, 1) * esz));
-        HIP_TRY(h, hipDeviceSynchronize());
-        (void)hipFree(h->d_vec);
-        h->hbm_bytes -= std::min<uint64_t>(h->hbm_bytes, nel * (4 - esz));
-        h->d_vec = reinterpret_cast<float *>(dnew);
-    }
-    HIP_TRY(h, hipStreamSynchronize(h->stream));          // the allocations' fills are done before anyone writes
-    r->vec_bytes = (uint64_t)r->n * h->dim * esz;
-    r->adj0_bytes = (uint64_t)r->n * h->stride0 * 4;
-    r->adj_upper_bytes = (uint64_t)r->upper_used * h->strideU * 4;
-    r->vec = h->d_vec; r->adj0 = h->d_adj0; r->adj_upper = h->d_adjU;
-    r->upper_base = h->d_upper_base; r->levels = h->d_levels;
-    h->fmt = (int)r->format;                              // the tables are being filled: not searchable until commit (n == 0)
-    h->bf16 = h->fmt == FMT_BF16;
-    if (h->fmt) h->T = 0;
-    return HNSW_OK;
-}
-
-hnsw_status hnsw_replica_commit(hnsw_index *h, const hnsw_replica *r, const uint8_t *dead)
-{
-    if (!h || !r) return HNSW_ERR_INVALID;
-    if (h->n != 0) return fail(h, HNSW_ERR_INVALID, "hnsw_replica_commit: the index is not empty");
-    if (r->vec != h->d_vec || r->adj0 != h->d_adj0 || r->levels != h->d_levels || r->stride0 != h->stride0 ||
-        r->stride_upper != h->strideU || r->n == 0 || r->n > h->cap || r->upper_used > h->upper_cap)
-        return fail(h, HNSW_ERR_INVALID, "hnsw_replica_commit: not the block hnsw_replica_prepare returned");
-    if (r->n_dead && !dead) return fail(h, HNSW_ERR_INVALID, "hnsw_replica_commit: tombstones missing");
-    ON_DEVICE(h);
-    HIP_TRY(h, hipDeviceSynchronize());                   // whoever filled the tables (a collective's stream) is done
-    // the host mirrors the engine keeps: levels, upper slots, tombstones
-    h->h_levels.assign(h->cap, 0);
-    h->h_upper_base.assign(h->cap, kNoUpper);
-    h->h_dead.assign(h->cap, 0);
-    HIP_TRY(h, hipMemcpy(h->h_levels.data(), h->d_levels, (size_t)r->n * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(h->h_upper_base.data(), h->d_upper_base, (size_t)r->n * 4, hipMemcpyDeviceToHost));
-    uint32_t used = 0, nd = 0;
-    for (uint32_t i = 0; i < r->n; ++i) {
-        if (h->h_levels[i] >= kMaxLayers) return fail(h, HNSW_ERR_INVALID, "replica: level too large");
-        if (h->h_levels[i] > 0) {
-            if (h->h_upper_base[i] != used) return fail(h, HNSW_ERR_INVALID, "replica: upper slots are not in id order");
-            used += h->h_levels[i];
-        }
-        if (dead) { h->h_dead[i] = dead[i] ? 1 : 0; nd += h->h_dead[i]; }
-    }
-    if (used != r->upper_used || nd != r->n_dead) return fail(h, HNSW_ERR_INVALID, "replica: slot / tombstone counts do not match the header");
-    if (r->enterpoint >= 0 && (h->h_dead[r->enterpoint] || h->h_levels[r->enterpoint] != r->max_layer))
-        return fail(h, HNSW_ERR_INVALID, "replica: the enterpoint must be a live node of the top layer");
-    h->n = r->n; h->n_dead = r->n_dead; h->upper_used = r->upper_used;
-    h->enterpoint = r->enterpoint; h->max_layer = r->max_layer;
-    h->max_deg0 = r->max_degree0; h->max_degU = r->max_degree_upper;
-    h->asymmetric = r->asymmetric != 0;
-    return push_header(h);
-}
-
-hnsw_status hnsw_get_tombstones(hnsw_index *h, uint8_t *dead)
-{
-    if (!h || !dead) return HNSW_ERR_INVALID;
-    std::copy(h->h_dead.begin(), h->h_dead.begin() + h->n, dead);
-    return HNSW_OK;
-}
-
-hnsw_status hnsw_get_info(hnsw_index *h, hnsw_info *info)
-{
-    if (!h || !info) return HNSW_ERR_INVALID;
-    info->dim = h->dim; info->m = h->m; info->m_max = h->m_max; info->m_max0 = h->m_max0;
-    info->ef_construction = h->efc;
-    info->node_count = h->n - h->n_dead;        // the reference's node_count: live nodes
-    info->allocated_ids = h->n;
-    info->max_layer = h->max_layer; info->enterpoint = h->enterpoint;
-    info->stride0 = h->stride0; info->stride_upper = h->strideU;
-    info->max_degree0 = h->max_deg0; info->max_degree_upper = h->max_degU;
-    info->hbm_bytes = h->hbm_bytes;
-    return HNSW_OK;
-}
-
-hnsw_status hnsw_get_levels(hnsw_index *h, uint32_t *levels)
-{
-    if (!h || !levels) return HNSW_ERR_INVALID;
-    std::copy(h->h_levels.begin(), h->h_levels.begin() + h->n, levels);
-    return HNSW_OK;
-}
-
-hnsw_status hnsw_get_level(hnsw_index *h, uint32_t id, uint32_t *level)
-{
-    if (!h || !level) return HNSW_ERR_INVALID;
-    if (id >= h->n) return fail(h, HNSW_ERR_NOT_FOUND, "node id out of range");
-    *level = h->h_levels[id];
-    return HNSW_OK;
-}
-
-hnsw_status hnsw_get_vector(hnsw_index *h, uint32_t id, float *out)
-{
-    if (!h || !out) return HNSW_ERR_INVALID;
-    if (id >= h->n) return fail(h, HNSW_ERR_NOT_FOUND, "node id out of range");
-    ON_DEVICE(h);
-    if (h->fmt) {                                    // the stored (rounded) values, widened by the search kernels' own code
-        DevScratch<float> row;
-        HIP_TRY(h, row.alloc(h->dim));
-        const uint32_t blocks = (h->dim / 4 + 63) / 64;
-        if (h->fmt == FMT_BF16)
-            hipLaunchKernelGGL(k_decode_row<FMT_BF16>, dim3(blocks), dim3(64), 0, h->stream, reinterpret_cast<const float4 *>(h->d_vec), (size_t)id, h->dim, row.p);
-        else
-            hipLaunchKernelGGL(k_decode_row<FMT_FP8>, dim3(blocks), dim3(64), 0, h->stream, reinterpret_cast<const float4 *>(h->d_vec), (size_t)id, h->dim, row.p);
-        HIP_TRY(h, hipGetLastError());
-        HIP_TRY(h, hipMemcpyAsync(out, row.p, (size_t)h->dim * 4, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        return HNSW_OK;
-    }
-    HIP_TRY(h, hipMemcpyAsync(out, h->d_vec + (size_t)id * h->dim, (size_t)h->dim * 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return HNSW_OK;
-}
-
-hnsw_status hnsw_get_neighbors(hnsw_index *h, uint32_t id, uint32_t layer, uint32_t *out, uint32_t cap,
-                               uint32_t *n)
-{
-    if (!h || !n) return HNSW_ERR_INVALID;
-    if (id >= h->n) return fail(h, HNSW_ERR_NOT_FOUND, "node id out of range");
-    *n = 0;
-    if (layer > h->h_levels[id]) return HNSW_OK; // push_levels: rows above the level are empty
-    ON_DEVICE(h);
-    const uint32_t stride = layer ? h->strideU : h->stride0;
-    const uint32_t *row = layer ? h->d_adjU + (size_t)(h->h_upper_base[id] + layer - 1) * stride
-                                : h->d_adj0 + (size_t)id * stride;
-    std::vector<uint32_t> tmp(stride);
-    HIP_TRY(h, hipMemcpyAsync(tmp.data(), row, (size_t)stride * 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    uint32_t cnt = std::min(tmp[0], stride - 1);
-    *n = cnt;
-    for (uint32_t i = 0; i < cnt && i < cap; ++i) out[i] = tmp[1 + i];
-    return HNSW_OK;
-}
-
-static hnsw_status layer_degrees(hnsw_index *h, uint32_t layer, std::vector<uint32_t> &deg)
-{
-    deg.assign(h->n, 0);
-    if (h->n == 0) return HNSW_OK;
-    DevScratch<uint32_t> s_deg;
-    HIP_TRY(h, s_deg.alloc(h->n));
-    uint32_t *d_deg = s_deg.p;
-    uint32_t blocks = (h->n + 255) / 256;
-    if (layer == 0)
-        hipLaunchKernelGGL(k_degrees, dim3(blocks), dim3(256), 0, h->stream, h->d_adj0, h->stride0,
-                           (const uint32_t *)nullptr, 0u, h->d_levels, 0u, h->n, d_deg);
-    else
-        hipLaunchKernelGGL(k_degrees, dim3(blocks), dim3(256), 0, h->stream, h->d_adjU, h->strideU,
-                           h->d_upper_base, layer - 1, h->d_levels, layer, h->n, d_deg);
-    HIP_TRY(h, hipMemcpyAsync(deg.data(), d_deg, (size_t)h->n * 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return HNSW_OK;
-}
-
-hnsw_status hnsw_layer_nnz(hnsw_index *h, uint32_t layer, uint64_t *nnz)
-{
-    if (!h || !nnz) return HNSW_ERR_INVALID;
-    ON_DEVICE(h);
-    std::vector<uint32_t> deg;
-    hnsw_status s = layer_degrees(h, layer, deg);
-    if (s != HNSW_OK) return s;
-    uint64_t t = 0;
-    for (uint32_t d : deg) t += d;
-    *nnz = t;
-    return HNSW_OK;
-}
-
-hnsw_status hnsw_export_layer(hnsw_index *h, uint32_t layer, uint64_t *row_ptr, uint32_t *col)
-{
-    if (!h || !row_ptr) return HNSW_ERR_INVALID;
-    ON_DEVICE(h);
-    std::vector<uint32_t> deg;
-    hnsw_status s = layer_degrees(h, layer, deg);
-    if (s != HNSW_OK) return s;
-    uint64_t t = 0;
-    for (uint32_t i = 0; i < h->n; ++i) { row_ptr[i] = t; t += deg[i]; }
-    row_ptr[h->n] = t;
-    if (t == 0 || h->n == 0) return HNSW_OK;
-    DevScratch<uint64_t> s_rp;
-    DevScratch<uint32_t> s_col;
-    HIP_TRY(h, s_rp.alloc((size_t)h->n + 1));
-    HIP_TRY(h, s_col.alloc((size_t)t));
-    uint64_t *d_rp = s_rp.p;
-    uint32_t *d_col = s_col.p;
-    HIP_TRY(h, hipMemcpyAsync(d_rp, row_ptr, (size_t)(h->n + 1) * 8, hipMemcpyHostToDevice, h->stream));
-    uint32_t blocks = (uint32_t)(((uint64_t)h->n * 64 + 255) / 256);
-    if (layer == 0)
-        hipLaunchKernelGGL(k_export_rows, dim3(blocks), dim3(256), 0, h->stream, h->d_adj0, h->stride0,
-                           (const uint32_t *)nullptr, 0u, h->d_levels, 0u, h->n, d_rp, d_col);
-    else
-        hipLaunchKernelGGL(k_export_rows, dim3(blocks), dim3(256), 0, h->stream, h->d_adjU, h->strideU,
-                           h->d_upper_base, layer - 1, h->d_levels, layer, h->n, d_rp, d_col);
-    HIP_TRY(h, hipMemcpyAsync(col, d_col, (size_t)t * 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return HNSW_OK;
-}
-
-// ---- snapshot (what the RDB save/load callbacks of src/types.rs:176-284 would stream) -----------
-namespace {
-constexpr char kSnapMagic[8] = {'H', 'N', 'S', 'W', 'M', 'I', '3', '5'};
-struct SnapHeader {
-    char magic[8];
-    uint32_t version, dim, m, efc, n, n_dead, max_layer, n_layers;
-    int64_t enterpoint;
-    uint64_t rng[4];
-};
-inline uint64_t pad8(uint64_t b) { return (b + 7) & ~7ull; }   // every section starts 8-byte aligned
-}
-
-hnsw_status hnsw_serialize_size(hnsw_index *h, uint64_t *bytes)
-{
-    if (!h || !bytes) return HNSW_ERR_INVALID;
-    uint64_t total = sizeof(SnapHeader) + pad8((uint64_t)h->n * 4) + pad8(h->n) + pad8((uint64_t)h->n * h->dim * 4);
-    const uint32_t n_layers = h->n ? h->max_layer + 1 : 0;
-    for (uint32_t l = 0; l < n_layers; ++l) {
-        uint64_t nnz = 0;
-        hnsw_status s = hnsw_layer_nnz(h, l, &nnz);
-        if (s != HNSW_OK) return s;
-        total += 8 + ((uint64_t)h->n + 1) * 8 + pad8(nnz * 4);
-    }
-    *bytes = total;
-    return HNSW_OK;
-}
-
-hnsw_status hnsw_serialize(hnsw_index *h, void *buf, uint64_t cap, uint64_t *written)
-{
-    if (!h || !buf || !written) return HNSW_ERR_INVALID;
-    if (h->fmt) return fail(h, HNSW_ERR_INVALID, "snapshots are taken from the f32 index (compressed storage is a derived serving copy)");
-    uint64_t need = 0;
-    hnsw_status s = hnsw_serialize_size(h, &need);
-    if (s != HNSW_OK) return s;
-    if (cap < need) return fail(h, HNSW_ERR_INVALID, "snapshot buffer too small");
-    ON_DEVICE(h);
-    unsigned char *p = static_cast<unsigned char *>(buf);
-    SnapHeader hd;
-    std::memset(&hd, 0, sizeof hd);
-    std::memcpy(hd.magic, kSnapMagic, 8);
-    hd.version = 1; hd.dim = h->dim; hd.m = h->m; hd.efc = h->efc; hd.n = h->n; hd.n_dead = h->n_dead;
-    hd.max_layer = h->max_layer; hd.n_layers = h->n ? h->max_layer + 1 : 0; hd.enterpoint = h->enterpoint;
-    std::memcpy(hd.rng, h->rng, sizeof hd.rng);
-    std::memcpy(p, &hd, sizeof hd); p += sizeof hd;
-    std::memset(p, 0, need - sizeof hd);
-    if (h->n) std::memcpy(p, h->h_levels.data(), (size_t)h->n * 4);
-    p += pad8((uint64_t)h->n * 4);
-    if (h->n) std::memcpy(p, h->h_dead.data(), h->n);
-    p += pad8(h->n);
-    if (h->n) {
-        HIP_TRY(h, hipMemcpyAsync(p, h->d_vec, (size_t)h->n * h->dim * 4, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-    }
-    p += pad8((uint64_t)h->n * h->dim * 4);
-    for (uint32_t l = 0; l < hd.n_layers; ++l) {
-        uint64_t nnz = 0;
-        if ((s = hnsw_layer_nnz(h, l, &nnz)) != HNSW_OK) return s;
-        std::memcpy(p, &nnz, 8); p += 8;
-        uint64_t *rp = reinterpret_cast<uint64_t *>(p); p += ((size_t)h->n + 1) * 8;
-        uint32_t *cl = reinterpret_cast<uint32_t *>(p); p += pad8(nnz * 4);
-        if ((s = hnsw_export_layer(h, l, rp, cl)) != HNSW_OK) return s;
-    }
-    *written = (uint64_t)(p - static_cast<unsigned char *>(buf));
-    return HNSW_OK;
-}
-
-hnsw_status hnsw_deserialize(const void *buf, uint64_t bytes, uint64_t seed, int device, hnsw_index **out)
-{
-    if (!buf || !out || bytes < sizeof(SnapHeader)) return HNSW_ERR_INVALID;
-    const unsigned char *p = static_cast<const unsigned char *>(buf), *end = p + bytes;
-    SnapHeader hd;
-    std::memcpy(&hd, p, sizeof hd); p += sizeof hd;
-    if (std::memcmp(hd.magic, kSnapMagic, 8) != 0 || hd.version != 1) { *out = nullptr; return HNSW_ERR_INVALID; }
-    hnsw_status s = hnsw_create(hd.dim, hd.m, hd.efc, seed, device, out);
-    if (s != HNSW_OK) return s;
-    hnsw_index *h = *out;
-    std::memcpy(h->rng, hd.rng, sizeof hd.rng);
-    if (hd.n == 0) return HNSW_OK;
-    // the blob is untrusted: every size is checked against what is left before it is used
-    const uint64_t left0 = (uint64_t)(end - p);
-    const uint64_t need0 = pad8((uint64_t)hd.n * 4) + pad8(hd.n) + pad8((uint64_t)hd.n * hd.dim * 4);
-    if (left0 < need0) return fail(h, HNSW_ERR_INVALID, "truncated snapshot");
-    if (hd.n_layers == 0 || hd.n_layers > kMaxLayers || hd.max_layer >= hd.n_layers || hd.n_dead > hd.n ||
-        hd.enterpoint >= (int64_t)hd.n || hd.enterpoint < -1)
-        return fail(h, HNSW_ERR_INVALID, "inconsistent snapshot header");
-    const uint32_t *levels = reinterpret_cast<const uint32_t *>(p); p += pad8((uint64_t)hd.n * 4);
-    const unsigned char *dead = p; p += pad8(hd.n);
-    const float *vectors = reinterpret_cast<const float *>(p); p += pad8((uint64_t)hd.n * hd.dim * 4);
-    uint32_t dead_count = 0;
-    for (uint32_t i = 0; i < hd.n; ++i) {
-        if (dead[i] > 1) return fail(h, HNSW_ERR_INVALID, "bad tombstone byte");
-        dead_count += dead[i];
-    }
-    if (dead_count != hd.n_dead) return fail(h, HNSW_ERR_INVALID, "tombstone count does not match the header");
-    if ((hd.enterpoint < 0) != (hd.n_dead == hd.n)) return fail(h, HNSW_ERR_INVALID, "enterpoint / live count mismatch");
-    if (hd.enterpoint >= 0 && (dead[hd.enterpoint] || levels[hd.enterpoint] != hd.max_layer))
-        return fail(h, HNSW_ERR_INVALID, "the enterpoint must be a live node of the top layer");
-    std::vector<const uint64_t *> rps(hd.n_layers);
-    std::vector<const uint32_t *> cols(hd.n_layers);
-    for (uint32_t l = 0; l < hd.n_layers; ++l) {
-        if ((uint64_t)(end - p) < 8 + ((uint64_t)hd.n + 1) * 8) return fail(h, HNSW_ERR_INVALID, "truncated snapshot");
-        uint64_t nnz;
-        std::memcpy(&nnz, p, 8); p += 8;
-        rps[l] = reinterpret_cast<const uint64_t *>(p); p += ((size_t)hd.n + 1) * 8;
-        if (nnz > (uint64_t)(end - p) / 4 || rps[l][hd.n] != nnz) return fail(h, HNSW_ERR_INVALID, "truncated snapshot (layer)");
-        cols[l] = reinterpret_cast<const uint32_t *>(p); p += pad8(nnz * 4);
-        if (p > end) return fail(h, HNSW_ERR_INVALID, "truncated snapshot (padding)");
-    }
-    // hnsw_import wants the enterpoint on the top layer.  Tombstones keep their level, which can be above the
-    // live graph's top (the enterpoint was deleted and a lower node elected, core.rs:449-472): import with the
-    // highest node as a placeholder and empty rows for the layers only tombstones reach, then fix up.
-    int64_t ep = 0;
-    uint32_t top = 0;
-    for (uint32_t i = 0; i < hd.n; ++i) {
-        if (levels[i] >= kMaxLayers) return fail(h, HNSW_ERR_INVALID, "level too large");
-        if (levels[i] > top) { top = levels[i]; ep = i; }
-        if (!dead[i] && levels[i] > hd.max_layer) return fail(h, HNSW_ERR_INVALID, "live node above max_layer");
-    }
-    if (hd.enterpoint >= 0 && levels[hd.enterpoint] == top) ep = hd.enterpoint;
-    std::vector<uint64_t> zero_rp;
-    if (top + 1 > hd.n_layers) {
-        zero_rp.assign((size_t)hd.n + 1, 0);
-        rps.resize(top + 1, zero_rp.data());
-        cols.resize(top + 1, nullptr);
-    }
-    if ((s = hnsw_import(h, hd.n, vectors, levels, ep, (uint32_t)rps.size(), rps.data(), cols.data())) != HNSW_OK) return s;
-    h->h_dead.assign(dead, dead + hd.n);
-    h->n_dead = hd.n_dead;
-    h->enterpoint = hd.enterpoint;
-    h->max_layer = hd.max_layer;
-    return push_header(h);
-}
+#include "hnsw_transfer.inc"   // hnsw_import, replicas, hnsw_get_*, hnsw_export_layer
+#include "hnsw_snapshot.inc"   // hnsw_serialize / hnsw_deserialize
 
 hnsw_status hnsw_get_counters(hnsw_index *h, hnsw_counters *search, hnsw_counters *insert)
 {
