@@ -28,7 +28,9 @@ namespace hnsw {
 
 constexpr uint32_t kOccMaxW = 64;           // window slots
 constexpr uint32_t kOccMaxReads = 3072;     // read-log entries per slot
-constexpr uint32_t kOccMaxShr = 32;         // speculative shrinks per slot (window slots x this <= HBM spill slots)
+constexpr uint32_t kOccMaxShr = 64;         // speculative records per slot (array stride; one per lane of the committing wave)
+constexpr uint32_t kOccInsShr = 32;         // ... of which an INSERT lists at most this many (window slots x this <= HBM spill slots);
+                                            // a delete may list all 64 (one re-selection per neighbour of the node, all its layers)
 constexpr uint32_t kOccHash = 4096;         // validation hash slots
 constexpr uint32_t kOccOwn = 256;           // own deltas of one commit mirrored in LDS
 constexpr uint32_t kOccMaxHits = 1024;      // (reader, z) pairs whose distance must be evaluated per validation
@@ -75,7 +77,7 @@ struct OccScratch {
     uint32_t *hits;     // [kOccMaxHits][3]: reader (0 = the node itself, 1 + sub = shrink sub), z, bound
     uint32_t *flags;    // [0] link plan stale, [1] hit count, [2 + sub] shrink sub stale
 };
-constexpr size_t kOccScratchBytes = (size_t)(kOccHash * 2 + kOccMaxReads * 4 + kOccOwn * 3 + kOccMaxHits * 3 + 2 + 64) * 4;
+constexpr size_t kOccScratchBytes = (size_t)(kOccHash * 2 + kOccMaxReads * 4 + kOccOwn * 3 + kOccMaxHits * 3 + 2 + 2 * kOccMaxShr) * 4;
 
 __device__ __forceinline__ OccScratch occ_carve(unsigned char *p)
 {
@@ -108,7 +110,7 @@ __device__ __forceinline__ void occ_clear_hash(const OccScratch &sc, uint32_t n_
 __device__ __forceinline__ void occ_build_hash(const OccScratch &sc, const OccRead *reads, uint32_t n_reads, const OccShr *shr,
                                                uint32_t n_shr, int lane)
 {
-    for (uint32_t i = lane; i < 2 + 64; i += 64) sc.flags[i] = 0;
+    for (uint32_t i = lane; i < 2 + 2 * kOccMaxShr; i += 64) sc.flags[i] = 0;
     __syncthreads();
     // the shrinks' rows, for the chain walk: flags[2 + kOccMaxShr + sub] = shr[sub].e
     if ((uint32_t)lane < n_shr && (uint32_t)lane < kOccMaxShr) sc.flags[2 + kOccMaxShr + lane] = shr[lane].e;
@@ -255,7 +257,7 @@ __device__ __forceinline__ void occ_plan_finish(const GraphView &g, const OccBuf
             run += cj + 2;
         }
         if (need) {
-            if (k >= kOccMaxShr || cnt + 1 > kAuxWords) fail = true;
+            if (k >= kOccInsShr || cnt + 1 > kAuxWords) fail = true;
             else {
                 OccShr *sp = &shr[k];
                 sp->lc = lc; sp->e = e; sp->nS = 0; sp->bound = 0; sp->log0 = off; sp->cnt = cnt;
@@ -372,12 +374,12 @@ __global__ __launch_bounds__(64, 1) void k_occ_plan(GraphView g, OccBufs ob, uin
 template <int MODE, int T, int R>
 __global__ __launch_bounds__(64, 1) void k_occ_shrinks(GraphView g, OccBufs ob, uint32_t first_node, uint32_t count, uint32_t mlinks,
                                                     uint32_t lnb, uint32_t lcap, uint32_t *__restrict__ gspill, uint32_t gnb,
-                                                    uint32_t del_id)
+                                                    uint32_t del_id, uint32_t per)
 {
     // del_id != kEmpty: the slot lists the re-selections of HNSW.NODE.DEL (k_occ_del_list): the row as it is, del_id ignored
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
-    const uint32_t b = blockIdx.x / kOccMaxShr, k = blockIdx.x % kOccMaxShr;
+    const uint32_t b = blockIdx.x / per, k = blockIdx.x % per;   // `per` records launched per slot (kOccInsShr / kOccMaxShr)
     if (b >= count) return;
     const uint32_t id = first_node + b;
     const uint32_t slot = id % ob.W;

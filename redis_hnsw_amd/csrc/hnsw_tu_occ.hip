@@ -37,8 +37,8 @@ static hnsw_status occ_round_t(hnsw_index *h, const InsertCfg &c, const OccBufs 
     if (!lean_plan)
         hipLaunchKernelGGL(kp, dim3(count), dim3(64), c.lds, h->stream, gv, ob, head, count, h->efc, h->m, c.lnb, c.lcap, h->d_spill,
                            h->spill_gnb, h->d_plan, h->select_shortcut ? 1u : 0u, h->occ_log_cap);
-    hipLaunchKernelGGL(ks, dim3(count * kOccMaxShr), dim3(64), c.lds, h->stream, gv, ob, head, count, h->m, c.lnb, c.lcap, h->d_spill,
-                       h->spill_gnb, kEmpty);
+    hipLaunchKernelGGL(ks, dim3(count * kOccInsShr), dim3(64), c.lds, h->stream, gv, ob, head, count, h->m, c.lnb, c.lcap, h->d_spill,
+                       h->spill_gnb, kEmpty, kOccInsShr);
     bool team = false;
     if (h->commit_team) {
         HIP_TRY(h, hipGetLastError());
@@ -73,7 +73,8 @@ static hnsw_status occ_delete_t(hnsw_index *h, const InsertCfg &c, const OccBufs
     }
     const GraphView gv = view_tag(h, c.tagcfg);
     hipLaunchKernelGGL(kl, dim3(1), dim3(64), 0, h->stream, gv, ob, id);
-    hipLaunchKernelGGL(ks, dim3(kOccMaxShr), dim3(64), c.lds, h->stream, gv, ob, id, 1u, h->m, c.lnb, c.lcap, h->d_spill, h->spill_gnb, id);
+    hipLaunchKernelGGL(ks, dim3(kOccMaxShr), dim3(64), c.lds, h->stream, gv, ob, id, 1u, h->m, c.lnb, c.lcap, h->d_spill, h->spill_gnb, id,
+                       kOccMaxShr);
     bool team = false;
     if (h->commit_team) {
         HIP_TRY(h, hipGetLastError());
