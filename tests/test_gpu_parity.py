@@ -985,3 +985,63 @@ def test_windowed_and_serial_exact_builds_agree(eng):
     ok, why = graphs_equal(a.export_graph(), b.export_graph())
     assert ok, why
     a.close(); b.close()
+
+
+# ---- the multi-wave forms (round 4): same answers, same graphs, and they are the ones that run -----------------
+@pytest.mark.parametrize("n,dim,m,ef,k,nq,wide", [(2000, 128, 16, 200, 10, 96, 0), (1200, 128, 24, 300, 20, 40, 0),
+                                                  (1500, 128, 16, 40, 10, 64, 0), (1500, 128, 16, 200, 10, 48, 40)])
+def test_two_wave_search_is_the_one_wave_search(eng, oracle_mod, built, n, dim, m, ef, k, nq, wide):
+    """hnsw_search_duo.hpp: a walker and a W-keeper wavefront per query for small batches and single calls.  Same ids,
+    similarity bits and work counters as the one-wave kernel and as the oracle -- narrow and wide adjacency rows, ef
+    below and above 64, a batch and one query per call -- and it IS the form that runs for these shapes."""
+    V, o, lv = built(n, dim, m, ef)
+    Q = make_data(nq, dim, seed=2)
+    want = o.search_batch(Q, k)
+    valid = np.arange(k)[None, :] < want[2][:, None]
+    gi = eng.Index("duo", dim, m, ef)
+    gi.import_graph(o.export())
+    if wide:
+        gi.set_tuning("force_restride", wide)            # rows of 64..127 words: the two-row-word form
+    for duo in (1, 0):
+        gi.set_tuning("duo", duo)
+        gi.reset_counters()
+        ids, sims, n_out = gi.search_batch(Q, k)
+        assert gi.last_search_was_duo() == bool(duo)
+        assert np.array_equal(n_out, want[2]) and np.array_equal(ids[valid], want[0][valid])
+        assert np.array_equal(_bits(sims)[valid], _bits(want[1])[valid])
+        sc, _ = gi.counters()
+        assert (sc.n_dist, sc.n_ids, sc.n_expand) == (want[3].n_dist, want[3].n_ids, want[3].n_expand)
+    gi.set_tuning("duo", 1)
+    for q in Q[:10]:
+        assert [r.id for r in gi.search_knn(q, k)] == o.search(q, k)[0].tolist()
+        assert gi.last_search_was_duo()
+    gi.close()
+
+
+@pytest.mark.parametrize("plan_duo,commit_team", [(1, 1), (0, 1), (1, 0), (0, 0)])
+def test_two_wave_plans_and_four_wave_commits_build_the_reference_graph(eng, oracle_mod, plan_duo, commit_team):
+    """HNSW.NODE.ADD / HNSW.NODE.DEL with the insert plans in their two-wave form and the commit kernels as a team of four
+    wavefronts (and each of them switched off): the same graph as the oracle's, row for row, through a windowed batch,
+    single adds and deletes -- including deletes of nodes with more than 32 neighbours (64 speculative records)."""
+    n, dim, m, ef = 3000, 128, 16, 100
+    V = make_data(n + 60, dim, seed=85)
+    lv = oracle_mod.draw_levels(n + 60, m, 4)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch(V, lv)
+    gi = eng.Index("team", dim, m, ef)
+    gi.set_tuning("plan_duo", plan_duo)
+    gi.set_tuning("commit_team", commit_team)
+    gi.add_batch(V[:n], levels=lv[:n], mode="exact")
+    for i in range(n, n + 60):
+        gi.add_node("node%d" % i, V[i], level=int(lv[i]))
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    deg = [len(o.neighbors(i, 0)) for i in range(n)]
+    victims = [int(i) for i in np.argsort(deg)[-6:]] + [5, 17, 600]          # the widest rows first
+    assert max(deg) > 32
+    for v in victims:
+        o.delete(v)
+        gi.delete_node("node%d" % v)
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    gi.close()
