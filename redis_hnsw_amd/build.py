@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 OBJ_DIR = os.path.join(_HERE, "build_obj")
 LIB_PATH = os.path.join(LIB_DIR, "libhnsw_mi355x.so")
-_COMMON = ["hnsw_host.hpp", "hnsw_device.hpp", "hnsw_insert.hpp", "hnsw_occ.hpp",
+_COMMON = ["hnsw_host.hpp", "hnsw_device.hpp", "hnsw_insert.hpp", "hnsw_occ.hpp", "hnsw_wave_sync.hpp",
            os.path.join("..", "..", "include", "hnsw_mi355x.h")]
 # (source, variants, headers besides _COMMON)
 UNITS = [
@@ -112,6 +112,15 @@ def build_profiling_library():
     """Development aid: the same library with per-phase cycle counters compiled in
     (-DHNSW_PHASE_TIMERS); use it with HNSW_MI355X_LIB=<path> scripts/phase_profile.py."""
     return _compile_and_link(PROF_LIB_PATH, OBJ_DIR + "_prof", extra_flags=["-DHNSW_PHASE_TIMERS"])
+
+
+DEBUG_LIB_PATH = os.path.join(LIB_DIR, "libhnsw_mi355x_dbg.so")
+
+
+def build_debug_library():
+    """Development aid: the library with -DHNSW_OCC_DEBUG -- the delete commit recomputes EVERY re-selection beside the
+    validation's verdict on its speculative record and counts the misses (scripts/del_repro.py reads them)."""
+    return _compile_and_link(DEBUG_LIB_PATH, OBJ_DIR + "_dbg", extra_flags=["-DHNSW_OCC_DEBUG"])
 
 
 if __name__ == "__main__":

@@ -710,7 +710,7 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
     if (!std::strcmp(key, "lean")) { h->lean = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "duo")) { h->duo = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "plan_duo")) { h->plan_duo = value != 0; return HNSW_OK; }
-    if (!std::strcmp(key, "commit_team")) { h->commit_team = value != 0; return HNSW_OK; }
+    if (!std::strcmp(key, "commit_team")) { h->commit_team = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return HNSW_OK; }
     if (!std::strcmp(key, "plan_duo_max")) { h->plan_duo_max = (uint32_t)std::max<int64_t>(value, 0); return HNSW_OK; }
     if (!std::strcmp(key, "duo_max")) { h->duo_max = (uint32_t)std::max<int64_t>(value, 0); return HNSW_OK; }
     if (!std::strcmp(key, "grid_stride")) { h->grid_stride = value != 0; return HNSW_OK; }
@@ -1007,6 +1007,20 @@ hnsw_status hnsw_debug_occ(hnsw_index *h, uint64_t *out5 /* [16] */)
     out5[3] = h->occ_last.n_stale; out5[4] = h->occ_last.nJ; out5[5] = h->occ_last.stop;   // [5] = rounds
     for (int i = 0; i < 8; ++i) out5[6 + i] = h->occ_last.prof[i];   // commit kernel phases, shader clocks
     out5[14] = h->occ_last.n_norec; out5[15] = h->occ_last.n_rowstale;
+    return HNSW_OK;
+}
+
+// the device's control block of the exact-order insert / delete as it stands (development aid; not in the public header):
+// [0..7] prof, [8..15] n_cls, [16] n_spec, [17] n_fallback
+hnsw_status hnsw_debug_occ_ctl(hnsw_index *h, uint64_t *out18)
+{
+    if (!h || !out18 || !h->d_occ_ctl) return HNSW_ERR_INVALID;
+    ON_DEVICE(h);
+    OccCtl c;
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(&c, h->d_occ_ctl, sizeof(OccCtl), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; ++i) { out18[i] = c.prof[i]; out18[8 + i] = c.n_cls[i]; }
+    out18[16] = c.n_spec; out18[17] = c.n_fallback;
     return HNSW_OK;
 }
 

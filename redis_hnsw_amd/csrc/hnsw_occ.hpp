@@ -953,6 +953,9 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_del_commit(GraphView g
     jr.own_base = jr.n;
     uint32_t checked = jr.n;
     unsigned long long n_spec = 0, n_fallback = 0, w_dist = 0, w_ids = 0;
+#ifdef HNSW_OCC_DEBUG
+    unsigned long long dbg_hash = 0, dbg_rec = 0, dbg_stale = 0, dbg_why = 0, dbg_miss = 0, dbg_over = 0;
+#endif
     uint32_t nt = 0;
     bool fail = false;
     const uint32_t l = g.levels[id];
@@ -982,7 +985,20 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_del_commit(GraphView g
             for (uint32_t i = lane; i < cnt; i += 64) m.aux[i] = erow[1 + i];
             __syncthreads();
             uint32_t nS;
+#ifdef HNSW_OCC_DEBUG
+            // ground truth beside the validation: every record is also recomputed; a record whose list differs from the
+            // recomputed one without having been flagged is a validation miss
+            unsigned long long dbg_spec_hash = 0;
+            if (k >= 0) {
+                const uint32_t ns0 = shr[k].nS;
+                for (uint32_t i = lane; i < ns0; i += 64) dbg_spec_hash += (unsigned long long)shr[k].S[i] * (unsigned long long)(2 * i + 1);
+                for (int o = 32; o; o >>= 1) dbg_spec_hash += __shfl_xor(dbg_spec_hash, o, 64);
+                dbg_spec_hash += ns0;
+            }
+            if (false) {
+#else
             if (k >= 0 && !sc.flags[2 + k]) {
+#endif
                 const uint32_t sv = shr[k].S[lane], sv2 = shr[k].S[64 + lane];
                 nS = shr[k].nS;
                 if ((uint32_t)lane < nS) m.S[lane] = (uint64_t)sv << 1;
@@ -1009,7 +1025,9 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_del_commit(GraphView g
                 }
                 WorkCtr nolog = {};
                 if constexpr (HW > 0)
+                {
                     nS = team_select<MODE, T>(g, m, vis, qe, nE, n, mmax, lc, nolog, lane, fail, id, task, W0sub, hmem0, tc, 1u + HW);
+                }
                 else
                     nS = select_topm<MODE, T>(g, m, vis, qe, m.W, nE, n, mmax, lc, nolog, lane, fail, id);
                 if (fail) break;
@@ -1017,6 +1035,21 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_del_commit(GraphView g
                 w_ids += cnt + nolog.n_ids;
                 n_fallback += 1;
             }
+#ifdef HNSW_OCC_DEBUG
+            {   // what was decided for this neighbour, into the control block (hnsw_debug_occ_ctl)
+                __syncthreads();
+                unsigned long long hs = 0;
+                for (uint32_t i = lane; i < nS; i += 64) hs += (unsigned long long)key_id(m.S[i]) * (unsigned long long)(2 * i + 1);
+                for (int o = 32; o; o >>= 1) hs += __shfl_xor(hs, o, 64);
+                dbg_hash = dbg_hash * 1000003ull + hs + nS;
+                if (k >= 0) {
+                    const bool same = dbg_spec_hash == hs + nS;
+                    if (!same && !sc.flags[2 + k]) dbg_miss += 1;
+                    if (same && sc.flags[2 + k]) dbg_over += 1;
+                }
+                if (k >= 0) { dbg_rec |= 1ull << k; if (sc.flags[2 + k]) dbg_stale |= 1ull << k; if (k < 16) dbg_why |= (unsigned long long)(sc.flags[2 + k] & 15u) << (4 * k); }
+            }
+#endif
             // update_node_connections(n, new, old, ignored = node) (core.rs:856)
             update_connections(g, m, n, erow, cnt, nS, lc, stride, maxdeg, id, touched, touched_cap, nt, lane, &jr);
         }
@@ -1039,6 +1072,10 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_del_commit(GraphView g
         ob.ctl->stop = OCC_STOP_NONE;
         ob.ctl->n_spec += n_spec;
         ob.ctl->n_fallback += n_fallback;
+#ifdef HNSW_OCC_DEBUG
+        ob.ctl->prof[0] = dbg_hash; ob.ctl->prof[1] = dbg_rec; ob.ctl->prof[2] = dbg_stale; ob.ctl->prof[3] = n_spec; ob.ctl->prof[4] = n_fallback;
+        ob.ctl->n_cls[0] = dbg_why; ob.ctl->n_cls[1] = dbg_miss; ob.ctl->n_cls[2] = dbg_over;
+#endif
         sl->planned = 0;
     }
 }

@@ -1,5 +1,6 @@
 // hnsw_tu_insert.hip -- HNSW.NODE.ADD / HNSW.NODE.DEL kernels of one metric variant (HNSW_VARIANT, see
 // hnsw_host.hpp): k_insert_plan, k_insert_commit_exact, k_delete_exact, k_shrink_batch, and their launchers.
+#include "hnsw_wave_sync.hpp"   // one-wave workgroups: "__syncthreads()" = the wave's own full synchronisation
 #include "hnsw_host.hpp"
 
 namespace hnsw_host {

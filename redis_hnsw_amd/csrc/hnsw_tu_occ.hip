@@ -1,6 +1,7 @@
 // hnsw_tu_occ.hip -- the exact-order parallel insert (hnsw_occ.hpp) for one metric variant (HNSW_VARIANT, see
 // hnsw_host.hpp): k_occ_validate, k_occ_plan, k_occ_shrinks, k_occ_commit and the launcher of one round; k_occ_del_list,
 // k_occ_del_commit and the launcher of a delete.
+#include "hnsw_wave_sync.hpp"   // one-wave workgroups: "__syncthreads()" = the wave's own full synchronisation
 #include "hnsw_host.hpp"
 
 namespace hnsw_host {

@@ -6,16 +6,7 @@
 // the block has four wavefronts that each run that code on their own, with loops of different lengths, so in THIS
 // unit a block-level synchronisation of the shared code is the wave's own, and the only s_barriers are the team's
 // hand-overs (team_bar).
-#include <hip/hip_runtime.h>
-namespace hnsw {
-__device__ __forceinline__ void wave_sync_for_team()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-} // namespace hnsw
-#define __syncthreads() ::hnsw::wave_sync_for_team()
+#include "hnsw_wave_sync.hpp"   // "__syncthreads()" = this wave's own full synchronisation
 #include "hnsw_host.hpp"
 
 namespace hnsw_host {
@@ -98,17 +89,10 @@ static hnsw_status del_commit_team_t(hnsw_index *h, const InsertCfg &c, const Oc
     return HNSW_OK;
 }
 
-// T = 24 (dim 768, the query in 96 registers): the team's re-selections of a DELETE disagreed with the oracle's at
-// 1 200 x 768 (scripts/del_repro.py; dims 128 and 256, M up to 32, agree), cause not found -- that variant keeps the
-// one-wave commit kernels for inserts and deletes alike.
-template <int T>
-constexpr bool kTeamVerified = T != 24;
-
 template <int MODE, int T>
 hnsw_status occ_commit_team_r(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t end_node, bool *done)
 {
     *done = false;
-    if (!kTeamVerified<T>) return HNSW_OK;
     switch (c.R) {
     case 1: return commit_team_t<MODE, T, 1>(h, c, ob, end_node, done);
     case 4: return commit_team_t<MODE, T, 4>(h, c, ob, end_node, done);
@@ -122,7 +106,6 @@ template <int MODE, int T>
 hnsw_status occ_del_commit_team_r(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t id, bool *done)
 {
     *done = false;
-    if (!kTeamVerified<T>) return HNSW_OK;
     switch (c.R) {
     case 1: return del_commit_team_t<MODE, T, 1>(h, c, ob, id, done);
     case 4: return del_commit_team_t<MODE, T, 4>(h, c, ob, id, done);

@@ -7,16 +7,7 @@
 // the compiler drops the s_barrier.  Here the block has a second wave that takes no part in any of that, and the
 // only s_barriers the first wave may execute are the two of each hand-over with the keeper: in THIS unit a block-level
 // synchronisation of the shared code is the wave's own (same fences, a wave barrier instead of s_barrier).
-#include <hip/hip_runtime.h>
-namespace hnsw {
-__device__ __forceinline__ void wave_sync_for_duo()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-} // namespace hnsw
-#define __syncthreads() ::hnsw::wave_sync_for_duo()
+#include "hnsw_wave_sync.hpp"   // "__syncthreads()" = this wave's own full synchronisation
 #include "hnsw_host.hpp"
 #include "hnsw_plan_lean.hpp"
 

@@ -1045,3 +1045,32 @@ def test_two_wave_plans_and_four_wave_commits_build_the_reference_graph(eng, ora
     ok, why = graphs_equal(o.export(), gi.export_graph())
     assert ok, why
     gi.close()
+
+
+@pytest.mark.parametrize("commit_team", [1, 0])
+@pytest.mark.parametrize("n,dim,m,ef", [(1200, 768, 16, 400), (1200, 768, 32, 100)])
+def test_dim768_deletes_equal_the_oracle_after_every_delete(eng, oracle_mod, n, dim, m, ef, commit_team):
+    """The dim-768 variant's HNSW.NODE.DEL, graph compared after EVERY delete.  These are the cases on which the
+    four-wave commit once accepted stale speculative re-selections: a delete writes more journal entries than its LDS
+    mirror holds, the validation reads the rest back from HBM, and the wave-level synchronisation did not wait for the
+    stores (hnsw_wave_sync.hpp).  Nodes with more neighbours than m_max0 among the victims."""
+    V = make_data(n, dim, seed=81)
+    lv = oracle_mod.draw_levels(n, m, 6)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch(V, lv)
+    gi = eng.Index("d768", dim, m, ef)
+    gi.set_tuning("commit_team", commit_team)
+    gi.add_batch(V, levels=lv, mode="exact")
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    for v in (7, 100, 555, 3, 148, 484):
+        o.delete(v)
+        gi.delete_node("node%d" % v)
+        ok, why = graphs_equal(o.export(), gi.export_graph())
+        assert ok, "after deleting %d: %s" % (v, why)
+    for i, v in enumerate((7, 100, 555)):                     # and back in: single adds on the thinned graph
+        o.add(V[v], int(lv[v]))
+        gi.add_node("again%d" % i, V[v], level=int(lv[v]))
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    gi.close()
