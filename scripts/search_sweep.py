@@ -68,6 +68,9 @@ def main():
         if int(kv.pop("bf16", 0)):
             gi.set_tuning("compress_bf16", 1)        # one way: later variants run on the bf16 copy too
             base = None
+        if int(kv.pop("fp8", 0)):
+            gi.set_tuning("compress_fp8", 1)         # likewise
+            base = None
         # defaults first, then the variant's knobs
         for key, val in dict(waves_per_cu=8, tag_bb=-1, tag_table=1, grid=-1, visited_bounded=1, launch_concurrency=1, lean=1, query_in_lds=0).items():
             gi.set_tuning(key, val)
@@ -99,7 +102,7 @@ def main():
         ms = e0.elapsed_time(e1) / a.reps if nstreams == 1 else (time.perf_counter() - t0) * 1e3 / a.reps
         sc, _ = gi.counters()
         nq = a.reps * B
-        esz = 2 if getattr(main, 'bf16', False) or 'bf16' in var else 4
+        esz = 1 if 'fp8' in var else (2 if 'bf16' in var else 4)
         byt = (sc.n_dist * esz * dim + sc.n_ids * 4) / a.reps + B * (4 * dim + 8 * k)
         run(0)
         torch.cuda.synchronize()
