@@ -1074,3 +1074,39 @@ def test_dim768_deletes_equal_the_oracle_after_every_delete(eng, oracle_mod, n, 
     ok, why = graphs_equal(o.export(), gi.export_graph())
     assert ok, why
     gi.close()
+
+
+def test_one_wave_and_four_wave_commits_give_the_same_verdicts_on_speculative_records(eng, oracle_mod):
+    """Deletes on random small indexes (dims 96 / 128 / 256 / 768): after every delete the graph is the oracle's, and the
+    one-wave and the four-wave commit kernel used the SAME speculative re-selections and recomputed the same others
+    (the control block's n_spec / n_fallback).  Before hnsw_wave_sync.hpp they did not: different builds of the same
+    validation flagged different records on dim 768, one of them too few."""
+    import ctypes as C
+    from redis_hnsw_amd import _capi
+    lib = _capi.load()
+    lib.hnsw_debug_occ_ctl.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    rng = np.random.default_rng(5)
+    for c, (dim, m, ef) in enumerate([(768, 16, 400), (128, 32, 100), (256, 8, 200), (96, 16, 100), (768, 24, 40)]):
+        n = int(rng.integers(600, 1200))
+        V = make_data(n, dim, seed=200 + c)
+        lv = oracle_mod.draw_levels(n, m, 21 + c)
+        victims = [int(x) for x in rng.choice(n, size=6, replace=False)]
+        verdicts = {}
+        for team in (1, 0):
+            o = oracle_mod.OracleIndex(dim, m, ef)
+            o.add_batch(V, lv)
+            gi = eng.Index("v", dim, m, ef)
+            gi.set_tuning("commit_team", team)
+            gi.add_batch(V, levels=lv, mode="exact")
+            out = (C.c_uint64 * 18)()
+            vs = []
+            for v in victims:
+                o.delete(v)
+                gi.delete_node("node%d" % v)
+                assert lib.hnsw_debug_occ_ctl(gi._h, out) == 0
+                vs.append((int(out[16]), int(out[17])))
+                ok, why = graphs_equal(o.export(), gi.export_graph())
+                assert ok, "%s team=%d after deleting %d: %s" % ((n, dim, m, ef), team, v, why)
+            verdicts[team] = vs
+            gi.close()
+        assert verdicts[1] == verdicts[0], ((n, dim, m, ef), verdicts)
