@@ -578,8 +578,8 @@ hnsw_status hnsw_create(uint32_t dim, uint32_t m, uint32_t ef_construction, uint
     *out = nullptr;
     hnsw_index *h = new hnsw_index();
     *out = h; // returned even on failure so the caller can read hnsw_last_error()
-    if (dim == 0 || m < 2 || m > 64 || ef_construction == 0 || ef_construction > 4096)
-        return fail(h, HNSW_ERR_INVALID, "supported: dim >= 1, 2 <= M <= 64, 1 <= EFCON <= 4096");
+    if (dim == 0 || m < 2 || m > kMaxM || ef_construction == 0 || ef_construction > 4096)
+        return fail(h, HNSW_ERR_INVALID, "supported: dim >= 1, 2 <= M <= 256, 1 <= EFCON <= 4096");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(h, HNSW_ERR_DEVICE, "no HIP device: this engine has no CPU path");
@@ -608,6 +608,14 @@ hnsw_status hnsw_create(uint32_t dim, uint32_t m, uint32_t ef_construction, uint
     for (uint32_t r = 0; r < kSpillRegions; ++r) HIP_TRY(h, hipEventCreateWithFlags(&h->spill_ev[r], hipEventDisableTiming));
     h->stride0 = default_stride(h->m_max0, m, 0);
     h->strideU = default_stride(h->m_max, m, 0);
+    if (m > 64) {
+        // the reference does not bound M (core.rs:322-347): above 64 the plans' lists no longer fit one id per lane, so
+        // every insert and delete takes the serial kernels (k_insert_plan / k_insert_commit_exact / k_delete_exact),
+        // which walk such lists 64 at a time; searches take the general kernel (rows wider than 127 ids)
+        h->wide_m = true;
+        h->occ_window = 0;
+        h->plan_lean = 0;
+    }
     hnsw_status s;
     if ((s = dev_alloc(h, &h->d_hdr, 1, 0)) != HNSW_OK) return s;
     h->enterpoint = -1;
@@ -702,6 +710,8 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
     if (!std::strcmp(key, "select_shortcut")) { h->select_shortcut = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "plan_lean")) { h->plan_lean = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "single_window")) { h->single_window = value != 0; return HNSW_OK; }
+    if (h->wide_m && (!std::strcmp(key, "occ_window") || !std::strcmp(key, "plan_lean") || !std::strcmp(key, "single_window")))
+        return HNSW_OK;                                  // M > 64: the serial kernels only (hnsw_create)
     if (!std::strcmp(key, "occ_window")) { h->occ_window = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), kOccMaxW); return HNSW_OK; }
     if (!std::strcmp(key, "occ_ahead_x10")) { h->occ_ahead_x10 = (uint32_t)std::max<int64_t>(value, 5); return HNSW_OK; }
     if (!std::strcmp(key, "occ_slack_extra")) { h->occ_slack_extra = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 64); return HNSW_OK; }
@@ -786,6 +796,7 @@ hnsw_status hnsw_add_batch(hnsw_index *h, const float *V, uint32_t n, uint32_t d
     ON_DEVICE(h);
     hnsw_status s;
     uint32_t done = 0;
+    if (h->wide_m) mode = 0;                                 // M > 64: the reference's order through the serial kernels
     // exact inserts: all of them (mode 0) or the seed prefix of the fast build.  Large exact batches go
     // through the optimistic window (same graph, planned in parallel, committed in order: hnsw_occ.hpp).
     if (mode == 0 && h->occ_window >= 2 && n >= h->occ_min_batch) {

@@ -126,6 +126,7 @@ struct hnsw_index {
     bool duo = true;                 // ... in its two-wave form (hnsw_search_duo.hpp) when at most duo_max queries are in flight
     uint32_t duo_max = 1024;         // 4 workgroups of two waves per CU: every query gets two SIMD slots
     bool last_search_duo = false;
+    bool wide_m = false;             // M > 64: serial insert / delete kernels only
     int commit_team = 1;             // the commit kernels run with three helper wavefronts (hnsw_tu_occteam.hip)
     bool plan_duo = true;            // insert plans (always lone chains) run in the two-wave form when at most plan_duo_max are launched at once
     uint32_t plan_duo_max = 256;     // one two-wave workgroup per CU

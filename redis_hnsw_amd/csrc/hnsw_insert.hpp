@@ -17,7 +17,7 @@
 namespace hnsw {
 
 constexpr uint32_t kMaxLayers = 32;       // levels 0..31
-constexpr uint32_t kPlanStride = 1 + 64;  // per (slot, layer): count + up to 64 ids
+constexpr uint32_t kPlanStride = 1 + kMaxM;  // per (slot, layer): count + up to M ids
 
 // ---------------------------------------------------------------------------
 // select_neighbors (core.rs:677-757) with extend_candidates = keep_pruned =
@@ -29,9 +29,10 @@ constexpr uint32_t kPlanStride = 1 + 64;  // per (slot, layer): count + up to 64
 // candidate is merged in.  cand[0..ncand) is sorted nearest first and is left
 // untouched.  Result in m.S[0..n), sorted; returns n.
 // ---------------------------------------------------------------------------
-// S holds up to kSelMax = 128 keys (m_max0 = 2M, M <= 64): one register slice per 64
+// S holds up to kSelMax keys (m_max0 = 2M): one register slice per 64; the eight-slice form serves M > 64 only
 __device__ __forceinline__ uint32_t merge_S(uint64_t *S, uint32_t nS, uint32_t mcap, uint64_t key, bool take, int lane)
 {
+    if (mcap > 128) return merge_sorted<8>(S, nS, mcap, key, take, lane);
     return mcap > 64 ? merge_sorted<2>(S, nS, mcap, key, take, lane) : merge_sorted<1>(S, nS, mcap, key, take, lane);
 }
 
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(64, 1) void k_insert_plan(GraphView g, uint32_t fir
             if (fail) break;
             uint32_t *pl = plan + ((size_t)s * kMaxLayers + lc) * kPlanStride;
             if (lane == 0) pl[0] = nS;
-            if ((uint32_t)lane < nS) pl[1 + lane] = key_id(m.S[lane]);
+            for (uint32_t i = lane; i < nS; i += 64) pl[1 + i] = key_id(m.S[i]);   // (more than 64 only when M > 64)
             ep = wnearest;                                  // core.rs:576
             __syncthreads();
         }
@@ -510,20 +511,23 @@ __global__ __launch_bounds__(64, 1) void k_insert_commit_exact(GraphView g, uint
         uint32_t *maxdeg = lc ? &g.hdr->max_degU : &g.hdr->max_deg0;
         const uint32_t *pl = plan + (size_t)lc * kPlanStride;
         const uint32_t nsel = pl[0];
-        const uint32_t myselid = (uint32_t)lane < nsel ? pl[1 + lane] : kEmpty;
 
-        // connect_neighbors (core.rs:759-774): nearest first
+        // connect_neighbors (core.rs:759-774): nearest first (64 at a time: more than one pass only when M > 64)
         uint32_t *qrow = row_ptr(g, id, lc);
         if (lane == 0) qrow[0] = nsel;
-        if ((uint32_t)lane < nsel) {
-            qrow[1 + lane] = myselid;                       // :770
-            uint32_t *nrow = row_ptr(g, myselid, lc);       // :771-772 (id is new: never present)
-            uint32_t c = nrow[0];
-            if (c + 1 > stride - 1) atomicOr(&g.hdr->status, ST_ROW_OVERFLOW);
-            else { nrow[1 + c] = id; nrow[0] = c + 1; atomicMax(maxdeg, c + 1); }
+        for (uint32_t sb = 0; sb < nsel; sb += 64) {
+            const uint32_t si = sb + (uint32_t)lane;
+            const uint32_t myselid = si < nsel ? pl[1 + si] : kEmpty;
+            if (si < nsel) {
+                qrow[1 + si] = myselid;                     // :770
+                uint32_t *nrow = row_ptr(g, myselid, lc);   // :771-772 (id is new: never present)
+                uint32_t c = nrow[0];
+                if (c + 1 > stride - 1) atomicOr(&g.hdr->status, ST_ROW_OVERFLOW);
+                else { nrow[1 + c] = id; nrow[0] = c + 1; atomicMax(maxdeg, c + 1); }
+            }
+            touch_push(touched, touched_cap, nt, myselid, si < nsel, lane); // :535-537
         }
         if (lane == 0) atomicMax(maxdeg, nsel);
-        touch_push(touched, touched_cap, nt, myselid, (uint32_t)lane < nsel, lane); // :535-537
         __threadfence();
         __syncthreads();
 

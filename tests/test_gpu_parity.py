@@ -1110,3 +1110,46 @@ def test_one_wave_and_four_wave_commits_give_the_same_verdicts_on_speculative_re
             verdicts[team] = vs
             gi.close()
         assert verdicts[1] == verdicts[0], ((n, dim, m, ef), verdicts)
+
+
+@pytest.mark.parametrize("n,dim,m,ef", [(2000, 32, 100, 200), (900, 128, 65, 100), (700, 64, 256, 300)])
+def test_m_above_64_builds_searches_and_deletes_like_the_oracle(eng, oracle_mod, n, dim, m, ef):
+    """The reference does not bound M (core.rs:322-347, src/lib.rs:39-56).  Above 64 a node's selected links no longer fit
+    one per lane: the serial insert / delete kernels walk them 64 at a time, select_neighbors keeps up to 2M = 512 keys.
+    Batch build (both modes: the fast one is the exact one here), single adds with the update list, searches, deletes:
+    the oracle's graph row for row, its answers bit for bit."""
+    V = make_data(n + 20, dim, seed=91)
+    lv = oracle_mod.draw_levels(n + 20, m, 8)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch(V[:n], lv[:n])
+    gi = eng.Index("widem", dim, m, ef)
+    half = n // 2
+    gi.add_batch(V[:half], levels=lv[:half], mode="exact")
+    gi.add_batch(V[half:n], levels=lv[half:n], mode="fast")
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    assert max(len(o.neighbors(i, 0)) for i in range(n)) > 64
+    for i in range(n, n + 20):
+        oid, ot = o.add(V[i], int(lv[i]), want_touched=True)
+        got = []
+        gi.add_node("node%d" % i, V[i], lambda s_, nid: got.append(nid), level=int(lv[i]))
+        assert sorted(got) == sorted(ot.tolist()), "touched set of insert %d" % i
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    Q = make_data(48, dim, seed=92)
+    k = 10
+    ids, sims, n_out = gi.search_batch(Q, k)
+    oids, osims, on, _ = o.search_batch(Q, k)
+    assert np.array_equal(n_out, on)
+    for q in range(len(Q)):
+        nv = int(on[q])
+        assert np.array_equal(ids[q, :nv], oids[q, :nv]) and np.array_equal(_bits(sims[q, :nv]), _bits(osims[q, :nv]))
+    deg = [len(o.neighbors(i, 0)) for i in range(n)]
+    for v in [int(i) for i in np.argsort(deg)[-3:]] + [3, 77]:
+        o.delete(v)
+        gi.delete_node("node%d" % v)
+        ok, why = graphs_equal(o.export(), gi.export_graph())
+        assert ok, "after deleting %d: %s" % (v, why)
+    for q in Q[:8]:
+        assert [r.id for r in gi.search_knn(q, k)] == o.search(q, k)[0].tolist()
+    gi.close()
