@@ -582,8 +582,8 @@ __device__ __forceinline__ int find_unexpanded(const uint64_t *W, uint32_t nW, i
 }
 
 constexpr uint32_t kAuxWords = 1024; // insert scratch: one adjacency row (degree <= 1023; the reference does not bound degrees, core.rs:790-796)
-constexpr uint32_t kSelMax = 512;   // select_neighbors result: m_max0 = 2M ids at most (M <= kMaxM = 256)
-constexpr uint32_t kMaxM = 256;     // M above 64 is served by the serial insert / delete kernels only (hnsw_create)
+constexpr uint32_t kSelMax = 256;   // select_neighbors result: m_max0 = 2M ids at most (M <= kMaxM = 128)
+constexpr uint32_t kMaxM = 128;     // M above 64 is served by the serial insert / delete kernels only (hnsw_create)
 
 // LDS carve-up.  Search: [W: R*64*8][fresh: 64*4][dsc: 64*4][qlds (T==0)][hash: nb*32].
 // The insert kernels add [S: 64*8][aux: kAuxWords*4] after dsc.

@@ -579,7 +579,7 @@ hnsw_status hnsw_create(uint32_t dim, uint32_t m, uint32_t ef_construction, uint
     hnsw_index *h = new hnsw_index();
     *out = h; // returned even on failure so the caller can read hnsw_last_error()
     if (dim == 0 || m < 2 || m > kMaxM || ef_construction == 0 || ef_construction > 4096)
-        return fail(h, HNSW_ERR_INVALID, "supported: dim >= 1, 2 <= M <= 256, 1 <= EFCON <= 4096");
+        return fail(h, HNSW_ERR_INVALID, "supported: dim >= 1, 2 <= M <= 128, 1 <= EFCON <= 4096");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(h, HNSW_ERR_DEVICE, "no HIP device: this engine has no CPU path");

@@ -29,10 +29,10 @@ constexpr uint32_t kPlanStride = 1 + kMaxM;  // per (slot, layer): count + up to
 // candidate is merged in.  cand[0..ncand) is sorted nearest first and is left
 // untouched.  Result in m.S[0..n), sorted; returns n.
 // ---------------------------------------------------------------------------
-// S holds up to kSelMax keys (m_max0 = 2M): one register slice per 64; the eight-slice form serves M > 64 only
+// S holds up to kSelMax keys (m_max0 = 2M): one register slice per 64; the four-slice form serves M > 64 only
 __device__ __forceinline__ uint32_t merge_S(uint64_t *S, uint32_t nS, uint32_t mcap, uint64_t key, bool take, int lane)
 {
-    if (mcap > 128) return merge_sorted<8>(S, nS, mcap, key, take, lane);
+    if (mcap > 128) return merge_sorted<4>(S, nS, mcap, key, take, lane);
     return mcap > 64 ? merge_sorted<2>(S, nS, mcap, key, take, lane) : merge_sorted<1>(S, nS, mcap, key, take, lane);
 }
 

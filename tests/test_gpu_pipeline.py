@@ -391,10 +391,10 @@ def test_large_m_builds_the_reference_graph(eng, oracle_mod, m, dim, ef, n):
     gi.close(); o.close()
 
 
-def test_m_above_256_is_refused_with_the_limit_in_the_message(eng):
+def test_m_above_128_is_refused_with_the_limit_in_the_message(eng):
     with pytest.raises(eng.HNSWError) as e:
-        eng.Index("toobig", 16, 257, 100)
-    assert "M <= 256" in e.value.msg
+        eng.Index("toobig", 16, 129, 100)
+    assert "M <= 128" in e.value.msg
     gi = eng.Index("fast64", 64, 64, 128)                              # and the fast build works at the limit
     V = make_data(3000, 64, seed=43)
     gi.add_batch(V, mode="fast")
