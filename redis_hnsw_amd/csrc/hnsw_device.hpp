@@ -53,6 +53,8 @@ struct GraphView {
     DevHeader *hdr;
     uint32_t dim, stride0, strideU;
     uint32_t tagcfg;            // 16-bit tag visited table: log2(buckets) | idbits << 8; 0 = 32-bit ids
+    uint32_t plan_stride;       // words per (slot, layer) row of the insert plans: 1 + max(64, M)
+    uint32_t selcap;            // keys select_neighbors' result list holds in LDS: kSelMax, kSelMaxWide when M > 64
 };
 
 // Make this wave's own global stores visible to its own later loads: wait for them (they are written through
@@ -582,26 +584,27 @@ __device__ __forceinline__ int find_unexpanded(const uint64_t *W, uint32_t nW, i
 }
 
 constexpr uint32_t kAuxWords = 1024; // insert scratch: one adjacency row (degree <= 1023; the reference does not bound degrees, core.rs:790-796)
-constexpr uint32_t kSelMax = 256;   // select_neighbors result: m_max0 = 2M ids at most (M <= kMaxM = 128)
+constexpr uint32_t kSelMax = 128;   // select_neighbors result: m_max0 = 2M ids at most (M <= 64; g.selcap = 256 for an index with M > 64)
+constexpr uint32_t kSelMaxWide = 256;
 constexpr uint32_t kMaxM = 128;     // M above 64 is served by the serial insert / delete kernels only (hnsw_create)
 
 // LDS carve-up.  Search: [W: R*64*8][fresh: 64*4][dsc: 64*4][qlds (T==0)][hash: nb*32].
 // The insert kernels add [S: 64*8][aux: kAuxWords*4] after dsc.
-__host__ __device__ inline size_t lds_fixed_bytes(int R, int T, uint32_t dim, bool ins)
+__host__ __device__ inline size_t lds_fixed_bytes(int R, int T, uint32_t dim, bool ins, uint32_t selcap = kSelMax)
 {
     size_t b = (size_t)R * 64 * 8 + 64 * 4 + 64 * 4;
-    if (ins) b += kSelMax * 8 + kAuxWords * 4;
+    if (ins) b += (size_t)selcap * 8 + kAuxWords * 4;
     if (T == 0) b += ((size_t)dim * 4 + 15) & ~(size_t)15;
     return b;
 }
-__host__ __device__ inline size_t lds_bytes(int R, int T, uint32_t dim, uint32_t nbuckets, bool ins)
+__host__ __device__ inline size_t lds_bytes(int R, int T, uint32_t dim, uint32_t nbuckets, bool ins, uint32_t selcap = kSelMax)
 {
-    return lds_fixed_bytes(R, T, dim, ins) + (size_t)nbuckets * 32;
+    return lds_fixed_bytes(R, T, dim, ins, selcap) + (size_t)nbuckets * 32;
 }
 
 template <int R, int T, bool INS>
 __device__ __forceinline__ void carve(unsigned char *smem, uint32_t dim, uint32_t nbuckets, uint32_t lcap, WaveMem &m,
-                                      Visited &vis, uint32_t tagcfg = 0)
+                                      Visited &vis, uint32_t tagcfg = 0, uint32_t selcap = kSelMax)
 {
     unsigned char *p = smem;
     m.W = reinterpret_cast<uint64_t *>(p); p += (size_t)R * 64 * 8;
@@ -610,7 +613,7 @@ __device__ __forceinline__ void carve(unsigned char *smem, uint32_t dim, uint32_
     m.S = nullptr;
     m.aux = nullptr;
     if (INS) {
-        m.S = reinterpret_cast<uint64_t *>(p); p += kSelMax * 8;
+        m.S = reinterpret_cast<uint64_t *>(p); p += (size_t)selcap * 8;
         m.aux = reinterpret_cast<uint32_t *>(p); p += kAuxWords * 4;
     }
     m.qlds = reinterpret_cast<float *>(p);

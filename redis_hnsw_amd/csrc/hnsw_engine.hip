@@ -103,6 +103,8 @@ void dev_free(hnsw_index *h, Tp *&p, size_t count)
     p = nullptr;
 }
 
+uint32_t plan_stride(const hnsw_index *h) { return 1u + (h->m > 64 ? kMaxM : 64u); }
+
 GraphView view(const hnsw_index *h)
 {
     GraphView g;
@@ -116,6 +118,8 @@ GraphView view(const hnsw_index *h)
     g.stride0 = h->stride0;
     g.strideU = h->strideU;
     g.tagcfg = 0;
+    g.plan_stride = plan_stride(h);
+    g.selcap = h->m > 64 ? kSelMaxWide : kSelMax;
     return g;
 }
 
@@ -234,7 +238,7 @@ int pick_R(uint32_t need)
 // 5.9 k on 1 M); there is no point in more than 3x that.
 uint32_t pick_lnb(const hnsw_index *h, int R, int T, bool ins, uint32_t nwaves)
 {
-    const size_t fixed = lds_fixed_bytes(R, T, h->dim, ins);
+    const size_t fixed = lds_fixed_bytes(R, T, h->dim, ins, h->m > 64 ? kSelMaxWide : kSelMax);
     if (h->lds_buckets_override >= 2) return (uint32_t)h->lds_buckets_override;
     // measured on MI355X: 40448 B per 64-thread block still gives 4 blocks per CU, 40960 B does not
     // (163840 / n - 512); 5..8 per CU follow the same rule, rounded down to 256 B

@@ -17,7 +17,7 @@
 namespace hnsw {
 
 constexpr uint32_t kMaxLayers = 32;       // levels 0..31
-constexpr uint32_t kPlanStride = 1 + kMaxM;  // per (slot, layer): count + up to M ids
+// plan rows: per (slot, layer) a count + up to M ids; g.plan_stride words each (65, or 1 + kMaxM for an index with M > 64)
 
 // ---------------------------------------------------------------------------
 // select_neighbors (core.rs:677-757) with extend_candidates = keep_pruned =
@@ -249,7 +249,7 @@ __device__ __forceinline__ uint32_t select_head_of_W(const WaveMem &m, uint32_t 
 // ---------------------------------------------------------------------------
 // plan kernel: one wave per new node (ids first_id .. first_id+count-1, whose
 // vectors / levels / upper slots are already in HBM and whose rows are empty).
-// plan[(slot*kMaxLayers + lc)*kPlanStride] = n, then n ids nearest first.
+// plan[(slot*kMaxLayers + lc)*g.plan_stride] = n, then n ids nearest first.
 // ---------------------------------------------------------------------------
 template <int MODE, int T, int R>
 __global__ __launch_bounds__(64, 1) void k_insert_plan(GraphView g, uint32_t first_id, uint32_t count, uint32_t ef,
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64, 1) void k_insert_plan(GraphView g, uint32_t fir
     const int lane = threadIdx.x;
     WaveMem m;
     Visited vis;
-    carve<R, T, true>(smem, g.dim, lnb, lcap, m, vis, g.tagcfg);
+    carve<R, T, true>(smem, g.dim, lnb, lcap, m, vis, g.tagcfg, g.selcap);
     vis.glob = gspill + (size_t)blockIdx.x * gnb * 8;
     vis.gnb = gnb;
     vis.glob_dirty = false;
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(64, 1) void k_insert_plan(GraphView g, uint32_t fir
                                     ? select_head_of_W(m, nW, mlinks, lane)
                                     : select_topm<MODE, T>(g, m, vis, qr, m.W, nW, id, mlinks, lc, ctr, lane, fail); // :531
             if (fail) break;
-            uint32_t *pl = plan + ((size_t)s * kMaxLayers + lc) * kPlanStride;
+            uint32_t *pl = plan + ((size_t)s * kMaxLayers + lc) * g.plan_stride;
             if (lane == 0) pl[0] = nS;
             for (uint32_t i = lane; i < nS; i += 64) pl[1 + i] = key_id(m.S[i]);   // (more than 64 only when M > 64)
             ep = wnearest;                                  // core.rs:576
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(64, 1) void k_insert_commit_exact(GraphView g, uint
     const int lane = threadIdx.x;
     WaveMem m;
     Visited vis;
-    carve<R, T, true>(smem, g.dim, lnb, lcap, m, vis, g.tagcfg);
+    carve<R, T, true>(smem, g.dim, lnb, lcap, m, vis, g.tagcfg, g.selcap);
     vis.glob = gspill;
     vis.gnb = gnb;
     vis.glob_dirty = false;
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(64, 1) void k_insert_commit_exact(GraphView g, uint
         const uint32_t stride = lc ? g.strideU : g.stride0;
         const uint32_t mmax = lc ? mlinks : 2 * mlinks;     // core.rs:560
         uint32_t *maxdeg = lc ? &g.hdr->max_degU : &g.hdr->max_deg0;
-        const uint32_t *pl = plan + (size_t)lc * kPlanStride;
+        const uint32_t *pl = plan + (size_t)lc * g.plan_stride;
         const uint32_t nsel = pl[0];
 
         // connect_neighbors (core.rs:759-774): nearest first (64 at a time: more than one pass only when M > 64)
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(64, 1) void k_delete_exact(GraphView g, uint32_t id
     const int lane = threadIdx.x;
     WaveMem m;
     Visited vis;
-    carve<R, T, true>(smem, g.dim, lnb, lcap, m, vis, g.tagcfg);
+    carve<R, T, true>(smem, g.dim, lnb, lcap, m, vis, g.tagcfg, g.selcap);
     vis.glob = gspill;
     vis.gnb = gnb;
     vis.glob_dirty = false;
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(64) void k_link_batch(GraphView g, uint32_t first_i
         for (uint32_t lc = 0; lc <= top; ++lc) {
             const uint32_t stride = lc ? g.strideU : g.stride0;
             const uint32_t mmax = lc ? mlinks : 2 * mlinks;
-            const uint32_t *pl = plan + ((size_t)s * kMaxLayers + lc) * kPlanStride;
+            const uint32_t *pl = plan + ((size_t)s * kMaxLayers + lc) * g.plan_stride;
             const uint32_t nsel = pl[0];
             uint32_t *qrow = row_ptr(g, id, lc);
             if (lane == 0) qrow[0] = nsel;

@@ -239,7 +239,7 @@ __device__ __forceinline__ void occ_plan_finish(const GraphView &g, const OccBuf
         const uint32_t lc = lc1;
         const uint32_t stride = lc ? g.strideU : g.stride0;
         const uint32_t mmax = lc ? mlinks : 2 * mlinks;     // core.rs:560
-        const uint32_t *pl = pl0 + (size_t)lc * kPlanStride;
+        const uint32_t *pl = pl0 + (size_t)lc * g.plan_stride;
         const uint32_t nsel = pl[0];
         const uint32_t e = (uint32_t)lane < nsel ? pl[1 + lane] : 0u;
         uint32_t cnt = (uint32_t)lane < nsel ? row_ptr(g, e, lc)[0] : 0u;
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_plan(GraphView g, OccBufs ob, uin
 
     WaveMem m;
     Visited vis;
-    carve<R, T, true>(smem, g.dim, lnb, lcap, m, vis, g.tagcfg);
+    carve<R, T, true>(smem, g.dim, lnb, lcap, m, vis, g.tagcfg, g.selcap);
     vis.glob = gspill + (size_t)blockIdx.x * gnb * 8;
     vis.gnb = gnb;
     vis.glob_dirty = false;
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_plan(GraphView g, OccBufs ob, uin
     const uint32_t lmax = g.hdr->max_layer;                 // core.rs:496
     const uint32_t ep0 = (uint32_t)g.hdr->enterpoint;       // core.rs:508
     const uint32_t l = g.levels[id];
-    uint32_t *pl0 = plan + (size_t)slot * kMaxLayers * kPlanStride;
+    uint32_t *pl0 = plan + (size_t)slot * kMaxLayers * g.plan_stride;
 
     QReg<T> qr;
     load_query<MODE, T>(g.vec + (size_t)id * g.dim, g.dim, qr, m.qlds, lane);
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_plan(GraphView g, OccBufs ob, uin
             for (uint32_t i = lane; i < nW; i += 64)
                 if (sel_log0 + i < kOccMaxReads) { reads[sel_log0 + i].meta = occ_meta(lc, OCC_SELECT, 0, sfull); reads[sel_log0 + i].bound = sbound; }
         }
-        uint32_t *pl = pl0 + (size_t)lc * kPlanStride;
+        uint32_t *pl = pl0 + (size_t)lc * g.plan_stride;
         if (lane == 0) pl[0] = nS;
         if ((uint32_t)lane < nS) pl[1 + lane] = key_id(m.S[lane]);
         // the node's own row: what connect_neighbors will make it (core.rs:770); nobody can reach it yet
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_shrinks(GraphView g, OccBufs ob, 
 
     WaveMem m;
     Visited vis;
-    carve<R, T, true>(smem, g.dim, lnb, lcap, m, vis, g.tagcfg);
+    carve<R, T, true>(smem, g.dim, lnb, lcap, m, vis, g.tagcfg, g.selcap);
     vis.glob = gspill + (size_t)blockIdx.x * gnb * 8;
     vis.gnb = gnb;
     vis.glob_dirty = false;
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit(GraphView g, Oc
     OccScratch sc = occ_carve(smem);
     WaveMem m;
     Visited vis;
-    carve<R, T, true>(smem + kOccScratchBytes, g.dim, lnb, lcap, m, vis, g.tagcfg);
+    carve<R, T, true>(smem + kOccScratchBytes, g.dim, lnb, lcap, m, vis, g.tagcfg, g.selcap);
     volatile TeamTask *task = reinterpret_cast<volatile TeamTask *>(smem + kOccScratchBytes + own_lds);
     uint64_t *W0sub = reinterpret_cast<uint64_t *>(smem + kOccScratchBytes + own_lds + sizeof(TeamTask));
     unsigned char *hmem0 = smem + kOccScratchBytes + own_lds + sizeof(TeamTask) + (size_t)kTeamCand * 8;
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit(GraphView g, Oc
         const uint32_t lmax = g.hdr->max_layer;
         const uint32_t l = g.levels[id];
         const uint32_t top = sl->top;
-        const uint32_t *pl0 = plan + (size_t)slot * kMaxLayers * kPlanStride;
+        const uint32_t *pl0 = plan + (size_t)slot * kMaxLayers * g.plan_stride;
         bool fail = false;
 
         for (uint32_t lc1 = top + 1; lc1-- > 0 && !fail;) { // core.rs:523
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit(GraphView g, Oc
             const uint32_t stride = lc ? g.strideU : g.stride0;
             const uint32_t mmax = lc ? mlinks : 2 * mlinks; // core.rs:560
             uint32_t *maxdeg = lc ? &g.hdr->max_degU : &g.hdr->max_deg0;
-            const uint32_t *pl = pl0 + (size_t)lc * kPlanStride;
+            const uint32_t *pl = pl0 + (size_t)lc * g.plan_stride;
             const uint32_t nsel = pl[0];
             const uint32_t myselid = (uint32_t)lane < nsel ? pl[1 + lane] : kEmpty;
             // connect_neighbors (core.rs:759-774), nearest first; the node's own row was written by its plan
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_del_commit(GraphView g
     OccScratch sc = occ_carve(smem);
     WaveMem m;
     Visited vis;
-    carve<R, T, true>(smem + kOccScratchBytes, g.dim, lnb, lcap, m, vis, g.tagcfg);
+    carve<R, T, true>(smem + kOccScratchBytes, g.dim, lnb, lcap, m, vis, g.tagcfg, g.selcap);
     volatile TeamTask *task = reinterpret_cast<volatile TeamTask *>(smem + kOccScratchBytes + own_lds);
     uint64_t *W0sub = reinterpret_cast<uint64_t *>(smem + kOccScratchBytes + own_lds + sizeof(TeamTask));
     unsigned char *hmem0 = smem + kOccScratchBytes + own_lds + sizeof(TeamTask) + (size_t)kTeamCand * 8;

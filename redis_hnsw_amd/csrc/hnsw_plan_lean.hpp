@@ -107,7 +107,7 @@ __global__ __launch_bounds__(DUO ? 128 : 64, 1) void k_insert_plan_lean(GraphVie
     }
     WaveMem m;
     Visited vis;
-    carve<R, 4, true>(smem, g.dim, lnb, lcap, m, vis, g.tagcfg);
+    carve<R, 4, true>(smem, g.dim, lnb, lcap, m, vis, g.tagcfg, g.selcap);
     vis.glob = gspill + (size_t)blockIdx.x * gnb * 8;
     vis.gnb = gnb;
     vis.glob_dirty = false;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(DUO ? 128 : 64, 1) void k_insert_plan_lean(GraphVie
                                     ? select_head_of_W(m, nW, mlinks, lane)
                                     : select_topm<MODE_AVX, 4>(g, m, vis, qr, m.W, nW, id, mlinks, lc, ctr, lane, fail); // :531
             if (fail) break;
-            uint32_t *pl = plan + ((size_t)s * kMaxLayers + lc) * kPlanStride;
+            uint32_t *pl = plan + ((size_t)s * kMaxLayers + lc) * g.plan_stride;
             if (lane == 0) pl[0] = nS;
             if ((uint32_t)lane < nS) pl[1 + lane] = key_id(m.S[lane]);
             ep = wnearest;                                  // core.rs:576
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(DUO ? 128 : 64, 1) void k_occ_plan_lean(GraphView g
 
     WaveMem m;
     Visited vis;
-    carve<R, 4, true>(smem, g.dim, lnb, lcap, m, vis, g.tagcfg);
+    carve<R, 4, true>(smem, g.dim, lnb, lcap, m, vis, g.tagcfg, g.selcap);
     vis.glob = gspill + (size_t)blockIdx.x * gnb * 8;
     vis.gnb = gnb;
     vis.glob_dirty = false;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(DUO ? 128 : 64, 1) void k_occ_plan_lean(GraphView g
     const uint32_t lmax = g.hdr->max_layer;                 // core.rs:496
     const uint32_t ep0 = (uint32_t)g.hdr->enterpoint;       // core.rs:508
     const uint32_t l = g.levels[id];
-    uint32_t *pl0 = plan + (size_t)slot * kMaxLayers * kPlanStride;
+    uint32_t *pl0 = plan + (size_t)slot * kMaxLayers * g.plan_stride;
 
     QReg<4> qr;
     load_query<MODE_AVX, 4>(g.vec + (size_t)id * g.dim, g.dim, qr, m.qlds, lane);
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(DUO ? 128 : 64, 1) void k_occ_plan_lean(GraphView g
             for (uint32_t i = lane; i < nW; i += 64)
                 if (sel_log0 + i < kOccMaxReads) { reads[sel_log0 + i].meta = occ_meta(lc, OCC_SELECT, 0, sfull); reads[sel_log0 + i].bound = sbound; }
         }
-        uint32_t *pl = pl0 + (size_t)lc * kPlanStride;
+        uint32_t *pl = pl0 + (size_t)lc * g.plan_stride;
         if (lane == 0) pl[0] = nS;
         if ((uint32_t)lane < nS) pl[1 + lane] = key_id(m.S[lane]);
         // the node's own row: what connect_neighbors will make it (core.rs:770); nobody can reach it yet

@@ -1112,7 +1112,7 @@ def test_one_wave_and_four_wave_commits_give_the_same_verdicts_on_speculative_re
         assert verdicts[1] == verdicts[0], ((n, dim, m, ef), verdicts)
 
 
-@pytest.mark.parametrize("n,dim,m,ef", [(2000, 32, 100, 200), (900, 128, 65, 100), (900, 64, 128, 300)])
+@pytest.mark.parametrize("n,dim,m,ef", [(1200, 32, 100, 200), (600, 128, 65, 100), (700, 64, 128, 200)])
 def test_m_above_64_builds_searches_and_deletes_like_the_oracle(eng, oracle_mod, n, dim, m, ef):
     """The reference does not bound M (core.rs:322-347, src/lib.rs:39-56).  Above 64 a node's selected links no longer fit
     one per lane: the serial insert / delete kernels walk them 64 at a time, select_neighbors keeps up to 2M = 256 keys.
