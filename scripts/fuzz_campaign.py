@@ -19,8 +19,8 @@ done = bad = 0
 while time.time() - t0 < budget:
     rng = np.random.default_rng(seed)
     kind = str(rng.choice(["uniform", "clustered", "line", "lattice", "dupes"]))
-    dim = int(rng.choice([4, 12, 32, 33, 64, 96, 100, 128, 128, 128, 256]))   # 128: the specialised search / plan routines
-    m = int(rng.choice([2, 3, 4, 5, 8, 12, 16, 24, 31, 32, 33, 40, 48, 64]))
+    dim = int(rng.choice([4, 12, 32, 33, 64, 96, 100, 128, 128, 128, 256, 768]))   # 128: the specialised search / plan routines; 768: the other register variant
+    m = int(rng.choice([2, 3, 4, 5, 8, 12, 16, 24, 31, 32, 33, 40, 48, 64, 65, 100, 128]))   # above 64: the serial kernels
     ef = int(rng.choice([m, m + 1, 16, 40, 100, 200, 300]))
     ef = max(ef, 2)
     case = (kind, dim, m, ef, int(rng.choice([40, 80, 120])), seed)
@@ -30,7 +30,8 @@ while time.time() - t0 < budget:
                           ("visited_bounded", [0, 1]), ("lean", [0, 1]), ("lds_hash_bits", [8, 10]),
                           ("occ_min_batch", [2, 64]), ("occ_ahead_x10", [10, 30]), ("waves_per_cu", [1, 4, 8]),
                           ("tag_table", [0, 1]), ("pipe_chunk", [64, 256, 1024]), ("grid_stride", [0, 1]),
-                          ("force_restride", [16, 48]), ("plan_lean", [0, 1]), ("single_window", [0, 1])):
+                          ("force_restride", [16, 48]), ("plan_lean", [0, 1]), ("single_window", [0, 1]),
+                          ("duo", [0, 1]), ("plan_duo", [0, 1]), ("commit_team", [0, 1])):
             if rng.random() < 0.4:
                 tun.append((key, int(rng.choice(vals))))
     case = case + (tuple(tun),)
