@@ -86,3 +86,27 @@ def test_ctypes_structs_have_the_header_s_layout(capi, tmp_path):
         assert int(got[cname]) == C.sizeof(st), cname
         for fname, _ in st._fields_:
             assert int(got["%s.%s" % (cname, fname)]) == getattr(st, fname).offset, (cname, fname)
+
+
+def test_insert_units_synchronise_their_wave_through_hnsw_wave_sync():
+    """The insert / delete kernels hand data between the lanes of a wave through HBM as well as through LDS; their
+    "__syncthreads()" must therefore wait for the wave's own stores.  Every translation unit that holds
+    such kernels includes hnsw_wave_sync.hpp before anything else, the header spells the wait out, and no unit brings
+    a weaker definition of its own."""
+    import os, re
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "redis_hnsw_amd", "csrc")
+    hdr = open(os.path.join(csrc, "hnsw_wave_sync.hpp")).read()
+    assert re.search(r's_waitcnt vmcnt\(0\) lgkmcnt\(0\)"\s*:::\s*"memory"', hdr)
+    assert "#define __syncthreads() ::hnsw::wave_sync_full()" in hdr
+    units = ["hnsw_tu_insert.hip", "hnsw_tu_occ.hip", "hnsw_tu_planlean.hip", "hnsw_tu_planduo.hip", "hnsw_tu_occteam.hip"]
+    for u in units:
+        src = open(os.path.join(csrc, u)).read()
+        incs = re.findall(r'^#include\s+[<"]([^>"]+)[>"]', src, flags=re.M)
+        assert incs and incs[0] == "hnsw_wave_sync.hpp", (u, incs[:2])
+        assert "#define __syncthreads" not in src, u
+    # and the kernels of those units live in headers that no other unit instantiates with the plain barrier
+    for f in os.listdir(csrc):
+        if f.endswith(".hip") and f not in units:
+            src = open(os.path.join(csrc, f)).read()
+            for k in ("k_occ_commit<", "k_occ_del_commit<", "k_insert_commit_exact<", "k_delete_exact<", "k_occ_shrinks<", "k_insert_plan<"):
+                assert k not in src, (f, k)
