@@ -1065,8 +1065,10 @@ def main():
             g1.close(); o1.close()
 
     known = {(1_000_000, 128, 16, 200, 10, 1024): "C2", (1_000_000, 768, 32, 400, 100, 4096): "C3",
-             (10_000_000, 128, 16, 200, 10, 1024): "C4"}
+             (10_000_000, 128, 16, 200, 10, 1024): "C4", (10_000, 128, 5, 200, 10, 1): "C1"}
     cfg_name = known.get((N, dim, M, ef, k, B), "custom")
+    if cfg_name == "C2" and args.graph == "exact":
+        cfg_name = "C5"                                  # the same index, BUILT on the GPU in the reference's order first
     qps = world * B * args.steps / t_wall
     out = {
         "metric": "HNSW.SEARCH QPS + recall@10, 1M x 128 f32, ef=200" if cfg_name == "C2" else
