@@ -40,6 +40,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec -- the roofline's denominator
 HBM_MEASURED_GBS = 6300.0  # same guide: what a streaming copy sustains from DRAM on this part
+GATHER_PROFILE = os.path.join(ROOT, "profiles", "r5_gather_bw.txt")   # scripts/microbench/gather_bw.hip on the GPU box
 FIXTURES = {(1_000_000, 128, 16, 200): os.path.join(ROOT, "data", "c2_ref_graph_1m.npz")}
 FIXTURE_50K = os.path.join(ROOT, "data", "c2_ref_graph_50k.npz")
 # the reference's own work counters of the C2 build at several prefix sizes (tests/fixtures/make_ref_counters.py)
@@ -64,6 +65,31 @@ def insert_roofline(n_dist, n_ids, n_inserts, seconds, dim, source):
                 n_ids_per_insert=round(n_ids / max(n_inserts, 1), 1), counts=source,
                 note="an insert is a chain of dependent expansions on a few wavefronts: latency-bound by construction, the "
                      "fraction says how far from a bandwidth-bound stream it is")
+
+
+def measured_gather(row_bytes, matrix_mb):
+    """profiles/r5_gather_bw.txt: what the part delivers for read-only random gathers of whole rows of `row_bytes`
+    (the search kernel's access pattern with nothing else to do) -- over 8 GB, where the 256 MB Infinity Cache cannot
+    help, and over an array the size of this workload's vector matrix.  GB/s, best residency of each; None if absent."""
+    far, this = None, None
+    try:
+        for line in open(GATHER_PROFILE):
+            if not line.startswith("gather "):
+                continue
+            kv = dict(t.split("=") for t in line.split("#")[0].split()[1:])
+            if int(kv["row_bytes"]) != row_bytes:
+                continue
+            gbs = 1e3 * float(kv["tbs"])
+            mb = float(kv["array_mb"])
+            if mb >= 8000:
+                far = max(far or 0.0, gbs)
+            if abs(mb - matrix_mb) <= 0.02 * matrix_mb:
+                this = max(this or 0.0, gbs)
+    except (OSError, ValueError, KeyError):
+        return None
+    if far is None:
+        return None
+    return dict(over_8_gb=far, over_an_array_of_this_matrix_size=this, source="profiles/r5_gather_bw.txt")
 
 
 def ref_insert_counters(prefix):
@@ -171,11 +197,23 @@ def spawn_ranks(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def measure_traffic(argv, log):
+def timed_launch_rows(rows, batch):
+    """Of the (kernel, lds, grid, dispatches, avg) groups of a --pmc pass, the ones that are the TIMED step's launch
+    shape: one workgroup of 64 threads per query (the specialised kernel), or the general kernel's grid-stride form
+    (at most 2048 workgroups) -- never the two-wave kernel of a lone launch (128 threads per query) and never the
+    1024-query chunks hnsw_search_batch cuts a host batch into.  Most dispatches first."""
+    want = {64 * batch, 64 * min(batch, 2048)}
+    hit = [r for r in rows if int(r[2]) in want and "duo" not in r[0]]
+    return sorted(hit, key=lambda r: -r[3])
+
+
+def measure_traffic(argv, log, batch, algorithmic):
     """HBM bytes per k_search launch of THIS command line, measured now: two short re-runs under
-    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes: the two do not fit one), the most frequent
-    k_search launch shape of each, FETCH x 2 (gfx950 correction) + WRITE.  (None, None) if rocprofv3 is missing or
-    a pass fails -- the caller then falls back to the committed figure and says so."""
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes: the two do not fit one), the dispatch group
+    whose grid is the timed step's (`timed_launch_rows`), FETCH x 2 (gfx950 correction) + WRITE.  The figure must lie
+    within 0.9 .. 1.3 x the algorithmic bytes of a launch, else the wrong group was read (or the kernel re-reads) and
+    the leg FAILS: (None, reason).  (None, None) if rocprofv3 is missing or a pass fails -- the caller then falls back
+    to the committed figure and says so."""
     import shutil
     import sqlite3
     import subprocess
@@ -194,7 +232,7 @@ def measure_traffic(argv, log):
         if a.startswith(("--steps=", "--warmup=", "--cpu-seconds=")):
             continue
         keep.append(a)
-    sub = keep + ["--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--no-extras", "--no-traffic"]
+    sub = keep + ["--steps", "12", "--warmup", "2", "--only-timed"]
     tmp = tempfile.mkdtemp(prefix="hnsw_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     vals = {}
@@ -202,7 +240,7 @@ def measure_traffic(argv, log):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, ctr)
             cmd = [exe, "--pmc", ctr, "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__)] + sub
-            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
             db = None
             for dp, _, files in os.walk(out):
                 for f in files:
@@ -214,17 +252,23 @@ def measure_traffic(argv, log):
             cur = sqlite3.connect(db).cursor()
             rows = list(cur.execute(
                 "select kernel_name, lds_block_size, grid_size, count(*), avg(value) from counters_collection "
-                "where kernel_name like '%k_search%' and counter_name = ? group by kernel_name, lds_block_size, grid_size "
-                "order by count(*) desc", (ctr,)))
+                "where kernel_name like '%k_search%' and counter_name = ? group by kernel_name, lds_block_size, grid_size",
+                (ctr,)))
+            rows = timed_launch_rows(rows, batch)
             if not rows:
-                return None, None
+                return None, "no k_search dispatch group with the timed step's grid (64 x %d) under --pmc %s" % (batch, ctr)
             vals[ctr] = rows[0]
         kib_r, kib_w = vals["FETCH_SIZE"][4], vals["WRITE_SIZE"][4]
         traffic = int(kib_r * 1024 * 2.0 + kib_w * 1024)
         src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE, then --pmc WRITE_SIZE, of `bench.py %s`; "
-               "%d launches of %s; FETCH_SIZE %.0f KiB x 2 (gfx950) + WRITE_SIZE %.0f KiB per launch; launches are serialised "
-               "under --pmc" % (" ".join(sub), vals["FETCH_SIZE"][3], vals["FETCH_SIZE"][0].split("(")[0].replace("void ", ""), kib_r, kib_w))
-        log("traffic per launch %.3f GB (in-run PMC)" % (traffic / 1e9))
+               "%d launches of %s with grid %d (the timed step's: one workgroup per query); FETCH_SIZE %.0f KiB x 2 (gfx950) + "
+               "WRITE_SIZE %.0f KiB per launch; launches are serialised under --pmc" % (
+                   " ".join(sub), vals["FETCH_SIZE"][3], vals["FETCH_SIZE"][0].split("(")[0].replace("void ", ""),
+                   vals["FETCH_SIZE"][2], kib_r, kib_w))
+        ratio = traffic / max(algorithmic, 1.0)
+        log("traffic per launch %.3f GB (in-run PMC) = %.3f x the algorithmic bytes" % (traffic / 1e9, ratio))
+        if not 0.9 <= ratio <= 1.3:
+            return None, "REJECTED: %.3f GB per launch is %.2f x the algorithmic bytes (outside 0.9 .. 1.3); %s" % (traffic / 1e9, ratio, src)
         return traffic, src
     except (subprocess.TimeoutExpired, OSError, sqlite3.Error) as e:
         log("in-run traffic measurement failed: %r" % (e,))
@@ -252,6 +296,8 @@ def main():
     ap.add_argument("--launch-concurrency", type=int, default=0,
                     help="engine tuning launch_concurrency (0 = default: the engine observes the launches in flight)")
     ap.add_argument("--no-traffic", action="store_true", help="do not re-run under rocprofv3 --pmc for roofline.traffic")
+    ap.add_argument("--only-timed", action="store_true",
+                    help="stop after the timed region (what the --pmc passes of roofline.traffic run); prints no JSON line")
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE",
                     help="extra engine tuning for experiments (hnsw_set_tuning), repeatable")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
@@ -543,6 +589,11 @@ def main():
     kernel_ms_median = float(np.median(per_launch)) if per_launch else None
     kernel_ms_p90 = float(np.percentile(per_launch, 90)) if per_launch else None
     log("timed region done: %.3f ms/step, %.3f ms per launch with %d in flight" % (1e3 * t_wall / args.steps, kernel_ms, S))
+    if args.only_timed:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     sc, _ = index.counters()
 
     gather_ok = None
@@ -939,8 +990,8 @@ def main():
     # MI355X_MICROARCH.md, calibrated on this access pattern in profiles/*_pmc_hbm.txt), else the committed figure
     traffic, traffic_source = None, None
     if not args.no_traffic and world == 1 and args.steps:
-        traffic, traffic_source = measure_traffic(sys.argv[1:], log)
-    if traffic is None:
+        traffic, traffic_source = measure_traffic(sys.argv[1:], log, B, bytes_per_launch)
+    if traffic is None and not (traffic_source or "").startswith("REJECTED"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             want = dict(nodes=N, dim=dim, M=M, ef=ef, k=k, batch=B, graph=mode, streams=S)
@@ -959,11 +1010,14 @@ def main():
     roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_source,
                     peak_hbm_spec=HBM_PEAK_GBS, hbm_measured_copy=HBM_MEASURED_GBS,
+                    hbm_measured_gather=measured_gather(4 * dim, N * dim * 4 / 1e6),
                     frac_of_measured_copy=round(achieved / HBM_MEASURED_GBS, 4),
                     what="ALGORITHMIC bytes (the reference's n_dist x 4 dim + n_ids x 4 + query + results per query) over time, "
                          "against the 8 TB/s HBM3E spec.  It is not a DRAM-level rate: the counters behind `traffic` sit at the "
-                         "L2's memory side and include Infinity-Cache hits (the 256 MB cache holds half of this 512 MB matrix), "
-                         "which is how the figure can exceed what a streaming copy sustains from DRAM (hbm_measured_copy)",
+                         "L2's memory side and include Infinity-Cache hits (256 MB of cache in front of this workload's %.2f GB vector "
+                         "matrix), which is how the figure can exceed what a streaming copy sustains from DRAM "
+                         "(hbm_measured_copy; hbm_measured_gather is the same access pattern without the walk: random %d-byte "
+                         "rows, profiles/r5_gather_bw.txt)" % (N * dim * 4 / 1e9, 4 * dim),
                     kernel="k_search", kernel_ms=round(kernel_ms, 4),
                     kernel_ms_median=None if kernel_ms_median is None else round(kernel_ms_median, 4),
                     kernel_ms_p90=None if kernel_ms_p90 is None else round(kernel_ms_p90, 4),
@@ -1010,7 +1064,39 @@ def main():
             if time.perf_counter() - tc > args.cpu_seconds / 2:
                 break
         tN = time.perf_counter() - tc
-        cpu = dict(value=round(done / t1, 1), unit="queries/s", cores=1, kind="port",
+        # tie census of the bench's own queries (oracle/hnsw_oracle.c: hnsw_oracle_tie_census): the reference orders
+        # SimPair by sim alone and leaves equal sims to std's BinaryHeap; engine and oracle break them by id.  Only a
+        # query where a DECISION met equal sims (core.rs:635, :657) or the k + 1 nearest hold equal sims can be answered
+        # differently by the Rust binary; those few are re-run in the Rust binary's own order (std's heap restated,
+        # pinned against the transcription) and compared with what the ENGINE answered
+        tq0 = time.perf_counter()
+        n_cen = 0
+        cen = dict(queries=0, stop_test_ties=0, accept_test_ties=0, queries_with_decision_tie=0, queries_with_answer_tie=0,
+                   queries_with_any_tie=0)
+        tied_q = []
+        Qcen = Qall[:n_qbatches * B]
+        while n_cen < Qcen.shape[0] and time.perf_counter() - tq0 < max(args.cpu_seconds, 6.0):
+            for qi in range(n_cen, min(n_cen + 256, Qcen.shape[0])):
+                c_ = o.tie_census(Qcen[qi:qi + 1], k)
+                for key_ in cen:
+                    cen[key_] += c_[key_]
+                if c_["queries_with_any_tie"]:
+                    tied_q.append(qi)
+            n_cen = min(n_cen + 256, Qcen.shape[0])
+        differ = 0
+        for qi in tied_q:
+            rid, rsim = o.search_std_heap(Qcen[qi], k)
+            gid, gsim, gn = index.search_batch(Qcen[qi:qi + 1], k)
+            gid, gsim = gid[0, :int(gn[0])], gsim[0, :int(gn[0])]
+            differ += not (np.array_equal(gid, rid) and np.array_equal(gsim.view(np.uint32), rsim.view(np.uint32)))
+        cen.update(tied_queries_answered_differently_in_the_rust_heap_order=differ,
+                   note="of the first %d queries of this bench: decisions that met EQUAL similarities of two different nodes "
+                        "(the only place the reference's sim-only order and the (sim, id) order can part); every tied query was "
+                        "re-run in std::collections::BinaryHeap's own order (restated, tests/golden/tiecase_rust_lattice.npz) "
+                        "and compared with the engine's answer, ids and similarity bits" % n_cen)
+        log("tie census of %d queries: %d with a decision tie, %d with an answer tie; %d answered differently in the Rust heap order" % (
+            n_cen, cen["queries_with_decision_tie"], cen["queries_with_answer_tie"], differ))
+        cpu = dict(value=round(done / t1, 1), unit="queries/s", cores=1, kind="port", tie_census=cen,
                    sample="%d queries of the same 1024-query batch on the same graph, 1 thread, %.1f s" % (done, t1),
                    cpu_model=cpu_model(),
                    all_cores=dict(value=round(reps * B / tN, 1), cores=cores, visible_cpus=os.cpu_count(),

@@ -210,6 +210,10 @@ typedef struct { uint32_t level; nrow *rows; /* [level+1] */ } onode;
 typedef struct {
     uint32_t *stamp; uint32_t stamp_cap; uint32_t epoch;
     heap C, W, res, w2, wd, r, ccopy, econn, enew, nbrs;
+    /* tie census (hnsw_oracle_tie_census): decisions of search_level that met EQUAL similarities of two
+     * different nodes -- the only places where the reference's sim-only order (core.rs:292-300) and this
+     * file's (sim, id) order can part */
+    uint64_t tie_stop, tie_accept;
 } scratch;
 
 struct hnsw_oracle {                                   /* core.rs:303-319  */
@@ -350,6 +354,7 @@ static void search_level(const hnsw_oracle *o, scratch *s, const float *query,
     while (C->n) {                                      /* :630 */
         simpair c = heap_pop(C);                        /* :631 nearest        */
         simpair f = heap_peek(W);                       /* :632 furthest       */
+        if (c.sim == f.sim && c.id != f.id) s->tie_stop++;   /* census: :635 decided by something other than sim */
         if (stop_test(c, f)) break;                     /* :635 c.sim < f.sim  */
         ct->n_expand++;
         const nrow *nb = row_of(o, c.id, level);        /* :642-645            */
@@ -360,6 +365,7 @@ static void search_level(const hnsw_oracle *o, scratch *s, const float *query,
             f = heap_peek(W);                           /* :651                */
             simpair ep2 = { hnsw_oracle_euclidean(query, vec(o, e), o->dim), e }; /* :652 */
             ct->n_dist++;
+            if (W->n >= ef && ep2.sim == f.sim) s->tie_accept++;  /* census: :657 decided by something other than sim */
             if (accept_test(ep2, f) || W->n < ef) {     /* :657                */
                 heap_push(C, ep2);                      /* :659                */
                 heap_push(W, ep2);                      /* :660                */
@@ -678,6 +684,133 @@ uint32_t hnsw_oracle_search(const hnsw_oracle *o, const float *q, uint32_t k,
     uint32_t n = search_knn_internal(o, (scratch *)&o->sc, q, k, o->ef_construction, /* :485 */
                                      ids, sims, &local);
     if (ctrs) *ctrs = local;
+    return n;
+}
+
+/* Tie census of HNSW.SEARCH (test infrastructure for the parity claim).  The reference orders SimPair by sim
+ * alone (core.rs:292-300) and leaves equal sims to std's BinaryHeap; this file and the engine break them by id.
+ * The two can only answer differently on a query where a DECISION met equal sims of two different nodes:
+ *   the stop test    core.rs:635  c.sim == f.sim  (the reference expands c, the total order may stop),
+ *   the accept test  core.rs:657  e.sim == f.sim with W full (the reference rejects e, the total order may accept),
+ *   the answer       core.rs:878-890: two of the k + 1 nearest of W have equal sims (which one is returned, or in
+ *                    which order, is the heap's business).
+ * (Which of two equal furthest members W evicts, :662-664, does not change f.sim and so changes no later decision.)
+ * out[0] queries, [1] stop-test ties, [2] accept-test ties, [3] queries with a stop or accept tie,
+ * out[4] queries whose k + 1 nearest hold equal sims, [5] queries with any of the three.  One thread.           */
+void hnsw_oracle_tie_census(const hnsw_oracle *o, const float *Q, uint32_t B, uint32_t k, uint64_t out[6])
+{
+    memset(out, 0, 6 * sizeof(uint64_t));
+    if (o->enterpoint < 0 || o->node_count - o->n_dead == 0) return;
+    scratch *s = (scratch *)&o->sc;
+    uint32_t *ids = (uint32_t *)malloc(((size_t)k + 1) * 4);
+    float *sims = (float *)malloc(((size_t)k + 1) * 4);
+    for (uint32_t b = 0; b < B; b++) {
+        hnsw_oracle_counters ct = { 0, 0, 0 };
+        s->tie_stop = s->tie_accept = 0;
+        uint32_t n = search_knn_internal(o, s, Q + (size_t)b * o->dim, k + 1, o->ef_construction, ids, sims, &ct);
+        int rt = 0;
+        for (uint32_t i = 1; i < n; i++) rt |= sims[i] == sims[i - 1];
+        out[0]++;
+        out[1] += s->tie_stop; out[2] += s->tie_accept;
+        out[3] += (s->tie_stop + s->tie_accept) != 0;
+        out[4] += rt != 0;
+        out[5] += (s->tie_stop + s->tie_accept) != 0 || rt;
+    }
+    free(ids); free(sims);
+}
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* HNSW.SEARCH in the RUST BINARY's tie order (test infrastructure).  SimPair compares by sim only (core.rs:292-300)  */
+/* and the reference keeps C, W and the result in std::collections::BinaryHeap (core.rs:625-628, :670-674), so which   */
+/* of two equal sims pops, is evicted or is returned first is decided by that heap's sift procedures.  They are      */
+/* restated here from the standard library's published source (library/alloc/src/collections/binary_heap.rs:         */
+/* push = sift_up(0, len-1), stopping at a parent that is >= the element; pop = swap the last element into the root,  */
+/* sift_down_to_bottom(0) -- always towards the greater child, the RIGHT one when the two are equal -- then sift_up;   */
+/* into_vec = the array as it is), as tests/transcription/hnsw_transcription.py (RustHeap) does independently in      */
+/* Python; tests/golden/tiecase_rust_lattice.npz pins one against the other on tie-heavy lattice data.               */
+/* ------------------------------------------------------------------------------------------------------------ */
+typedef struct { simpair *a; uint32_t n, cap; int reverse; } rheap;
+static inline int rh_le(const rheap *h, float x, float y) { return h->reverse ? y <= x : x <= y; }   /* x <= y in the heap's order */
+static uint32_t rh_sift_up(rheap *h, uint32_t start, uint32_t pos)
+{
+    simpair e = h->a[pos];
+    while (pos > start) {
+        uint32_t parent = (pos - 1) / 2;
+        if (rh_le(h, e.sim, h->a[parent].sim)) break;      /* hole.element() <= hole.get(parent) */
+        h->a[pos] = h->a[parent];
+        pos = parent;
+    }
+    h->a[pos] = e;
+    return pos;
+}
+static void rh_push(rheap *h, simpair x)
+{
+    if (h->n == h->cap) { h->cap = h->cap ? h->cap * 2 : 64; h->a = (simpair *)realloc(h->a, (size_t)h->cap * sizeof(simpair)); }
+    h->a[h->n++] = x;
+    rh_sift_up(h, 0, h->n - 1);
+}
+static simpair rh_pop(rheap *h)
+{
+    simpair item = h->a[--h->n];
+    if (h->n) {
+        simpair t = h->a[0]; h->a[0] = item; item = t;
+        const uint32_t end = h->n;
+        uint32_t pos = 0, child = 1;
+        simpair e = h->a[0];
+        while (end >= 2 && child <= end - 2) {             /* sift_down_to_bottom */
+            if (rh_le(h, h->a[child].sim, h->a[child + 1].sim)) child++;
+            h->a[pos] = h->a[child];
+            pos = child;
+            child = 2 * pos + 1;
+        }
+        if (child == end - 1) { h->a[pos] = h->a[child]; pos = child; }
+        h->a[pos] = e;
+        rh_sift_up(h, 0, pos);
+    }
+    return item;
+}
+/* core.rs:607-675 with the reference's own comparisons (:635 c.sim < f.sim, :657 e.sim > f.sim) on std's heaps; res = :670-674 */
+static void search_level_std(const hnsw_oracle *o, scratch *s, const float *query, uint32_t ep, uint32_t ef, uint32_t level,
+                             rheap *C, rheap *W, rheap *res)
+{
+    visited_reset(s, o->node_count);
+    visited_test_and_set(s, ep);
+    simpair qpair = { hnsw_oracle_euclidean(query, vec(o, ep), o->dim), ep };
+    C->n = W->n = res->n = 0; C->reverse = 0; W->reverse = 1; res->reverse = 0;
+    rh_push(C, qpair); rh_push(W, qpair);
+    while (C->n) {
+        simpair c = rh_pop(C);
+        simpair f = W->a[0];
+        if (c.sim < f.sim) break;                           /* :635 */
+        const nrow *nb = row_of(o, c.id, level);
+        for (uint32_t i = 0; i < nb->n; i++) {
+            uint32_t e = nb->ids[i];
+            if (visited_test_and_set(s, e)) continue;
+            f = W->a[0];
+            simpair e2 = { hnsw_oracle_euclidean(query, vec(o, e), o->dim), e };
+            if (e2.sim > f.sim || W->n < ef) {              /* :657 */
+                rh_push(C, e2); rh_push(W, e2);
+                if (W->n > ef) rh_pop(W);
+            }
+        }
+    }
+    for (uint32_t i = 0; i < W->n; i++) rh_push(res, W->a[i]);   /* :670-674: into_vec order, pushed one by one */
+}
+uint32_t hnsw_oracle_search_std_heap(const hnsw_oracle *o, const float *q, uint32_t k, uint32_t *ids, float *sims)
+{
+    if (o->enterpoint < 0 || o->node_count - o->n_dead == 0) return 0;
+    scratch *s = (scratch *)&o->sc;
+    rheap C = {0}, W = {0}, res = {0};
+    uint32_t ep = (uint32_t)o->enterpoint, lc = o->max_layer;
+    while (lc > 0) {                                        /* :869-874 */
+        search_level_std(o, s, q, ep, 1, lc, &C, &W, &res);
+        ep = res.a[0].id;                                   /* :872 peek */
+        lc--;
+    }
+    search_level_std(o, s, q, ep, o->ef_construction, 0, &C, &W, &res);   /* :876 */
+    uint32_t n = 0;
+    while (n < k && res.n) { simpair p = rh_pop(&res); ids[n] = p.id; sims[n] = p.sim; n++; }   /* :878-890 */
+    free(C.a); free(W.a); free(res.a);
     return n;
 }
 

@@ -89,6 +89,17 @@ void hnsw_oracle_search_batch(const hnsw_oracle *o, const float *Q, uint32_t B,
                               uint32_t *n_out, uint32_t threads,
                               hnsw_oracle_counters *ctrs);
 
+/* Tie census of B searches (one thread): how many decisions of search_level met EQUAL similarities of two
+ * different nodes -- the only places where the reference's sim-only order (core.rs:292-300, :635, :657) and the
+ * oracle's (sim, id) order can part.  out[0] queries, [1] stop-test ties, [2] accept-test ties (W full),
+ * [3] queries with either, [4] queries whose k + 1 nearest hold equal sims, [5] queries with any of these.      */
+void hnsw_oracle_tie_census(const hnsw_oracle *o, const float *Q, uint32_t B, uint32_t k, uint64_t out[6]);
+
+/* HNSW.SEARCH in the Rust binary's own tie order: the reference's sim-only comparisons (core.rs:635, :657) on
+ * std::collections::BinaryHeap restated (sift_up / sift_down_to_bottom); what hnsw_oracle_search answers whenever
+ * no decision ties (hnsw_oracle_tie_census), and what the reference's binary answers when one does.              */
+uint32_t hnsw_oracle_search_std_heap(const hnsw_oracle *o, const float *q, uint32_t k, uint32_t *ids, float *sims);
+
 /* core.rs:414-475 + 824-863 (HNSW.NODE.DEL).  Ids are never reused; node_count() keeps counting
  * allocated ids, live_count() is the reference's node_count.  The new enterpoint, which the
  * reference picks arbitrarily from the highest non-empty layer (HashSet order, core.rs:453), is the

@@ -78,6 +78,10 @@ def lib():
     L.hnsw_oracle_import.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, fp, u32p,
                                      C.c_int64, C.c_uint32, C.POINTER(u64p), C.POINTER(u32p)]
     L.hnsw_oracle_set_strict_ties.argtypes = [C.c_int]
+    L.hnsw_oracle_tie_census.argtypes = [C.c_void_p, fp, C.c_uint32, C.c_uint32, u64p]
+    L.hnsw_oracle_tie_census.restype = None
+    L.hnsw_oracle_search_std_heap.argtypes = [C.c_void_p, fp, C.c_uint32, u32p, fp]
+    L.hnsw_oracle_search_std_heap.restype = C.c_uint32
     _lib = L
     return L
 
@@ -201,6 +205,24 @@ class OracleIndex:
         lib().hnsw_oracle_search_batch(self._h, _fp(Q), B, k, _u32p(ids), _fp(sims), _u32p(n_out),
                                        threads, C.byref(ct))
         return ids, sims, n_out, ct
+
+    def search_std_heap(self, q, k):
+        """HNSW.SEARCH in the Rust binary's own tie order (sim-only comparisons on std's BinaryHeap, restated)"""
+        q = _f32(q)
+        ids = np.empty(k, dtype=np.uint32)
+        sims = np.empty(k, dtype=np.float32)
+        n = lib().hnsw_oracle_search_std_heap(self._h, _fp(q), k, _u32p(ids), _fp(sims))
+        return ids[:n].copy(), sims[:n].copy()
+
+    def tie_census(self, Q, k):
+        """decisions of B searches that met EQUAL similarities of two different nodes (core.rs:635, :657, and the
+        k + 1 nearest of the answer): the only places where the reference's sim-only order and the (sim, id) order of
+        oracle and engine can part.  dict of counts; one thread."""
+        Q = _f32(Q)
+        out = np.zeros(6, dtype=np.uint64)
+        lib().hnsw_oracle_tie_census(self._h, _fp(Q), Q.shape[0], k, out.ctypes.data_as(C.POINTER(C.c_uint64)))
+        return dict(queries=int(out[0]), stop_test_ties=int(out[1]), accept_test_ties=int(out[2]),
+                    queries_with_decision_tie=int(out[3]), queries_with_answer_tie=int(out[4]), queries_with_any_tie=int(out[5]))
 
     # -- introspection ---------------------------------------------------------
     @property

@@ -35,44 +35,91 @@ __global__ __launch_bounds__(256) void k_gather(const float4 *__restrict__ vec, 
 }
 
 template <int T>
-void run(size_t rows, int blocks, int threads)
+void run(const char *tag, size_t rows, int blocks, int threads)
 {
     const size_t row_f4 = T * 8, n_ids = 1u << 24;
     float4 *vec;
     uint32_t *ids;
     float *out;
-    hipMalloc(&vec, rows * row_f4 * sizeof(float4));
+    if (hipMalloc(&vec, rows * row_f4 * sizeof(float4)) != hipSuccess) { printf("# %s: allocation failed\n", tag); return; }
     hipMemset(vec, 0, rows * row_f4 * sizeof(float4));
     hipMalloc(&ids, n_ids * 4);
     hipMalloc(&out, 4);
     std::vector<uint32_t> h(n_ids);
-    std::mt19937 rng(1);
-    for (auto &x : h) x = rng() % rows;
+    std::mt19937_64 rng(1);
+    for (auto &x : h) x = (uint32_t)(rng() % rows);
     hipMemcpy(ids, h.data(), n_ids * 4, hipMemcpyHostToDevice);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     hipLaunchKernelGGL(k_gather<T>, dim3(blocks), dim3(threads), 0, 0, vec, ids, (uint32_t)n_ids, out);
-    hipEventRecord(e0);
-    hipLaunchKernelGGL(k_gather<T>, dim3(blocks), dim3(threads), 0, 0, vec, ids, (uint32_t)n_ids, out);
-    hipEventRecord(e1);
-    hipEventSynchronize(e1);
-    float ms;
-    hipEventElapsedTime(&ms, e0, e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_gather<T>, dim3(blocks), dim3(threads), 0, 0, vec, ids, (uint32_t)n_ids, out);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
     const double bytes = (double)n_ids * T * 128;
-    printf("row %4d B, %7zu rows (%5.0f MB), %4d blocks x %3d threads: %6.2f TB/s\n", T * 128, rows,
-           rows * row_f4 * 16 / 1e6, blocks, threads, bytes / (ms * 1e-3) / 1e12);
+    printf("gather row_bytes=%d rows=%zu array_mb=%.0f waves_per_simd=%d tbs=%.3f   # %s\n", T * 128, rows,
+           rows * row_f4 * 16 / 1e6, blocks * threads / 64 / 1024, bytes / (best * 1e-3) / 1e12, tag);
+    fflush(stdout);
     hipFree(vec); hipFree(ids); hipFree(out);
+}
+
+// the guide's "what a streaming read sustains": every wave reads contiguous 1 KB pieces of a large array, read-only
+__global__ __launch_bounds__(256) void k_stream(const float4 *__restrict__ vec, size_t n_f4, float *__restrict__ out)
+{
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_f4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = vec[i];
+        acc += v.x + v.y + v.z + v.w;
+    }
+    if (acc == 12345.678f) out[0] = acc;
+}
+void run_stream(size_t bytes)
+{
+    float4 *vec;
+    float *out;
+    if (hipMalloc(&vec, bytes) != hipSuccess) return;
+    hipMemset(vec, 0, bytes);
+    hipMalloc(&out, 4);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_stream, dim3(256 * 8), dim3(256), 0, 0, vec, bytes / 16, out);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_stream, dim3(256 * 8), dim3(256), 0, 0, vec, bytes / 16, out);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    printf("stream_read array_mb=%.0f tbs=%.3f\n", bytes / 1e6, (double)bytes / (best * 1e-3) / 1e12);
+    fflush(stdout);
+    hipFree(vec); hipFree(out);
 }
 
 int main()
 {
-    // the search kernel's residency: 1024 waves (one per SIMD); then 2, 4 and 8 per SIMD
-    for (int wps : {1, 2, 4, 8}) {
-        run<4>(1000000, 256 * wps, 256);      // C2: 1 M x 512 B
-    }
-    run<4>(10000000, 256 * 8, 256);           // C4: 10 M x 512 B
-    run<24>(1000000, 256 * 2, 256);           // C3: 1 M x 3 KB
-    run<24>(1000000, 256 * 4, 256);
+    printf("# scripts/microbench/gather_bw.hip: read-only random gathers of whole rows (8 lanes x 16 B per 128-byte block, 32 rows\n"
+           "# in flight per wave, as the search kernel's distance rounds read them), 2^24 rows per launch, best of 3 launches;\n"
+           "# tbs = row bytes x rows / time.  The Infinity Cache is 256 MB: arrays far larger than it are served by HBM.\n");
+    run_stream((size_t)8 << 30);
+    // 512-byte rows (dim 128): the search kernel's residency is 1 wave per SIMD for a lone launch, 2 with launches overlapped
+    for (int wps : {1, 2, 4, 8}) run<4>("8 GB, far beyond the cache", (size_t)16 << 20, 256 * wps, 256);
+    for (int wps : {2, 8}) run<4>("256 MB: fits the Infinity Cache", (size_t)500000, 256 * wps, 256);
+    for (int wps : {1, 2, 8}) run<4>("C2's matrix: 1 M x 512 B", (size_t)1000000, 256 * wps, 256);
+    for (int wps : {2, 8}) run<4>("C4's matrix: 10 M x 512 B", (size_t)10000000, 256 * wps, 256);
+    // 3072-byte rows (dim 768)
+    for (int wps : {1, 2, 4}) run<24>("8 GB, far beyond the cache", (size_t)2796202, 256 * wps, 256);
+    for (int wps : {2, 4}) run<24>("256 MB: fits the Infinity Cache", (size_t)83333, 256 * wps, 256);
+    for (int wps : {1, 2, 4}) run<24>("C3's matrix: 1 M x 3072 B", (size_t)1000000, 256 * wps, 256);
     return 0;
 }

@@ -56,20 +56,31 @@ def dispatches(db, sub):
             r[0].split("(")[0].replace("void ", "")[:60], r[1], r[2], r[3], r[4], r[5], r[6]))
 
 
-def traffic(fetch_db, write_db, sub, commit, args):
-    """JSON entry for profiles/traffic.json: HBM bytes per launch of the most frequent k_search launch shape
-    (FETCH_SIZE is KiB and reports half of a wide coalesced read on gfx950: x2, see MI355X_MICROARCH.md)"""
+def timed_rows(rows, batch):
+    """the dispatch groups with the timed step's launch shape (bench.py: timed_launch_rows): one workgroup of 64
+    threads per query, or the general kernel's grid-stride form (<= 2048 workgroups); never the two-wave kernel,
+    never the 1024-query chunks of a host batch.  Most dispatches first."""
+    want = {64 * batch, 64 * min(batch, 2048)}
+    hit = [r for r in rows if int(r[2]) in want and "duo" not in r[0]]
+    return sorted(hit, key=lambda r: -r[3])
+
+
+def traffic(fetch_db, write_db, sub, commit, args, batch):
+    """JSON entry for profiles/traffic.json: HBM bytes per launch of the k_search dispatch group whose grid is the
+    TIMED step's (batch queries per launch) -- not the most frequent group: with --batch 4096 the 1024-query chunks of
+    the host-buffer leg outnumber the timed launches.  FETCH_SIZE is KiB and reports half of a wide coalesced read on
+    gfx950: x2, see MI355X_MICROARCH.md."""
     import json
 
     def top(db, counter):
         cur = sqlite3.connect(db).cursor()
         q = ("select kernel_name, lds_block_size, grid_size, count(*), avg(value) from counters_collection "
-             "where kernel_name like ? and counter_name = ? group by kernel_name, lds_block_size, grid_size order by count(*) desc")
-        rows = list(cur.execute(q, ("%" + sub + "%", counter)))
+             "where kernel_name like ? and counter_name = ? group by kernel_name, lds_block_size, grid_size")
+        rows = timed_rows(list(cur.execute(q, ("%" + sub + "%", counter))), batch)
         return rows[0] if rows else None
     f, w = top(fetch_db, "FETCH_SIZE"), top(write_db, "WRITE_SIZE")
-    out = dict(commit=commit, bench_args=args, kernel=f[0].split("(")[0].replace("void ", "") if f else None,
-               lds_bytes=f[1] if f else None, launches_sampled=f[3] if f else 0,
+    out = dict(commit=commit, bench_args=args, batch=batch, kernel=f[0].split("(")[0].replace("void ", "") if f else None,
+               lds_bytes=f[1] if f else None, grid=f[2] if f else None, launches_sampled=f[3] if f else 0,
                fetch_size_kib_per_launch=f[4] if f else None, write_size_kib_per_launch=w[4] if w else None,
                fetch_correction=2.0)
     if f and w:
@@ -83,6 +94,6 @@ if __name__ == "__main__":
     elif sys.argv[1] == "dispatches":
         dispatches(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "traffic":
-        traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6])
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6], int(sys.argv[7]))
     else:
         pmc(sys.argv[2], sys.argv[3])

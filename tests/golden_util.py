@@ -9,7 +9,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def golden_cases():
     """goldens written by the C oracle itself (make_golden.py): they pin stability"""
     return sorted(n for n in (os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-                  if not n.startswith("transcribed_"))
+                  if not n.startswith(("transcribed_", "tiecase_")))
 
 
 def transcribed_cases(kind="exact"):
@@ -62,3 +62,19 @@ def load_golden(name):
                 search_counters=z["search_counters"], insert_counters=z["insert_counters"],
                 n_first=int(z["n_first"]) if "n_first" in z else n,
                 deleted=z["deleted"] if "deleted" in z else np.zeros(0, dtype=np.int64))
+
+
+def load_tiecase(name="tiecase_rust_lattice"):
+    """tests/transcription/make_rust_tie_golden.py: a graph built AND searched by the transcription in its "rust" tie
+    mode (std's BinaryHeap restated) on distinct points of the lattice {0,1,2}^8 -- equal similarities everywhere"""
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    n, dim, m, ef, k, nq = [int(x) for x in z["params"]]
+
+    def lattice(cnt, seed):
+        codes = np.random.default_rng(seed).choice(3 ** dim, size=cnt, replace=False)
+        return np.stack([(codes // 3 ** j) % 3 for j in range(dim)], axis=1).astype(np.float32)
+    L = int(z["max_layer"]) + 1
+    g = dict(levels=z["levels"].astype(np.uint32), enterpoint=int(z["enterpoint"]), max_layer=int(z["max_layer"]),
+             row_ptr=[z["row_ptr_%d" % l] for l in range(L)], col=[z["col_%d" % l] for l in range(L)], vectors=lattice(n, 1))
+    return dict(n=n, dim=dim, m=m, ef=ef, k=k, Q=lattice(nq, 2), graph=g, ids=z["ids"], sim_bits=z["sim_bits"], n_out=z["n_out"],
+                accept_ties=int(z["accept_ties"]))

@@ -22,6 +22,29 @@ def test_occ_model_reproduces_the_serial_graph(tmp_path):
         assert m and float(m.group(1)) >= 1.0
 
 
+def test_parallel_validated_commits_reproduce_the_serial_graph(tmp_path):
+    """PAR=1: the commits of a round are applied in validated GROUPS instead of one by one -- every
+    window node runs its whole commit against the graph as it stands (a dry run in a private overlay of the rows it
+    rewrites), and node j joins the group of the nodes before it iff none of their deltas is relevant to anything j
+    read (link plan, the speculative records it used, the select_neighbors it recomputed) and none is on a row j
+    changed.  The model's graph must stay the serial oracle's; without the changed-row rule (PAR_NOROWCHECK, unsound on
+    purpose) it must not."""
+    exe = str(tmp_path / "occ_model")
+    src = os.path.join(ROOT, "tests", "experiments", "occ_model.c")
+    subprocess.check_call(["gcc", "-O2", "-mavx2", "-mfma", "-ffp-contract=off", "-w", "-o", exe, src, "-lm", "-lpthread"])
+    env = dict(os.environ, PAR="1")
+    for args in (["1500", "160", "16", "32", "6", "40"], ["800", "128", "32", "16", "4", "24"], ["3000", "400", "32", "16", "8", "32"],
+                 ["2000", "300", "24", "8", "5", "24"]):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "graphs IDENTICAL" in r.stdout
+        m = re.search(r"([0-9.]+) nodes per group", r.stdout)
+        assert m and float(m.group(1)) > 1.0               # groups do form
+    r = subprocess.run([exe, "2000", "300", "24", "8", "5", "24"], capture_output=True, text=True, timeout=600,
+                       env=dict(env, PAR_NOROWCHECK="1"))
+    assert r.returncode != 0 and "graphs IDENTICAL" not in r.stdout
+
+
 def test_select_after_search_is_the_head_of_W(tmp_path):
     """tests/experiments/select_head.c: the reference's insert() with the full select_neighbors never returns
     anything but the m nearest of W (what the engine's plan kernels use instead of the extension)."""
