@@ -25,6 +25,7 @@ UNITS = [
     ("hnsw_tu_insert.hip", [0, 1, 2, 3], []),
     ("hnsw_tu_occ.hip", [0, 1, 2, 3], []),
     ("hnsw_tu_occteam.hip", [0, 1, 2, 3], []),
+    ("hnsw_tu_occpar.hip", [0, 1, 2, 3], ["hnsw_occ_par.hpp"]),
     ("hnsw_tu_planlean.hip", [0, 1], ["hnsw_plan_lean.hpp", "hnsw_search_lean.hpp", "hnsw_search_duo.hpp"]),
     ("hnsw_tu_planduo.hip", [0, 1], ["hnsw_plan_lean.hpp", "hnsw_search_lean.hpp", "hnsw_search_duo.hpp"]),
     ("hnsw_group.hip", [None], []),                   # one process, several GPUs: host code above the C ABI

@@ -73,6 +73,14 @@ __device__ __forceinline__ uint32_t *row_ptr(const GraphView &g, uint32_t id, ui
     return g.adjU + (size_t)(g.upper_base[id] + lc - 1) * g.strideU;
 }
 
+// a row about to be EDITED (wave-uniform id; every lane calls).  For the graph itself that is the row; a private
+// overlay of the graph (hnsw_occ_par.hpp: OverlayView) copies the row on first touch and hands out the copy.
+__device__ __forceinline__ uint32_t *row_mut(const GraphView &g, uint32_t id, uint32_t lc, int lane)
+{
+    (void)lane;
+    return row_ptr(g, id, lc);
+}
+
 // ---------------------------------------------------------------------------
 // keys: (squared distance bits << 32) | (id << 1) | expanded.  Squared
 // distances are >= +0 so their IEEE bits order like unsigned ints; smaller key

@@ -649,6 +649,7 @@ void hnsw_destroy(hnsw_index *h)
     if (h->pipe_fork) (void)hipEventDestroy(h->pipe_fork);
     (void)hipFree(h->d_plan); (void)hipFree(h->d_touched); (void)hipFree(h->d_work);
     (void)hipFree(h->d_occ_slots); (void)hipFree(h->d_occ_reads); (void)hipFree(h->d_occ_shr); (void)hipFree(h->d_occ_ring); (void)hipFree(h->d_occ_ctl);
+    (void)hipFree(h->d_par); (void)hipFree(h->d_par_delta); (void)hipFree(h->d_par_rows);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_sync) (void)hipEventDestroy(h->ev_sync);
@@ -724,6 +725,7 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
     if (!std::strcmp(key, "lean")) { h->lean = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "duo")) { h->duo = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "plan_duo")) { h->plan_duo = value != 0; return HNSW_OK; }
+    if (!std::strcmp(key, "commit_par")) { h->commit_par = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "commit_team")) { h->commit_team = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return HNSW_OK; }
     if (!std::strcmp(key, "plan_duo_max")) { h->plan_duo_max = (uint32_t)std::max<int64_t>(value, 0); return HNSW_OK; }
     if (!std::strcmp(key, "duo_max")) { h->duo_max = (uint32_t)std::max<int64_t>(value, 0); return HNSW_OK; }
@@ -1036,6 +1038,16 @@ hnsw_status hnsw_debug_occ_ctl(hnsw_index *h, uint64_t *out18)
     HIP_TRY(h, hipMemcpy(&c, h->d_occ_ctl, sizeof(OccCtl), hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; ++i) { out18[i] = c.prof[i]; out18[8 + i] = c.n_cls[i]; }
     out18[16] = c.n_spec; out18[17] = c.n_fallback;
+    return HNSW_OK;
+}
+
+// the parallel group commit of the last windowed build (hnsw_occ_par.hpp; development aid, not in the public header):
+// [0] groups committed, [1] dry runs made, groups closed by [2] a stale link plan, [3] a record the node used, [4] a row it rewrote
+hnsw_status hnsw_debug_occ_par(hnsw_index *h, uint64_t *out5)
+{
+    if (!h || !out5) return HNSW_ERR_INVALID;
+    out5[0] = h->occ_last.n_groups; out5[1] = h->occ_last.n_dry; out5[2] = h->occ_last.n_conf_link;
+    out5[3] = h->occ_last.n_conf_rec; out5[4] = h->occ_last.n_conf_row;
     return HNSW_OK;
 }
 

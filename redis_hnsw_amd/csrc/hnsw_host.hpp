@@ -95,6 +95,11 @@ struct hnsw_index {
     hnsw::OccShr *d_occ_shr = nullptr;
     hnsw::OccDelta *d_occ_ring = nullptr;
     hnsw::OccCtl *d_occ_ctl = nullptr;
+    // ... its commits in validated parallel groups (hnsw_occ_par.hpp): per-workgroup state, deltas and scratch rows
+    void *d_par = nullptr, *d_par_delta = nullptr;
+    uint32_t *d_par_rows = nullptr;
+    uint32_t par_ovstride = 0;
+    bool commit_par = true;         // tuning: a window's commits go in parallel groups (0 = the in-order commit wave only)
     bool occ_fresh_slots = false;   // the round about to be launched starts from cleared slots (single hnsw_add)
     bool occ_want_touched = false;  // the commit kernel records the update_fn list (a single hnsw_add through a one-node window)
     bool single_window = true;      // tuning: a single hnsw_add runs as a one-node window (speculative shrinks in parallel) instead of the serial kernels
@@ -270,6 +275,10 @@ template <int MODE, int T>
 hnsw_status occ_commit_team_r(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t end_node, bool *done);
 template <int MODE, int T>
 hnsw_status occ_del_commit_team_r(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t id, bool *done);
+// hnsw_tu_occpar.hip: the round's commits in validated parallel groups, one workgroup per window node (*done stays false
+// when the kernel cannot serve the round: the caller launches the in-order commit)
+template <int MODE, int T>
+hnsw_status occ_commit_par_r(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t count, uint32_t end_node, bool *done);
 // hnsw_tu_planduo.hip: the same plans with a second wavefront keeping W for their layer searches
 template <bool WIDE>
 hnsw_status launch_plan_duo_v(hnsw_index *h, const InsertCfg &c, uint32_t first, uint32_t count, uint32_t idbits);

@@ -36,8 +36,10 @@ __device__ __forceinline__ uint32_t merge_S(uint64_t *S, uint32_t nS, uint32_t m
     return mcap > 64 ? merge_sorted<2>(S, nS, mcap, key, take, lane) : merge_sorted<1>(S, nS, mcap, key, take, lane);
 }
 
-template <int MODE, int T>
-__device__ __forceinline__ uint32_t select_topm(const GraphView &g, const WaveMem &m, Visited &vis, const QReg<T> &qr,
+// GV: the graph (GraphView) or a private overlay of it (OverlayView, hnsw_occ_par.hpp): rows are reached through
+// row_ptr(g, ...) / row_mut(g, ...), everything else is the graph's
+template <int MODE, int T, class GV>
+__device__ __forceinline__ uint32_t select_topm(const GV &g, const WaveMem &m, Visited &vis, const QReg<T> &qr,
                                 const uint64_t *cand, uint32_t ncand, uint32_t qid, uint32_t mcap,
                                 uint32_t lc, WorkCtr &ctr, int lane, bool &fail, uint32_t ignored = kEmpty)
 {
@@ -331,6 +333,8 @@ struct OccJournal {
     uint32_t n;                                      // the committing wave's copy of the counter (wave-uniform)
     OccDelta *own;                                   // optional LDS mirror of the entries from own_base on
     uint32_t own_base;
+    uint32_t cap;                                    // 0: `ring` is the journal ring; else a private linear buffer of `cap` entries
+                                                     // (a dry run's deltas, hnsw_occ_par.hpp): entries beyond it are counted, not written
 };
 // lanes flagged `on` each append one delta (wave-uniform call)
 __device__ __forceinline__ void journal_push(OccJournal *jr, bool on, uint32_t row, uint32_t lc, uint32_t z, bool add, int lane)
@@ -341,14 +345,15 @@ __device__ __forceinline__ void journal_push(OccJournal *jr, bool on, uint32_t r
     if (on) {
         const uint32_t p = (jr->n + (uint32_t)__popcll(b & lanemask_lt(lane))) & ((1u << kOccJournalBits) - 1u);
         const OccDelta d = OccDelta{row, lc | (add ? 256u : 0u), z};
-        jr->ring[p] = d;
+        if (!jr->cap || p < jr->cap) jr->ring[p] = d;
         const uint32_t o = jr->n + (uint32_t)__popcll(b & lanemask_lt(lane)) - jr->own_base;
         if (jr->own && o < 256u) jr->own[o] = d;
     }
     jr->n += (uint32_t)__popcll(b);
 }
 
-__device__ __forceinline__ void update_connections(const GraphView &g, const WaveMem &m, uint32_t e, uint32_t *erow, uint32_t cnt,
+template <class GV>
+__device__ __forceinline__ void update_connections(const GV &g, const WaveMem &m, uint32_t e, uint32_t *erow, uint32_t cnt,
                                    uint32_t nS, uint32_t lc, uint32_t stride, uint32_t *maxdeg, uint32_t ignored,
                                    uint32_t *touched, uint32_t touched_cap, uint32_t &nt, int lane,
                                    OccJournal *jr = nullptr)
@@ -371,7 +376,7 @@ __device__ __forceinline__ void update_connections(const GraphView &g, const Wav
             const int j = __ffsll((unsigned long long)dm) - 1;
             dm &= dm - 1;
             const uint32_t xj = (uint32_t)__builtin_amdgcn_readlane((int)x, j);
-            uint32_t *xrow = row_ptr(g, xj, lc);
+            uint32_t *xrow = row_mut(g, xj, lc, lane);
             // the first 64 words in one load (lane 0 = the count): rows of <= 63 ids need nothing else, one round
             // trip instead of two
             const uint32_t wx = (uint32_t)lane < stride ? xrow[lane] : kEmpty;
@@ -426,7 +431,7 @@ __device__ __forceinline__ void update_connections(const GraphView &g, const Wav
             const int j = __ffsll((unsigned long long)am) - 1;
             am &= am - 1;
             const uint32_t xj = (uint32_t)__builtin_amdgcn_readlane((int)x, j);
-            uint32_t *xrow = row_ptr(g, xj, lc);
+            uint32_t *xrow = row_mut(g, xj, lc, lane);
             const uint32_t wx = (uint32_t)lane < stride ? xrow[lane] : kEmpty;
             uint32_t xc1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wx);
             if (xc1 > stride - 1) xc1 = stride - 1;

@@ -54,6 +54,9 @@ struct OccCtl {
     unsigned long long n_commit, n_spec, n_fallback, n_stale, n_norec, n_rowstale;
     unsigned long long n_cls[8];            // recomputed shrinks by cause: no record, row changed, pool not full, a relevant removal, relevant additions only
     unsigned long long prof[8];             // commit kernel, shader clocks: hash, first check, connect, shrink checks, apply, recompute, finish, total
+    // parallel validated commits (hnsw_occ_par.hpp)
+    uint32_t bar, bar_start;                // grid barrier of k_occ_commit_par: arrivals ever / the count the next launch starts from
+    unsigned long long n_groups, n_dry, n_conf_link, n_conf_rec, n_conf_row;   // groups committed, dry runs made, groups closed by: a stale link plan / a record used / a changed row
 };
 
 struct OccBufs {
@@ -136,9 +139,13 @@ __device__ __forceinline__ void occ_build_hash(const OccScratch &sc, const OccRe
 template <int MODE, int T>
 __device__ __forceinline__ void occ_check_range(const GraphView &g, const WaveMem &m, const OccScratch &sc, const OccBufs &ob,
                                                 const OccRead *reads, const OccShr *shr, uint32_t q, uint32_t from,
-                                                uint32_t to, int lane, bool shrinks_only = false, uint32_t own_base = kEmpty)
+                                                uint32_t to, int lane, bool shrinks_only = false, uint32_t own_base = kEmpty,
+                                                const OccDelta *src = nullptr)
 {
+    // src: the deltas come from this linear buffer (another node's dry run, hnsw_occ_par.hpp) instead of the journal ring
     (void)reads;
+    const OccDelta *jsrc = src ? src : ob.ring;
+    const uint32_t jmask = src ? 0xFFFFFFFFu : (1u << kOccJournalBits) - 1u;
     if (to - from > (1u << kOccJournalBits) - 4096u) {      // the ring has wrapped past this plan: stale
         if (lane == 0) sc.flags[0] = 1;
         __syncthreads();
@@ -149,8 +156,7 @@ __device__ __forceinline__ void occ_check_range(const GraphView &g, const WaveMe
         const uint32_t j = base + lane;
         if (j < to) {
             // the committing node's own entries are mirrored in LDS (own_base = journal index of own[0])
-            const OccDelta d = (j >= own_base && j - own_base < kOccOwn) ? sc.own[j - own_base]
-                                                                         : ob.ring[j & ((1u << kOccJournalBits) - 1u)];
+            const OccDelta d = (j >= own_base && j - own_base < kOccOwn) ? sc.own[j - own_base] : jsrc[j & jmask];
             const uint32_t key = (d.row << 5) | (d.lc_add & 31u);
             const bool add = (d.lc_add & 256u) != 0;
             uint32_t h = occ_hash(key);
@@ -666,6 +672,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit(GraphView g, Oc
     jr.n = ob.ctl->nJ;
     jr.own = nullptr;
     jr.own_base = 0;
+    jr.cap = 0;
     occ_init_hash(sc, lane);
     uint32_t head = ob.ctl->head;
     uint32_t stop = OCC_STOP_NONE;
@@ -947,6 +954,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_del_commit(GraphView g
     OccJournal jr;
     jr.ring = ob.ring;
     jr.n = ob.ctl->nJ;
+    jr.cap = 0;
     occ_init_hash(sc, lane);
     occ_build_hash(sc, reads, sl->n_reads, shr, n_shr, lane);
     jr.own = sc.own;                                            // the delete's deltas are mirrored in LDS
@@ -1079,5 +1087,27 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_del_commit(GraphView g
         sl->planned = 0;
     }
 }
+
+// ---- sizes and records of the parallel group commit (kernels: hnsw_occ_par.hpp) ----------------------------------
+constexpr uint32_t kParTab = 512;         // overlay table slots = scratch rows of a workgroup
+constexpr uint32_t kParMaxRows = 400;     // rows a dry run may rewrite
+constexpr uint32_t kParMaxDelta = 1024;   // deltas it may journal
+constexpr uint32_t kParSubRows = 63;      // the read log's sub-operation that stands for "a row this dry run rewrote"
+constexpr uint32_t kParMaxSub = 63;       // speculative records use 0 .. n_shr-1 (<= kOccInsShr), recomputations the ones up to 62
+enum { PAR_NONE = 0, PAR_READY = 1, PAR_REPLAN = 2, PAR_SERIAL = 3, PAR_RESTRIDE = 4 };
+constexpr size_t kParLdsBytes = (size_t)kParTab * 4 + 64;
+
+struct OccPar {                           // what a workgroup publishes about its node, per iteration
+    uint32_t state, conflict, promotes, n_delta;
+    uint32_t n_spec, n_fallback, n_norec, maxdeg0, maxdegU, why, pad0, pad1;
+    unsigned long long w_dist, w_ids, w_skipped;
+};
+struct ParBufs {
+    OccPar *par;                          // [workgroups]
+    OccDelta *delta;                      // [workgroups][kParMaxDelta]
+    uint32_t *rows;                       // [workgroups][kParTab + 1][ovstride]
+    uint32_t ovstride;                    // words per scratch row = max(stride0, strideU)
+};
+
 
 } // namespace hnsw

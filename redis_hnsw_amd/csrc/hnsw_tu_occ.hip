@@ -41,7 +41,13 @@ static hnsw_status occ_round_t(hnsw_index *h, const InsertCfg &c, const OccBufs 
     hipLaunchKernelGGL(ks, dim3(count * kOccInsShr), dim3(64), c.lds, h->stream, gv, ob, head, count, h->m, c.lnb, c.lcap, h->d_spill,
                        h->spill_gnb, kEmpty, kOccInsShr);
     bool team = false;
-    if (h->commit_team) {
+    if (h->commit_par && count > 1 && !h->occ_want_touched) {
+        // the window's commits in validated parallel groups, one workgroup per window node (hnsw_occ_par.hpp)
+        HIP_TRY(h, hipGetLastError());
+        hnsw_status ps = occ_commit_par_r<MODE, T>(h, c, ob, count, end_node, &team);
+        if (ps != HNSW_OK) return ps;
+    }
+    if (!team && h->commit_team) {
         HIP_TRY(h, hipGetLastError());
         hnsw_status ts = occ_commit_team_r<MODE, T>(h, c, ob, end_node, &team);
         if (ts != HNSW_OK) return ts;

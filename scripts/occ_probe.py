@@ -16,6 +16,7 @@ lv = oracle.draw_levels(N, M, 7)
 gi = Index("occ", dim, M, ef)
 gi.set_tuning("occ_window", W)
 if os.environ.get("PLAN_LEAN"): gi.set_tuning("plan_lean", int(os.environ["PLAN_LEAN"]))
+if os.environ.get("COMMIT_PAR"): gi.set_tuning("commit_par", int(os.environ["COMMIT_PAR"]))
 if os.environ.get("OCC_AHEAD"): gi.set_tuning("occ_ahead_x10", int(os.environ["OCC_AHEAD"]))
 t = time.time(); gi.add_batch(V, levels=lv, mode="exact"); dt = time.time() - t
 lib = _capi.load()
@@ -33,6 +34,18 @@ try:
     lib.hnsw_debug_occ_causes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.hnsw_debug_occ_causes(gi._h, cz)
     print("recomputed shrinks by first cause: no record %d, own row changed %d, pool not full %d, a relevant removal %d, a relevant addition %d" % tuple(cz[:5]))
+except AttributeError:
+    pass
+try:
+    pz = (C.c_uint64 * 5)()
+    lib.hnsw_debug_occ_par.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.hnsw_debug_occ_par(gi._h, pz)
+    if pz[0]:
+        it = max(out[6 + 6], 1)
+        print("group commit kernel, us per iteration (workgroup 0): dry run %.1f, wait %.1f, validate %.1f, wait %.1f, apply %.1f, wait %.1f; %d iterations (%.2f per round), %d of them without a group" % (
+            tuple(out[6 + i] / it / 100.0 for i in range(6)) + (it, it / max(out[5], 1), out[6 + 7])))
+        print("parallel group commits: %d groups (%.2f per round, %.2f nodes per group), %d dry runs (%.2f per commit); groups closed by a stale link plan %d, "
+              "a record used %d, a row rewritten %d" % (pz[0], pz[0] / max(out[5], 1), out[0] / pz[0], pz[1], pz[1] / nc, pz[2], pz[3], pz[4]))
 except AttributeError:
     pass
 if check:

@@ -403,7 +403,19 @@ static int par_conflict(hnsw_oracle *o, uint32_t qj, txn *tj, const dry *dj, con
     if (!g_par_norowcheck)
         for (uint32_t a = 0; a < di->nd; a++)
             for (uint32_t i = 0; i < dj->nimg; i++)
-                if (dj->img[i].modified && dj->img[i].row == di->d[a].row && dj->img[i].lc == di->d[a].lc) { st_par_conf_row++; return 1; }
+                if (dj->img[i].modified && dj->img[i].row == di->d[a].row && dj->img[i].lc == di->d[a].lc) {
+                    st_par_conf_row++;
+                    if (getenv("PAR_ROWSTATS")) {
+                        /* what did j do to that row?  appended itself only (a selected neighbour that needed no shrink) / more */
+                        const rowimg *im = &dj->img[i];
+                        int append_only = im->npost == im->npre + 1 && !memcmp(im->pre, im->post, im->npre * 4) && im->post[im->npre] == qj;
+                        int i_adds_only = 1; uint32_t i_n = 0;
+                        for (uint32_t b = 0; b < di->nd; b++) if (di->d[b].row == im->row && di->d[b].lc == im->lc) { i_n++; i_adds_only &= di->d[b].add; }
+                        uint32_t mm = im->lc == 0 ? o->m_max0 : o->m_max;
+                        fprintf(stderr, "rowconf lc=%u j_append_only=%d i_adds_only=%d i_n=%u npre=%u mmax=%u room=%d\n", im->lc, append_only, i_adds_only, i_n, im->npre, mm, (int)(im->npre + i_n + 1 <= mm));
+                    }
+                    return 1;
+                }
     return 0;
 }
 
