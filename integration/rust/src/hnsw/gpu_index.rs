@@ -79,6 +79,7 @@ pub struct GpuIndex {
     pos_nodes: Vec<u32>,
     pos_layer: Vec<u32>,
     pending: Vec<Change>,       // what the commands since the last sync_redis did
+    gone: HashMap<String, u32>, // names deleted since the last sync_redis (they have left `ids` but still sit in the stored value)
     // search_knn takes &self (core.rs:477) and the module lets readers in concurrently (try_read, src/lib.rs:474),
     // but one engine handle serves one caller at a time (staging buffers, stream, error string): readers queue here
     search_lock: Mutex<()>,
@@ -95,6 +96,12 @@ impl GpuIndex {
     fn last_error(&self) -> HNSWError {
         let p = unsafe { ffi::hnsw_last_error(self.h) };
         HNSWError::String(unsafe { CStr::from_ptr(p) }.to_string_lossy().into_owned())
+    }
+
+    /// id of a name that sits in the stored hnswindex value: a name whose removal is still queued first (it left `ids`
+    /// when the command ran; a node re-added under the same name enters the stored value only when ITS entry is applied)
+    fn stored_id(&self, name: &str) -> Option<&u32> {
+        self.gone.get(name).or_else(|| self.ids.get(name))
     }
 
     /// Index::new(name, mfunc, data_dim, m, ef_construction)  core.rs:322-347 (the metric is Euclidean, :332)
@@ -117,6 +124,7 @@ impl GpuIndex {
             pos_nodes: Vec::new(),
             pos_layer: Vec::new(),
             pending: Vec::new(),
+            gone: HashMap::new(),
             search_lock: Mutex::new(()),
         };
         if st != ffi::HNSW_OK {
@@ -193,15 +201,22 @@ impl GpuIndex {
                     // positions are only ever edited here, so they describe `ir` as it is now
                     let (p, l, q) = (self.pos_nodes[id] as usize, self.levels[id] as usize, self.pos_layer[id] as usize);
                     self.pos_nodes[id] = NOT_STORED;
-                    ir.nodes.swap_remove(p);
+                    let name = ir.nodes.swap_remove(p);
+                    if self.gone.get(&name) == Some(&(id as u32)) {
+                        self.gone.remove(&name);
+                    }
                     if p < ir.nodes.len() {
-                        let moved = self.ids[&ir.nodes[p]] as usize;
-                        self.pos_nodes[moved] = p as u32;
+                        // the element moved into the hole may itself be pending removal (its name has left `ids`
+                        // already, its own Removed entry comes later in this queue): stored_id still knows it
+                        if let Some(&moved) = self.stored_id(&ir.nodes[p]) {
+                            self.pos_nodes[moved as usize] = p as u32;
+                        }
                     }
                     ir.layers[l].swap_remove(q); // core.rs:426-430: the one set that holds it
                     if q < ir.layers[l].len() {
-                        let moved = self.ids[&ir.layers[l][q]] as usize;
-                        self.pos_layer[moved] = q as u32;
+                        if let Some(&moved) = self.stored_id(&ir.layers[l][q]) {
+                            self.pos_layer[moved as usize] = q as u32;
+                        }
                     }
                 }
             }
@@ -211,6 +226,7 @@ impl GpuIndex {
         // core.rs:453-466: empty top layers are popped when the enterpoint goes; with no node left there is no layer
         ir.layers.truncate(if self.ids.is_empty() { 0 } else { info.max_layer as usize + 1 });
         ir.enterpoint = self.enterpoint();
+        self.gone.clear();
     }
 
     /// add_node(&mut self, name, data, update_fn)  core.rs:383-412
@@ -264,6 +280,7 @@ impl GpuIndex {
             return Err(self.last_error());
         }
         self.ids.remove(name); // status OK = the node is gone from the graph (see add_node)
+        self.gone.insert(name.to_owned(), id);
         self.names[id as usize] = None;
         self.pending.push(Change::Removed(id));
         if nt as usize > touched.len() {

@@ -14,6 +14,7 @@
 // Everything is force-inlined into the kernels: a real call makes the compiler
 // spill the state structs to scratch and turn LDS accesses into flat ones.
 #pragma once
+#include "hnsw_wave_sync.hpp"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -43,6 +44,29 @@ struct DevHeader {
     unsigned long long ctr_insert[4];
     unsigned long long prof[8];       // HNSW_PHASE_TIMERS builds: cycles per phase
 };
+
+// The synchronisation point of the code in this file -- lanes of ONE wavefront handing each other data.  The file is
+// compiled into two kinds of translation units, and each unit says which it is before it includes anything:
+//   HNSW_SYNC_WAVE_FULL  the insert / delete units (hnsw_tu_insert, _occ, _occteam, _occpar, _planlean, _planduo): the
+//                        code is run by one wavefront per copy and hands over through HBM as well as LDS (read-log
+//                        entries, rows) -> wave_sync() of hnsw_wave_sync.hpp: vmcnt(0) + lgkmcnt(0) + wave barrier;
+//   HNSW_SYNC_BLOCK      the search units and the engine (hnsw_engine, hnsw_tu_search, _lean, _duo): 64-thread
+//                        workgroups whose lanes hand over through LDS only -- the visited set's HBM spill tables are
+//                        written and read with agent-scope atomics, W / the scatter buffer / the query live in LDS, and
+//                        no kernel of these units loads a word another lane of the same launch stored to HBM with a plain
+//                        store -> __syncthreads() (for one wave: LDS wait + wave barrier, no s_barrier).
+// A unit that does not say is refused; the meaning no longer depends on which header came first.
+#if defined(HNSW_SYNC_WAVE_FULL) == defined(HNSW_SYNC_BLOCK)
+#error "define exactly one of HNSW_SYNC_WAVE_FULL / HNSW_SYNC_BLOCK before including the engine's headers (see hnsw_device.hpp)"
+#endif
+__device__ __forceinline__ void dev_sync()
+{
+#ifdef HNSW_SYNC_WAVE_FULL
+    wave_sync();
+#else
+    __syncthreads();
+#endif
+}
 
 struct GraphView {
     const float *vec;           // [cap][dim]
@@ -79,6 +103,16 @@ __device__ __forceinline__ uint32_t *row_mut(const GraphView &g, uint32_t id, ui
 {
     (void)lane;
     return row_ptr(g, id, lc);
+}
+// ... for an edit that REWRITES the row's live words (count + ids) in one go: where to write, and in *src where the row's
+// present content is read from.  An overlay hands out an empty scratch row on first touch and the graph's row as the
+// source -- no copy, the edit's own store fills the scratch row.
+__device__ __forceinline__ uint32_t *row_rewrite(const GraphView &g, uint32_t id, uint32_t lc, int lane, const uint32_t **src)
+{
+    (void)lane;
+    uint32_t *r = row_ptr(g, id, lc);
+    *src = r;
+    return r;
 }
 
 // ---------------------------------------------------------------------------
@@ -186,7 +220,7 @@ __device__ __forceinline__ void load_query(const float *src, uint32_t dim, QReg<
         for (int t = 0; t < T; ++t) qr.q[t] = s4[t * 8 + pp];
     } else {
         for (uint32_t i = lane; i < dim; i += 64) qlds[i] = src[i];
-        __syncthreads();
+        dev_sync();
     }
 }
 
@@ -441,7 +475,7 @@ __device__ __forceinline__ void visited_clear(Visited &v, int lane)
     v.count = 0;
     v.spilled = false;
     v.lossy = false;
-    __syncthreads();
+    dev_sync();
 }
 
 // Move the whole LDS set to the HBM table and continue there.
@@ -467,7 +501,7 @@ __device__ __forceinline__ void visited_spill(Visited &v, int lane, unsigned lon
         }
     }
     __threadfence();
-    __syncthreads();
+    dev_sync();
     v.spilled = true;
     v.glob_dirty = true;
     if (lane == 0 && spill_ctr) atomicAdd(spill_ctr, 1ull);
@@ -561,7 +595,7 @@ __device__ __forceinline__ uint32_t merge_sorted(uint64_t *W, uint32_t nW, uint3
         rank += __popcll(__ballot(take && nk < s));
         if (lane == j) mypos = rank;
     }
-    __syncthreads();
+    dev_sync();
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         uint32_t i = r * 64 + lane;
@@ -572,7 +606,7 @@ __device__ __forceinline__ uint32_t merge_sorted(uint64_t *W, uint32_t nW, uint3
     }
     if (take && mypos < cap) W[mypos] = nk;
     const uint32_t total = nW + (uint32_t)__popcll(tmask);
-    __syncthreads();
+    dev_sync();
     return total < cap ? total : cap;
 }
 
@@ -734,13 +768,13 @@ __device__ __forceinline__ uint32_t search_level_v1(const GraphView &g, const Wa
         visited_insert(vis, ep);                 // core.rs:617
     }
     vis.count = 1;
-    __syncthreads();
+    dev_sync();
     compute_dists<MODE, T>(g, qr, m, 1, lane);   // core.rs:621
     ctr.n_dist += 1;
-    __syncthreads();
+    dev_sync();
     if (lane == 0) m.W[0] = pack_key(m.dsc[0], ep); // core.rs:627-628
     uint32_t nW = 1;
-    __syncthreads();
+    dev_sync();
     const uint32_t stride = lc ? g.strideU : g.stride0;
 
     const uint32_t log_start = ctr.log_n;
@@ -750,7 +784,7 @@ __device__ __forceinline__ uint32_t search_level_v1(const GraphView &g, const Wa
         if (pos < 0) break;                               // core.rs:630,635
         const uint64_t ckey = m.W[pos];
         const uint32_t c = key_id(ckey);
-        __syncthreads();
+        dev_sync();
         if (lane == 0) m.W[pos] = ckey | 1ull;
         ctr.n_expand += 1;
         const uint32_t log_idx = ctr.log_n;
@@ -775,9 +809,9 @@ __device__ __forceinline__ uint32_t search_level_v1(const GraphView &g, const Wa
             if (fresh) m.fresh[__popcll(fm & lanemask_lt(lane))] = word;
             vis.count += nf;
             ctr.n_dist += nf;
-            __syncthreads();
+            dev_sync();
             compute_dists<MODE, T>(g, qr, m, nf, lane);    // core.rs:652
-            __syncthreads();
+            dev_sync();
             const bool have = (uint32_t)lane < nf;
             const uint64_t key = have ? pack_key(m.dsc[lane], m.fresh[lane]) : ~0ull;
             PH_MARK(ctr, 2);  // vector gather + distances
@@ -786,7 +820,7 @@ __device__ __forceinline__ uint32_t search_level_v1(const GraphView &g, const Wa
             nW = merge_sorted<R>(m.W, nW, ef, key, take, lane); // core.rs:659-664
             PH_MARK(ctr, 3);  // merge into W
         }
-        __syncthreads();
+        dev_sync();
         // read log: the accept threshold once this row's keys are in (what a later change of the row is judged by)
         if (ctr.log && lane == 0 && log_idx < ctr.log_cap)
             ctr.log[log_idx] = OccRead{c, occ_meta(lc, OCC_SEARCH, 0, false), (uint32_t)(ckey >> 32)};
@@ -863,9 +897,9 @@ __device__ __forceinline__ uint32_t merge_apply(uint64_t (&w)[R], uint64_t *Wbuf
     }
     if (take && mypos < cap) Wbuf[mypos] = nk;
     // One wave owns Wbuf and the LDS serves a wave's requests in issue order, so the reads below see
-    // the scatter above; only the compiler has to be kept from reordering them.  (A __syncthreads()
+    // the scatter above; only the compiler has to be kept from reordering them.  (A dev_sync()
     // here would also drain the vector loads this merge is meant to run under.)
-    __builtin_amdgcn_wave_barrier();
+    lds_order();
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t i = r * 64 + lane;
@@ -873,7 +907,7 @@ __device__ __forceinline__ uint32_t merge_apply(uint64_t (&w)[R], uint64_t *Wbuf
     }
     // the accept threshold of the next expansion (core.rs:651): the cap-th key once the list is full
     if (worst) *worst = total == cap ? Wbuf[cap - 1] : ~0ull;
-    __builtin_amdgcn_wave_barrier();
+    lds_order();
     return total;
 }
 
@@ -1045,7 +1079,7 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
 #pragma unroll
     for (int r = 0; r < R; ++r) pup[r] = 0;
     const uint32_t log_start = ctr.log_n;             // read log of this call (occ_finalize_search_log)
-    __syncthreads();
+    dev_sync();
     PH_T0();
 
     for (;;) {
@@ -1258,7 +1292,7 @@ __device__ __forceinline__ uint32_t search_level_v2(const GraphView &g, const Wa
     // leave W in LDS for the callers (top-k output, select_neighbors)
 #pragma unroll
     for (int r = 0; r < R; ++r) m.W[r * 64 + lane] = w[r];
-    __syncthreads();
+    dev_sync();
     return nW;
 }
 

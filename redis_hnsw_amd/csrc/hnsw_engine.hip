@@ -5,6 +5,7 @@
 // translation units (hnsw_tu_*.hip, see hnsw_host.hpp); this file holds the
 // handle's bookkeeping, the entry points and the small utility kernels.
 #define HNSW_UTILITY_KERNELS 1
+#define HNSW_SYNC_BLOCK   // search / engine unit: 64-thread workgroups handing over through LDS only (hnsw_device.hpp)
 #include "hnsw_host.hpp"
 #include "hnsw_kernels.hpp"
 #include "hnsw_search_lean.hpp"
@@ -713,10 +714,10 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
         return HNSW_OK;
     }
     if (!std::strcmp(key, "select_shortcut")) { h->select_shortcut = value != 0; return HNSW_OK; }
+    if (h->wide_m && (!std::strcmp(key, "occ_window") || !std::strcmp(key, "plan_lean") || !std::strcmp(key, "single_window")))
+        return HNSW_OK;                                  // M > 64: the serial kernels only (hnsw_create); these knobs stay off
     if (!std::strcmp(key, "plan_lean")) { h->plan_lean = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "single_window")) { h->single_window = value != 0; return HNSW_OK; }
-    if (h->wide_m && (!std::strcmp(key, "occ_window") || !std::strcmp(key, "plan_lean") || !std::strcmp(key, "single_window")))
-        return HNSW_OK;                                  // M > 64: the serial kernels only (hnsw_create)
     if (!std::strcmp(key, "occ_window")) { h->occ_window = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), kOccMaxW); return HNSW_OK; }
     if (!std::strcmp(key, "occ_ahead_x10")) { h->occ_ahead_x10 = (uint32_t)std::max<int64_t>(value, 5); return HNSW_OK; }
     if (!std::strcmp(key, "occ_slack_extra")) { h->occ_slack_extra = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 64); return HNSW_OK; }
@@ -725,7 +726,8 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
     if (!std::strcmp(key, "lean")) { h->lean = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "duo")) { h->duo = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "plan_duo")) { h->plan_duo = value != 0; return HNSW_OK; }
-    if (!std::strcmp(key, "commit_par")) { h->commit_par = value != 0; return HNSW_OK; }
+    if (!std::strcmp(key, "commit_par")) { h->commit_par = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return HNSW_OK; }
+    if (!std::strcmp(key, "commit_par_min_x10")) { h->commit_par_min_x10 = (uint32_t)std::max<int64_t>(value, 0); return HNSW_OK; }
     if (!std::strcmp(key, "commit_team")) { h->commit_team = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return HNSW_OK; }
     if (!std::strcmp(key, "plan_duo_max")) { h->plan_duo_max = (uint32_t)std::max<int64_t>(value, 0); return HNSW_OK; }
     if (!std::strcmp(key, "duo_max")) { h->duo_max = (uint32_t)std::max<int64_t>(value, 0); return HNSW_OK; }
@@ -1043,11 +1045,13 @@ hnsw_status hnsw_debug_occ_ctl(hnsw_index *h, uint64_t *out18)
 
 // the parallel group commit of the last windowed build (hnsw_occ_par.hpp; development aid, not in the public header):
 // [0] groups committed, [1] dry runs made, groups closed by [2] a stale link plan, [3] a record the node used, [4] a row it rewrote
-hnsw_status hnsw_debug_occ_par(hnsw_index *h, uint64_t *out5)
+hnsw_status hnsw_debug_occ_par(hnsw_index *h, uint64_t *out5 /* [21] */)
 {
     if (!h || !out5) return HNSW_ERR_INVALID;
     out5[0] = h->occ_last.n_groups; out5[1] = h->occ_last.n_dry; out5[2] = h->occ_last.n_conf_link;
     out5[3] = h->occ_last.n_conf_rec; out5[4] = h->occ_last.n_conf_row;
+    for (int i = 0; i < 8; ++i) out5[5 + i] = h->occ_last.par_prof[i];   // workgroup 0's phase clocks (100 MHz), iterations, launches
+    for (int i = 0; i < 8; ++i) out5[13 + i] = h->occ_last.dry_prof[i];  // all dry runs' phase clocks; [7] sum of the slowest per iteration
     return HNSW_OK;
 }
 

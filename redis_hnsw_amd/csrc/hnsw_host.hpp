@@ -99,7 +99,10 @@ struct hnsw_index {
     void *d_par = nullptr, *d_par_delta = nullptr;
     uint32_t *d_par_rows = nullptr;
     uint32_t par_ovstride = 0;
-    bool commit_par = true;         // tuning: a window's commits go in parallel groups (0 = the in-order commit wave only)
+    int commit_par = 1;             // tuning: a window's commits go in validated parallel groups (hnsw_occ_par.hpp): 0 never (the in-order commit
+                                    // wave only), 1 when the window has been committing at least commit_par_min_x10 / 10 nodes per round (a group
+                                    // costs one dry run whatever its size: below ~5 nodes per round the in-order wave is as fast), 2 always
+    uint32_t commit_par_min_x10 = 45;
     bool occ_fresh_slots = false;   // the round about to be launched starts from cleared slots (single hnsw_add)
     bool occ_want_touched = false;  // the commit kernel records the update_fn list (a single hnsw_add through a one-node window)
     bool single_window = true;      // tuning: a single hnsw_add runs as a one-node window (speculative shrinks in parallel) instead of the serial kernels

@@ -12,6 +12,7 @@
 // Layers are independent structures, so planning every layer before committing
 // any is equivalent to the reference's interleaving.
 #pragma once
+#include "hnsw_wave_sync.hpp"
 #include "hnsw_device.hpp"
 
 namespace hnsw {
@@ -67,7 +68,7 @@ __device__ __forceinline__ uint32_t select_topm(const GV &g, const WaveMem &m, V
         }
         if (nS > mcap) nS = mcap;
     }
-    __syncthreads();
+    wave_sync();
 
     const uint32_t stride = lc ? g.strideU : g.stride0;
     if constexpr (MODE == MODE_AVX) {
@@ -131,12 +132,12 @@ __device__ __forceinline__ uint32_t select_topm(const GV &g, const WaveMem &m, V
         auto drain = [&](uint32_t keep_below) {             // evaluate blocks of 64 until fewer than keep_below wait
             while (qn >= keep_below && qn) {
                 const uint32_t n = qn < 64u ? qn : 64u;
-                __syncthreads();
+                wave_sync();
                 evaluate(n);
-                __syncthreads();
+                wave_sync();
                 const uint32_t rest = qn - n;                // < 64
                 const uint32_t mv = (uint32_t)lane < rest ? queue[n + lane] : 0u;
-                __syncthreads();
+                wave_sync();
                 if ((uint32_t)lane < rest) queue[lane] = mv;
                 qn = rest;
             }
@@ -178,7 +179,7 @@ __device__ __forceinline__ uint32_t select_topm(const GV &g, const WaveMem &m, V
             }
         }
         drain(1);
-        __syncthreads();
+        wave_sync();
         return nS;
     }
     // software prefetch: the next candidate's row is requested before the
@@ -211,16 +212,16 @@ __device__ __forceinline__ uint32_t select_topm(const GV &g, const WaveMem &m, V
             vis.count += nf;
             ctr.n_dist += nf;
             if (fresh) m.fresh[__popcll(fm & lanemask_lt(lane))] = word;
-            __syncthreads();
+            wave_sync();
             compute_dists<MODE, T>(g, qr, m, nf, lane);      // core.rs:711
-            __syncthreads();
+            wave_sync();
             const bool have = (uint32_t)lane < nf;
             const uint64_t key = have ? pack_key(m.dsc[lane], m.fresh[lane]) : ~0ull;
             const uint64_t worst = nS == mcap ? m.S[mcap - 1] : ~0ull;
             nS = merge_S(m.S, nS, mcap, key, have && key < worst, lane); // core.rs:717
         }
     }
-    __syncthreads();
+    wave_sync();
     return nS;
 }
 
@@ -244,7 +245,7 @@ __device__ __forceinline__ uint32_t select_head_of_W(const WaveMem &m, uint32_t 
 {
     const uint32_t nS = nW < mcap ? nW : mcap;
     for (uint32_t i = lane; i < nS; i += 64) m.S[i] = m.W[i] & ~1ull;
-    __syncthreads();
+    wave_sync();
     return nS;
 }
 
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(64, 1) void k_insert_plan(GraphView g, uint32_t fir
         for (uint32_t lc = lmax; lc > l && !fail; --lc) {   // core.rs:511-520
             search_level<MODE, T, 1>(g, m, vis, qr, ep, 1, lc, ctr, lane, fail);
             ep = key_id(m.W[0]);                            // core.rs:514
-            __syncthreads();
+            wave_sync();
         }
         const uint32_t top = lmax < l ? lmax : l;
         for (uint32_t lc1 = top + 1; lc1-- > 0 && !fail;) { // core.rs:523
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(64, 1) void k_insert_plan(GraphView g, uint32_t fir
             if (lane == 0) pl[0] = nS;
             for (uint32_t i = lane; i < nS; i += 64) pl[1 + i] = key_id(m.S[i]);   // (more than 64 only when M > 64)
             ep = wnearest;                                  // core.rs:576
-            __syncthreads();
+            wave_sync();
         }
         if (fail && lane == 0) atomicOr(&g.hdr->status, ST_VISITED_OVERFLOW);
     }
@@ -376,23 +377,27 @@ __device__ __forceinline__ void update_connections(const GV &g, const WaveMem &m
             const int j = __ffsll((unsigned long long)dm) - 1;
             dm &= dm - 1;
             const uint32_t xj = (uint32_t)__builtin_amdgcn_readlane((int)x, j);
-            uint32_t *xrow = row_mut(g, xj, lc, lane);
             // the first 64 words in one load (lane 0 = the count): rows of <= 63 ids need nothing else, one round
-            // trip instead of two
-            const uint32_t wx = (uint32_t)lane < stride ? xrow[lane] : kEmpty;
+            // trip instead of two.  The live words are rewritten whole (row_rewrite: an overlay's scratch row is filled
+            // by this very store)
+            const uint32_t *xsrc;
+            uint32_t *xrow = row_rewrite(g, xj, lc, lane, &xsrc);
+            const uint32_t wx = (uint32_t)lane < stride ? xsrc[lane] : kEmpty;
             uint32_t xc1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wx);
             if (xc1 > stride - 1) xc1 = stride - 1;
             if (xc1 <= 63) {
                 const uint64_t hit = __ballot(lane >= 1 && (uint32_t)lane <= xc1 && wx == e);
-                if (!hit) { if (lane == 0) atomicOr(&g.hdr->status, ST_ASYMMETRIC); }      // reference panics, :150
-                else {
+                if (!hit) {                                                                // reference panics, :150
+                    if (lane == 0) atomicOr(&g.hdr->status, ST_ASYMMETRIC);
+                    if ((uint32_t)lane <= xc1) xrow[lane] = wx;
+                } else {
                     const int pos = __ffsll((unsigned long long)hit) - 1;                  // word index of e
                     const uint32_t nxt = (uint32_t)__shfl_down((int)wx, 1, 64);             // word lane + 1
-                    if (lane >= pos && (uint32_t)lane < xc1) xrow[lane] = nxt;
-                    if (lane == 0) xrow[0] = xc1 - 1;
+                    if ((uint32_t)lane < xc1) xrow[lane] = lane == 0 ? xc1 - 1 : (lane >= pos ? nxt : wx);
                 }
                 continue;
             }
+            if (xsrc != xrow) { for (uint32_t i = lane; i < stride; i += 64) xrow[i] = xsrc[i]; wave_sync(); }   // wide rows: copy, then edit in place
             const uint32_t xc = xc1;
             bool found = false;
             for (uint32_t b2 = 0; b2 < xc; b2 += 64) {          // rows wider than 63 ids: more than one pass
@@ -403,10 +408,10 @@ __device__ __forceinline__ void update_connections(const GV &g, const WaveMem &m
                 if (!found && hit) {
                     found = true;
                     const uint32_t pos = b2 + (uint32_t)(__ffsll((unsigned long long)hit) - 1);
-                    __builtin_amdgcn_wave_barrier();
+                    wave_sync();
                     if (p >= pos && p + 1 < xc) xrow[1 + p] = vnext;
                 } else if (found) {
-                    __builtin_amdgcn_wave_barrier();
+                    wave_sync();
                     if (p + 1 < xc) xrow[1 + p] = vnext;
                 }
             }
@@ -431,18 +436,23 @@ __device__ __forceinline__ void update_connections(const GV &g, const WaveMem &m
             const int j = __ffsll((unsigned long long)am) - 1;
             am &= am - 1;
             const uint32_t xj = (uint32_t)__builtin_amdgcn_readlane((int)x, j);
-            uint32_t *xrow = row_mut(g, xj, lc, lane);
-            const uint32_t wx = (uint32_t)lane < stride ? xrow[lane] : kEmpty;
+            const uint32_t *xsrc;
+            uint32_t *xrow = row_rewrite(g, xj, lc, lane, &xsrc);
+            const uint32_t wx = (uint32_t)lane < stride ? xsrc[lane] : kEmpty;
             uint32_t xc1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wx);
             if (xc1 > stride - 1) xc1 = stride - 1;
             if (xc1 < 63) {                                         // the row and the appended slot are words 0..63
                 const bool there = __ballot(lane >= 1 && (uint32_t)lane <= xc1 && wx == e) != 0;
-                if (!there && lane == 0) {
-                    if (xc1 + 1 > stride - 1) atomicOr(&g.hdr->status, ST_ROW_OVERFLOW);
-                    else { xrow[1 + xc1] = e; xrow[0] = xc1 + 1; atomicMax(maxdeg, xc1 + 1); }
+                if (there || xc1 + 1 > stride - 1) {
+                    if (!there && lane == 0) atomicOr(&g.hdr->status, ST_ROW_OVERFLOW);
+                    if ((uint32_t)lane <= xc1) xrow[lane] = wx;
+                } else {
+                    if ((uint32_t)lane <= xc1 + 1) xrow[lane] = lane == 0 ? xc1 + 1 : ((uint32_t)lane == xc1 + 1 ? e : wx);
+                    if (lane == 0) atomicMax(maxdeg, xc1 + 1);
                 }
                 continue;
             }
+            if (xsrc != xrow) { for (uint32_t i = lane; i < stride; i += 64) xrow[i] = xsrc[i]; wave_sync(); }   // wide rows: copy, then edit in place
             const uint32_t xc = xc1;
             bool present = false;
             for (uint32_t b2 = 0; b2 < xc; b2 += 64) {
@@ -462,7 +472,7 @@ __device__ __forceinline__ void update_connections(const GV &g, const WaveMem &m
     if (lane == 0) erow[0] = kept;
     touch_push(touched, touched_cap, nt, e, lane == 0, lane);               // :787
     fence_own_writes();
-    __syncthreads();
+    wave_sync();
 }
 
 // ---------------------------------------------------------------------------
@@ -534,7 +544,7 @@ __global__ __launch_bounds__(64, 1) void k_insert_commit_exact(GraphView g, uint
         }
         if (lane == 0) atomicMax(maxdeg, nsel);
         __threadfence();
-        __syncthreads();
+        wave_sync();
 
         // shrink loop (core.rs:540-574), e nearest first
         for (uint32_t si = 0; si < nsel && !fail; ++si) {
@@ -553,10 +563,10 @@ __global__ __launch_bounds__(64, 1) void k_insert_commit_exact(GraphView g, uint
                 const uint32_t i = base + lane;
                 const uint32_t nf = cnt - base < 64 ? cnt - base : 64;
                 if (i < cnt) { uint32_t x = erow[1 + i]; m.fresh[lane] = x; m.aux[i] = x; }
-                __syncthreads();
+                wave_sync();
                 compute_dists<MODE, T>(g, qe, m, nf, lane);  // :550
                 ctr.n_dist += nf;
-                __syncthreads();
+                wave_sync();
                 const bool have = (uint32_t)lane < nf;
                 const uint64_t key = have ? pack_key(m.dsc[lane], m.fresh[lane]) : ~0ull;
                 nE = merge_sorted<R>(m.W, nE, R * 64, key, have, lane);
@@ -633,10 +643,10 @@ __global__ __launch_bounds__(64, 1) void k_delete_exact(GraphView g, uint32_t id
                 const uint32_t i = base + lane;
                 const uint32_t nf = cnt - base < 64 ? cnt - base : 64;
                 if (i < cnt) { uint32_t x = erow[1 + i]; m.fresh[lane] = x; m.aux[i] = x; }
-                __syncthreads();
+                wave_sync();
                 compute_dists<MODE, T>(g, qe, m, nf, lane);   // :840-841
                 ctr.n_dist += nf;
-                __syncthreads();
+                wave_sync();
                 const bool have = (uint32_t)lane < nf;
                 const uint64_t key = have ? pack_key(m.dsc[lane], m.fresh[lane]) : ~0ull;
                 nE = merge_sorted<R>(m.W, nE, R * 64, key, have, lane);
@@ -649,7 +659,7 @@ __global__ __launch_bounds__(64, 1) void k_delete_exact(GraphView g, uint32_t id
         }
         if (lane == 0) drow[0] = 0;                               // the node is gone (core.rs:419)
         __threadfence();
-        __syncthreads();
+        wave_sync();
     }
     if (fail && lane == 0) atomicOr(&g.hdr->status, ST_VISITED_OVERFLOW);
     if (lane == 0) {
@@ -740,17 +750,17 @@ __global__ __launch_bounds__(64) void k_shrink_batch(GraphView g, uint32_t mlink
         }
         if (cnt <= mmax) continue;
         QReg<T> qe;
-        __syncthreads();
+        wave_sync();
         load_query<MODE, T>(g.vec + (size_t)e * g.dim, g.dim, qe, m.qlds, lane);
         uint32_t nE = 0;
         for (uint32_t base = 0; base < cnt; base += 64) {
             const uint32_t i = base + lane;
             const uint32_t nf = cnt - base < 64 ? cnt - base : 64;
             if (i < cnt) m.fresh[lane] = erow[1 + i];
-            __syncthreads();
+            wave_sync();
             compute_dists<MODE, T>(g, qe, m, nf, lane);
             ndist += nf;
-            __syncthreads();
+            wave_sync();
             const bool have = (uint32_t)lane < nf;
             const uint64_t key = have ? pack_key(m.dsc[lane], m.fresh[lane]) : ~0ull;
             nE = merge_sorted<2>(m.W, nE, 128, key, have, lane);
@@ -761,7 +771,7 @@ __global__ __launch_bounds__(64) void k_shrink_batch(GraphView g, uint32_t mlink
             erow[0] = keep;
             atomicMax(lc ? &g.hdr->max_degU : &g.hdr->max_deg0, keep);
         }
-        __syncthreads();
+        wave_sync();
     }
     if (lane == 0 && ndist) atomicAdd(&g.hdr->ctr_insert[0], ndist);
 }

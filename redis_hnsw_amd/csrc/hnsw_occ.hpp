@@ -57,6 +57,8 @@ struct OccCtl {
     // parallel validated commits (hnsw_occ_par.hpp)
     uint32_t bar, bar_start;                // grid barrier of k_occ_commit_par: arrivals ever / the count the next launch starts from
     unsigned long long n_groups, n_dry, n_conf_link, n_conf_rec, n_conf_row;   // groups committed, dry runs made, groups closed by: a stale link plan / a record used / a changed row
+    unsigned long long dry_prof[8];         // all workgroups' dry runs, 100 MHz ticks: hash + journal check, connect, record checks, row load + spec apply, recompute, update_connections, finish; [7] = sum over iterations of the slowest dry run
+    unsigned long long par_prof[8];         // k_occ_commit_par, workgroup 0, 100 MHz ticks: dry run, wait, validate, wait, apply, wait; [6] iterations, [7] launches
 };
 
 struct OccBufs {
@@ -103,18 +105,18 @@ static_assert(kOccHash == (1u << 12), "occ_hash");
 __device__ __forceinline__ void occ_init_hash(const OccScratch &sc, int lane)       // once per kernel
 {
     for (uint32_t i = lane; i < kOccHash; i += 64) { sc.hkey[i] = kEmpty; sc.hhead[i] = kEmpty; }
-    __syncthreads();
+    wave_sync();
 }
 __device__ __forceinline__ void occ_clear_hash(const OccScratch &sc, uint32_t n_reads, int lane)   // after a slot is done
 {
     for (uint32_t i = lane; i < n_reads; i += 64) { const uint32_t h = sc.hslot[i]; sc.hkey[h] = kEmpty; sc.hhead[h] = kEmpty; }
-    __syncthreads();
+    wave_sync();
 }
 __device__ __forceinline__ void occ_build_hash(const OccScratch &sc, const OccRead *reads, uint32_t n_reads, const OccShr *shr,
                                                uint32_t n_shr, int lane)
 {
     for (uint32_t i = lane; i < 2 + 2 * kOccMaxShr; i += 64) sc.flags[i] = 0;
-    __syncthreads();
+    wave_sync();
     // the shrinks' rows, for the chain walk: flags[2 + kOccMaxShr + sub] = shr[sub].e
     if ((uint32_t)lane < n_shr && (uint32_t)lane < kOccMaxShr) sc.flags[2 + kOccMaxShr + lane] = shr[lane].e;
     for (uint32_t i = lane; i < n_reads; i += 64) {
@@ -131,7 +133,7 @@ __device__ __forceinline__ void occ_build_hash(const OccScratch &sc, const OccRe
         sc.hslot[i] = h;
         sc.hnext[i] = atomicExch(&sc.hhead[h], i);
     }
-    __syncthreads();
+    wave_sync();
 }
 
 // Check journal[from, to) against the hashed reads.  q = the slot's node; own_connect: entries (row,+q) are
@@ -148,7 +150,7 @@ __device__ __forceinline__ void occ_check_range(const GraphView &g, const WaveMe
     const uint32_t jmask = src ? 0xFFFFFFFFu : (1u << kOccJournalBits) - 1u;
     if (to - from > (1u << kOccJournalBits) - 4096u) {      // the ring has wrapped past this plan: stale
         if (lane == 0) sc.flags[0] = 1;
-        __syncthreads();
+        wave_sync();
         return;
     }
     // ---- collect: entries on rows the plan read ----
@@ -191,7 +193,7 @@ __device__ __forceinline__ void occ_check_range(const GraphView &g, const WaveMe
             }
         }
     }
-    __syncthreads();
+    wave_sync();
     // ---- evaluate: dist(reader, z) <= bound ? ----
     uint32_t nh = sc.flags[1];
     if (nh > kOccMaxHits) nh = kOccMaxHits;
@@ -212,14 +214,14 @@ __device__ __forceinline__ void occ_check_range(const GraphView &g, const WaveMe
             const uint64_t sm = __ballot(sel);
             const uint32_t nf = (uint32_t)__popcll(sm);
             const uint32_t idx = (uint32_t)__popcll(sm & lanemask_lt(lane));
-            __syncthreads();
+            wave_sync();
             if (sel) m.fresh[idx] = z;
             const uint32_t rid = rd ? sc.flags[2 + kOccMaxShr + rd - 1] : q;
             QReg<T> qr;
             load_query<MODE, T>(g.vec + (size_t)rid * g.dim, g.dim, qr, m.qlds, lane);
-            __syncthreads();
+            wave_sync();
             compute_dists<MODE, T>(g, qr, m, nf, lane);
-            __syncthreads();
+            wave_sync();
             if (sel && __float_as_uint(m.dsc[idx]) <= bound) {
                 if (rd) atomicOr(&sc.flags[1 + rd], was_add ? OCC_WHY_ADD : OCC_WHY_REMOVE);
                 else sc.flags[0] = 1;
@@ -228,7 +230,7 @@ __device__ __forceinline__ void occ_check_range(const GraphView &g, const WaveMe
         }
     }
     if (lane == 0) sc.flags[1] = 0;
-    __syncthreads();
+    wave_sync();
 }
 
 // The tail of a plan: the shrinks the connect will trigger (core.rs:560-561) are listed here (k_occ_shrinks computes
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_plan(GraphView g, OccBufs ob, uin
     for (uint32_t lc = lmax; lc > l && !fail; --lc) {       // core.rs:511-520
         search_level<MODE, T, 1>(g, m, vis, qr, ep, 1, lc, ctr, lane, fail);
         ep = key_id(m.W[0]);                                // core.rs:514
-        __syncthreads();
+        wave_sync();
     }
     const uint32_t top = lmax < l ? lmax : l;
     for (uint32_t lc1 = top + 1; lc1-- > 0 && !fail;) {     // core.rs:523
@@ -365,10 +367,10 @@ __global__ __launch_bounds__(64, 1) void k_occ_plan(GraphView g, OccBufs ob, uin
         if (lane == 0) qrow[0] = nS;
         if ((uint32_t)lane < nS) qrow[1 + lane] = key_id(m.S[lane]);
         ep = wnearest;                                      // core.rs:576
-        __syncthreads();
+        wave_sync();
     }
     __threadfence();
-    __syncthreads();
+    wave_sync();
 
     occ_plan_finish(g, ob, sl, shr, pl0, ctr, id, top, mlinks, log_cap, snap, epoch, fail, vis, lane);
 }
@@ -419,9 +421,9 @@ __global__ __launch_bounds__(64, 1) void k_occ_shrinks(GraphView g, OccBufs ob, 
         const uint32_t i = base + lane;
         const uint32_t nf = tot - base < 64 ? tot - base : 64;
         if (i < tot) { const uint32_t x = i < cnt ? erow[1 + i] : id; m.fresh[lane] = x; m.aux[i] = x; }
-        __syncthreads();
+        wave_sync();
         compute_dists<MODE, T>(g, qe, m, nf, lane);
-        __syncthreads();
+        wave_sync();
         const bool have = (uint32_t)lane < nf;
         const uint64_t key = have ? pack_key(m.dsc[lane], m.fresh[lane]) : ~0ull;
         nE = merge_sorted<R>(m.W, nE, R * 64, key, have, lane);
@@ -549,13 +551,13 @@ __device__ __forceinline__ uint32_t team_share(uint64_t *dst, const uint64_t *W0
 {
     const uint32_t n = nE > wave ? (nE - wave + nw - 1) / nw : 0u;
     for (uint32_t i = lane; i < n; i += 64) dst[i] = W0[i * nw + wave];
-    __syncthreads();
+    wave_sync();
     return n;
 }
 
 // a helper wavefront of the commit workgroup: serves TEAM_SELECT tasks until TEAM_EXIT
-template <int MODE, int T>
-__device__ __forceinline__ void team_helper(const GraphView &g, volatile TeamTask *task, const uint64_t *W0, unsigned char *hmem,
+template <int MODE, int T, class GV>
+__device__ __forceinline__ void team_helper(const GV &g, volatile TeamTask *task, const uint64_t *W0, unsigned char *hmem,
                                             const TeamCfg &tc, uint32_t *hspill, uint32_t wave, uint32_t nw, int lane)
 {
     WaveMem m;
@@ -592,8 +594,8 @@ __device__ __forceinline__ void team_helper(const GraphView &g, volatile TeamTas
 }
 
 // the committing wave's side: econn is sorted in m.W[0..nE); result in m.S[0..nS)
-template <int MODE, int T>
-__device__ __forceinline__ uint32_t team_select(const GraphView &g, const WaveMem &m, Visited &vis, const QReg<T> &qe, uint32_t nE,
+template <int MODE, int T, class GV>
+__device__ __forceinline__ uint32_t team_select(const GV &g, const WaveMem &m, Visited &vis, const QReg<T> &qe, uint32_t nE,
                                                 uint32_t e, uint32_t mmax, uint32_t lc, WorkCtr &ctr, int lane, bool &fail,
                                                 uint32_t ignored, volatile TeamTask *task, uint64_t *W0sub, unsigned char *hmem0,
                                                 const TeamCfg &tc, uint32_t nw)
@@ -624,7 +626,7 @@ __device__ __forceinline__ uint32_t team_select(const GraphView &g, const WaveMe
             }
             const bool dup = have && lo < nS && m.S[lo] == key;
             const uint64_t worst = nS == mmax ? m.S[mmax - 1] : ~0ull;
-            __syncthreads();
+            wave_sync();
             nS = merge_S(m.S, nS, mmax, key, have && !dup && key < worst, lane);
         }
     }
@@ -706,7 +708,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit(GraphView g, Oc
         checked = jr.n;
         OCC_T(1);
         if (sc.flags[0]) {                                   // the link plan is stale: re-plan (end of the round)
-            __syncthreads();
+            wave_sync();
             occ_clear_hash(sc, sl->n_reads, lane);
             if (lane == 0) sl->planned = 0;
             stop = OCC_STOP_REPLAN;
@@ -742,7 +744,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit(GraphView g, Oc
             touch_push(touched, touched_cap, nt, myselid, touched != nullptr && (uint32_t)lane < nsel, lane);   // :535-537
             journal_push(&jr, (uint32_t)lane < nsel, myselid, lc, id, true, lane);
             fence_own_writes();
-            __syncthreads();
+            wave_sync();
             OCC_T(2);
 
             for (uint32_t si = 0; si < nsel && !fail; ++si) {   // shrink loop (core.rs:540-574), e nearest first
@@ -764,14 +766,14 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit(GraphView g, Oc
                 }
                 OCC_T(3);
                 for (uint32_t i = lane; i < cnt; i += 64) m.aux[i] = erow[1 + i];
-                __syncthreads();
+                wave_sync();
                 uint32_t nS;
                 if (k >= 0 && !sc.flags[2 + k]) {
                     const uint32_t sv = shr[k].S[lane], sv2 = shr[k].S[64 + lane];   // loaded alongside nS, not after it
                     nS = shr[k].nS;
                     if ((uint32_t)lane < nS) m.S[lane] = (uint64_t)sv << 1;
                     if (64u + (uint32_t)lane < nS) m.S[64 + lane] = (uint64_t)sv2 << 1;
-                    __syncthreads();
+                    wave_sync();
                     n_spec += 1;
                     w_dist += shr[k].w_dist;
                     w_ids += shr[k].w_ids;
@@ -784,9 +786,9 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit(GraphView g, Oc
                         const uint32_t i = base + lane;
                         const uint32_t nf = cnt - base < 64 ? cnt - base : 64;
                         if (i < cnt) m.fresh[lane] = m.aux[i];
-                        __syncthreads();
+                        wave_sync();
                         compute_dists<MODE, T>(g, qe, m, nf, lane);
-                        __syncthreads();
+                        wave_sync();
                         const bool have = (uint32_t)lane < nf;
                         const uint64_t key = have ? pack_key(m.dsc[lane], m.fresh[lane]) : ~0ull;
                         nE = merge_sorted<R>(m.W, nE, R * 64, key, have, lane);
@@ -823,7 +825,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit(GraphView g, Oc
             sl->planned = 0;
         }
         fence_own_writes();
-        __syncthreads();
+        wave_sync();
         occ_clear_hash(sc, sl->n_reads, lane);
         n_commit += 1;
         head += 1;
@@ -991,7 +993,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_del_commit(GraphView g
                 checked = jr.n;
             }
             for (uint32_t i = lane; i < cnt; i += 64) m.aux[i] = erow[1 + i];
-            __syncthreads();
+            wave_sync();
             uint32_t nS;
 #ifdef HNSW_OCC_DEBUG
             // ground truth beside the validation: every record is also recomputed; a record whose list differs from the
@@ -1011,7 +1013,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_del_commit(GraphView g
                 nS = shr[k].nS;
                 if ((uint32_t)lane < nS) m.S[lane] = (uint64_t)sv << 1;
                 if (64u + (uint32_t)lane < nS) m.S[64 + lane] = (uint64_t)sv2 << 1;
-                __syncthreads();
+                wave_sync();
                 n_spec += 1;
                 w_dist += shr[k].w_dist;
                 w_ids += shr[k].w_ids;
@@ -1024,9 +1026,9 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_del_commit(GraphView g
                     const uint32_t i = base + lane;
                     const uint32_t nf = cnt - base < 64 ? cnt - base : 64;
                     if (i < cnt) m.fresh[lane] = m.aux[i];
-                    __syncthreads();
+                    wave_sync();
                     compute_dists<MODE, T>(g, qe, m, nf, lane);
-                    __syncthreads();
+                    wave_sync();
                     const bool have = (uint32_t)lane < nf;
                     const uint64_t key = have ? pack_key(m.dsc[lane], m.fresh[lane]) : ~0ull;
                     nE = merge_sorted<R>(m.W, nE, R * 64, key, have, lane);
@@ -1045,7 +1047,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_del_commit(GraphView g
             }
 #ifdef HNSW_OCC_DEBUG
             {   // what was decided for this neighbour, into the control block (hnsw_debug_occ_ctl)
-                __syncthreads();
+                wave_sync();
                 unsigned long long hs = 0;
                 for (uint32_t i = lane; i < nS; i += 64) hs += (unsigned long long)key_id(m.S[i]) * (unsigned long long)(2 * i + 1);
                 for (int o = 32; o; o >>= 1) hs += __shfl_xor(hs, o, 64);
@@ -1063,7 +1065,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_del_commit(GraphView g
         }
         if (lane == 0) drow[0] = 0;                              // the node is gone (core.rs:419)
         __threadfence();
-        __syncthreads();
+        wave_sync();
     }
     if (fail && lane == 0) atomicOr(&g.hdr->status, ST_VISITED_OVERFLOW);
     if constexpr (HW > 0) {

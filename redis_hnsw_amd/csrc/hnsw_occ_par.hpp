@@ -87,6 +87,27 @@ __device__ __forceinline__ uint32_t *row_mut(const OverlayView &g, uint32_t id, 
     wave_sync_full();                                     // the copy has landed before anybody reads it back
     return dst;
 }
+// a row about to be REWRITTEN (count + ids in one store, update_connections): on first touch the scratch row is handed
+// out EMPTY and the graph's row is where the present content is read from -- no copy, no round trip
+__device__ __forceinline__ uint32_t *row_rewrite(const OverlayView &g, uint32_t id, uint32_t lc, int lane, const uint32_t **src)
+{
+    const uint32_t key = (id << 5) | lc;
+    uint32_t h = ov_hash(key);
+    for (;;) {
+        const uint32_t k = g.ovkey[h];
+        if (k == key) { uint32_t *r = g.ovrows + (size_t)h * g.ovstride; *src = r; return r; }
+        if (k == kEmpty) break;
+        h = (h + 1) & (kParTab - 1);
+    }
+    *src = row_ptr(static_cast<const GraphView &>(g), id, lc);
+    if (g.ovctl[0] >= kParMaxRows) {                      // no room: the dry run is void
+        if (lane == 0) g.ovctl[1] = 1u;
+        return g.ovrows + (size_t)kParTab * g.ovstride;
+    }
+    if (lane == 0) { g.ovkey[h] = key; g.ovctl[0] += 1u; }
+    lds_order();
+    return g.ovrows + (size_t)h * g.ovstride;
+}
 // connect_neighbors: lane i < n is about to append to the row of its own selected neighbour -- all of them enter the
 // overlay, the copies four rows at a time.  Returns this lane's scratch row.
 __device__ __forceinline__ uint32_t *ov_own_lanes(const OverlayView &g, bool valid, uint32_t id, uint32_t lc, int lane)
@@ -167,7 +188,7 @@ __device__ __forceinline__ void par_barrier(uint32_t *ctr, uint32_t &target, uin
         __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while ((int32_t)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(4);
     }
-    __builtin_amdgcn_wave_barrier();
+    lds_order();                                          // (the wave reconverges; the fence below does the waiting)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    // what the others wrote before they arrived, and no stale L1 lines
     asm volatile("" ::: "memory");
 }
@@ -180,13 +201,16 @@ __device__ __forceinline__ void par_barrier(uint32_t *ctr, uint32_t &target, uin
 // validate / apply until the head's link plan is stale, the window is exhausted, or the head needs the host
 // (ctl->stop).
 // ---------------------------------------------------------------------------------------------------------
-template <int MODE, int T, int R>
-__global__ __launch_bounds__(64, 1) void k_occ_commit_par(GraphView g, OccBufs ob, ParBufs pb, uint32_t end_node, uint32_t mlinks,
+// HW > 0: every workgroup has HW helper wavefronts that share each recomputed select_neighbors with its committing
+// wave (team_select, hnsw_occ.hpp), reading through the same overlay; they take no part in the grid barriers.
+template <int MODE, int T, int R, int HW = 0>
+__global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g, OccBufs ob, ParBufs pb, uint32_t end_node, uint32_t mlinks,
                                                        uint32_t lnb, uint32_t lcap, uint32_t *__restrict__ gspill, uint32_t gnb,
-                                                       const uint32_t *__restrict__ plan, uint32_t slack)
+                                                       const uint32_t *__restrict__ plan, uint32_t slack, uint32_t own_lds = 0,
+                                                       TeamCfg tc = TeamCfg{})
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const uint32_t b = blockIdx.x, nwg = gridDim.x;
     OccScratch sc = occ_carve(smem);
     OverlayView ov;
@@ -199,6 +223,17 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit_par(GraphView g, OccBufs o
     WaveMem m;
     Visited vis;
     carve<R, T, true>(smem + kOccScratchBytes + kParLdsBytes, g.dim, lnb, lcap, m, vis, g.tagcfg, g.selcap);
+    volatile TeamTask *task = reinterpret_cast<volatile TeamTask *>(smem + kOccScratchBytes + kParLdsBytes + own_lds);
+    uint64_t *W0sub = reinterpret_cast<uint64_t *>(smem + kOccScratchBytes + kParLdsBytes + own_lds + sizeof(TeamTask));
+    unsigned char *hmem0 = smem + kOccScratchBytes + kParLdsBytes + own_lds + sizeof(TeamTask) + (size_t)kTeamCand * 8;
+    if constexpr (HW > 0) {
+        const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 6;
+        if (wave > 0) {                                      // HBM spill regions: [0, 64) the committing waves', then HW per workgroup
+            team_helper<MODE, T>(ov, task, m.W, hmem0 + (size_t)(wave - 1) * tc.hbytes, tc, gspill + (size_t)(64u + b * HW) * gnb * 8, wave,
+                                 1u + HW, lane);
+            return;
+        }
+    }
     vis.glob = gspill + (size_t)b * gnb * 8;
     vis.gnb = gnb;
     vis.glob_dirty = false;
@@ -212,10 +247,13 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit_par(GraphView g, OccBufs o
     uint32_t bar_target = ob.ctl->bar_start;
     occ_init_hash(sc, lane);
     unsigned long long n_groups = 0, n_dry = 0, n_conf_link = 0, n_conf_rec = 0, n_conf_row = 0;   // (groups: workgroup 0 keeps the round's)
-    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // workgroup 0, 100 MHz ticks: dry run, wait, validate, wait, apply, wait; [6] iterations, [7] iterations without a group
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // workgroup 0, 100 MHz ticks: dry run, wait, validate, wait, apply, wait; [6] iterations, [7] launches
     unsigned long long t_ = wall_clock64();
 #define PAR_T(i) do { const unsigned long long n_ = wall_clock64(); prof[i] += n_ - t_; t_ = n_; } while (0)
 
+    unsigned long long dprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long d_ = 0;
+#define DRY_T(i) do { const unsigned long long n_ = wall_clock64(); dprof[i] += n_ - d_; d_ = n_; } while (0)
     // the dry run this workgroup holds (kept across iterations while nothing committed touches it)
     bool have = false, redo = false;
     uint32_t cur_id = kEmpty, kept_state = PAR_NONE;
@@ -243,6 +281,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit_par(GraphView g, OccBufs o
             have = false;
         }
         uint32_t state = PAR_NONE;
+        unsigned long long dry_ticks = 0;
         if (id < end_node) {
             if (!sl->planned || sl->node != id) state = PAR_REPLAN;
             else if (sl->fail) state = PAR_SERIAL;
@@ -251,6 +290,8 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit_par(GraphView g, OccBufs o
             else if (have) state = kept_state;
             else {
                 const uint32_t n_shr = sl->n_shr;
+                d_ = wall_clock64();
+                dry_ticks = d_;
                 live = 0; n_delta = 0; promotes = 0; n_spec = n_fallback = n_norec = 0; w_dist = w_ids = w_skipped = 0;
                 n_hash = sl->n_reads;
                 occ_build_hash(sc, reads, n_hash, shr, n_shr, lane);
@@ -260,6 +301,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit_par(GraphView g, OccBufs o
                     state = PAR_REPLAN;
                 } else {
                     n_dry += 1;
+                    DRY_T(0);
                     for (uint32_t i = lane; i < kParTab; i += 64) ov.ovkey[i] = kEmpty;
                     if (lane < 4) ov.ovctl[lane] = 0u;
                     wave_sync_full();
@@ -299,6 +341,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit_par(GraphView g, OccBufs o
                         journal_push(&jr, (uint32_t)lane < nsel, myselid, lc, id, true, lane);
                         fence_own_writes();
                         wave_sync_full();
+                        DRY_T(1);
 
                         for (uint32_t si = 0; si < nsel && !fail; ++si) {   // shrink loop (core.rs:540-574), e nearest first
                             const uint32_t e = pl[1 + si];
@@ -316,6 +359,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit_par(GraphView g, OccBufs o
                                 occ_check_range<MODE, T>(g, m, sc, ob, reads, shr, id, checked, jr.n, lane, true, 0u, mydelta);
                                 checked = jr.n;
                             }
+                            DRY_T(2);
                             for (uint32_t i = lane; i < cnt; i += 64) m.aux[i] = erow[1 + i];
                             wave_sync_full();
                             uint32_t nS;
@@ -329,6 +373,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit_par(GraphView g, OccBufs o
                                 w_dist += shr[k].w_dist;
                                 w_ids += shr[k].w_ids;
                                 live |= 1ull << k;
+                                DRY_T(3);
                             } else {
                                 // recompute on the spot (core.rs:544-568), reading through the overlay
                                 QReg<T> qe;
@@ -346,7 +391,10 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit_par(GraphView g, OccBufs o
                                     nE = merge_sorted<R>(m.W, nE, R * 64, key, hv, lane);
                                 }
                                 WorkCtr nolog = {};
-                                nS = select_topm<MODE, T>(ov, m, vis, qe, m.W, nE, e, mmax, lc, nolog, lane, fail);
+                                if constexpr (HW > 0)
+                                    nS = team_select<MODE, T>(ov, m, vis, qe, nE, e, mmax, lc, nolog, lane, fail, kEmpty, task, W0sub, hmem0, tc, 1u + HW);
+                                else
+                                    nS = select_topm<MODE, T>(ov, m, vis, qe, m.W, nE, e, mmax, lc, nolog, lane, fail);
                                 if (fail) break;
                                 w_dist += cnt + nolog.n_dist;
                                 w_ids += cnt + nolog.n_ids;
@@ -365,8 +413,10 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit_par(GraphView g, OccBufs o
                                     nsub += 1;
                                     wave_sync_full();
                                 }
+                                DRY_T(4);
                             }
                             update_connections(ov, m, e, erow, cnt, nS, lc, stride, maxdeg, kEmpty, (uint32_t *)nullptr, 0u, nt, lane, &jr);
+                            DRY_T(5);
                         }
                     }
                     if (vis.glob_dirty) visited_clear(vis, lane);
@@ -391,6 +441,8 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit_par(GraphView g, OccBufs o
                         promotes = l > lmax ? 1u : 0u;
                     }
                     wave_sync_full();
+                    DRY_T(6);
+                    dry_ticks = d_ - dry_ticks;
                     have = true;                             // kept until a group touches it (a void dry run, PAR_SERIAL, as well)
                     cur_id = id;
                     kept_state = state;
@@ -400,11 +452,20 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit_par(GraphView g, OccBufs o
         redo = false;
         if (lane == 0) {
             me->state = state; me->conflict = 0u; me->promotes = state == PAR_READY ? promotes : 0u; me->n_delta = state == PAR_READY ? n_delta : 0u;
-            me->why = 0u;
+            me->why = 0u; me->pad0 = (uint32_t)(dry_ticks < 0xFFFFFFu ? dry_ticks : 0u);
         }
         PAR_T(0);
         par_barrier(&ob.ctl->bar, bar_target, nwg, lane);
         PAR_T(1);
+        {   // the head of the window is not ready (its link plan is stale, or it needs the host): the round ends here
+            const uint32_t hs = pb.par[head % nwg].state;
+            if (hs != PAR_READY) {
+                if (b == 0 && lane == 0)
+                    ob.ctl->stop = hs == PAR_SERIAL ? OCC_STOP_SERIAL : hs == PAR_RESTRIDE ? OCC_STOP_RESTRIDE : OCC_STOP_REPLAN;
+                prof[6] += 1;
+                break;
+            }
+        }
 
         // ------------------------------------------------------------------ validate against the nodes before this one
         uint32_t conflict = 0, why = 0, fc = kEmpty;        // fc: position of the first earlier node this one cannot commit beside
@@ -437,6 +498,11 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit_par(GraphView g, OccBufs o
             const OccPar *pp = &pb.par[in ? (head + (uint32_t)lane) % nwg : 0u];     // lane = position in the window
             const uint32_t st = in ? pp->state : PAR_NONE, cf = in ? pp->conflict : 1u, pr = in ? pp->promotes : 0u;
             const uint32_t nd = in ? pp->n_delta : 0u, wy = in ? pp->why : 0u;
+            {   // the slowest dry run of the iteration
+                uint32_t mx = in ? pp->pad0 : 0u;
+                for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, d, 64); mx = o > mx ? o : mx; }
+                if (b == 0) dprof[7] += mx;
+            }
             const uint64_t bad = __ballot(!in || st != PAR_READY || cf != 0u);
             p = bad ? (uint32_t)(__ffsll((unsigned long long)bad) - 1) : nwg;
             const uint64_t prm = __ballot(in && pr != 0u) & (p >= 64 ? ~0ull : lanemask_lt((int)p));
@@ -477,8 +543,12 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit_par(GraphView g, OccBufs o
 #pragma unroll
                     for (int u = 0; u < 8; ++u) w[u] = (u < n && (uint32_t)lane < st[u]) ? src[u][lane] : 0u;
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (u < n && (uint32_t)lane < st[u]) dst[u][lane] = w[u];
+                    for (int u = 0; u < 8; ++u) {                     // the live words only: count + ids (the rest of a scratch row is undefined)
+                        uint32_t cu = (uint32_t)__builtin_amdgcn_readfirstlane((int)w[u]);
+                        if (cu > st[u] - 1) cu = st[u] - 1;
+                        st[u] = u < n ? cu + 1 : 0u;
+                        if ((uint32_t)lane < st[u]) dst[u][lane] = w[u];
+                    }
                     for (int u = 0; u < n; ++u)
                         for (uint32_t i = 64 + lane; i < st[u]; i += 64) dst[u][i] = src[u][i];
                 }
@@ -521,19 +591,28 @@ __global__ __launch_bounds__(64, 1) void k_occ_commit_par(GraphView g, OccBufs o
         par_barrier(&ob.ctl->bar, bar_target, nwg, lane);
         PAR_T(5);
         prof[6] += 1;
-        if (!p) prof[7] += 1;
         if (p == 0 || head + p >= end_node) break;
     }
-    if (lane == 0 && n_dry) atomicAdd(&ob.ctl->n_dry, n_dry);
+    if constexpr (HW > 0) {
+        if (lane == 0) task->op = TEAM_EXIT;
+        team_bar();
+    }
+    if (lane == 0 && n_dry) {
+        atomicAdd(&ob.ctl->n_dry, n_dry);
+        for (int i = 0; i < 7; ++i) atomicAdd(&ob.ctl->dry_prof[i], dprof[i]);
+    }
+    if (b == 0 && lane == 0) atomicAdd(&ob.ctl->dry_prof[7], dprof[7]);
     if (b == 0 && lane == 0) {
         ob.ctl->bar_start = bar_target;
         ob.ctl->n_groups += n_groups;
         ob.ctl->n_conf_link += n_conf_link;
         ob.ctl->n_conf_rec += n_conf_rec;
         ob.ctl->n_conf_row += n_conf_row;
-        for (int i = 0; i < 8; ++i) ob.ctl->prof[i] += prof[i];
+        prof[7] = 1;
+        for (int i = 0; i < 8; ++i) ob.ctl->par_prof[i] += prof[i];
     }
 #undef PAR_T
+#undef DRY_T
 }
 
 } // namespace hnsw

@@ -61,7 +61,7 @@ struct PlanLean {
     {
         search_level_lean<VEC, 1, kPlanLeanBB, DB, WIDE, LOG>(g, Wbuf, ts, q, ep, 1, lc, ctr, lane, &g.hdr->ctr_search[3]);
         const uint32_t n = key_id(Wbuf[0]);
-        __builtin_amdgcn_wave_barrier();
+        lds_order();
         return n;
     }
     // search_level(ef) (core.rs:524): W sorted in Wbuf[0..nW), expanded bits set
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(DUO ? 128 : 64, 1) void k_insert_plan_lean(GraphVie
         for (uint32_t lc1 = top + 1; lc1-- > 0 && !fail;) { // core.rs:523
             const uint32_t lc = lc1;
             const uint32_t nW = pl_.search(g, ep, ef, lc, ctr, lane);                    // :524
-            __syncthreads();
+            wave_sync();
             const uint32_t wnearest = key_id(m.W[0]);
             const uint32_t nS = shortcut && select_is_head_of_W(ef, mlinks, nW)
                                     ? select_head_of_W(m, nW, mlinks, lane)
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(DUO ? 128 : 64, 1) void k_insert_plan_lean(GraphVie
             if (lane == 0) pl[0] = nS;
             if ((uint32_t)lane < nS) pl[1 + lane] = key_id(m.S[lane]);
             ep = wnearest;                                  // core.rs:576
-            __syncthreads();
+            wave_sync();
         }
         if (fail && lane == 0) atomicOr(&g.hdr->status, ST_VISITED_OVERFLOW);
         pl_.finish(lane);
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(DUO ? 128 : 64, 1) void k_occ_plan_lean(GraphView g
     for (uint32_t lc1 = top + 1; lc1-- > 0 && !fail;) {     // core.rs:523
         const uint32_t lc = lc1;
         const uint32_t nW = pl_.search(g, ep, ef, lc, ctr, lane);                        // :524
-        __syncthreads();
+        wave_sync();
         const uint32_t wnearest = key_id(m.W[0]);
         uint32_t nS;
         if (shortcut && select_is_head_of_W(ef, mlinks, nW)) {
@@ -241,11 +241,11 @@ __global__ __launch_bounds__(DUO ? 128 : 64, 1) void k_occ_plan_lean(GraphView g
         if (lane == 0) qrow[0] = nS;
         if ((uint32_t)lane < nS) qrow[1 + lane] = key_id(m.S[lane]);
         ep = wnearest;                                      // core.rs:576
-        __syncthreads();
+        wave_sync();
     }
     pl_.finish(lane);
     __threadfence();
-    __syncthreads();
+    wave_sync();
     occ_plan_finish(g, ob, sl, shr, pl0, ctr, id, top, mlinks, log_cap, snap, epoch, fail, vis, lane);
 }
 

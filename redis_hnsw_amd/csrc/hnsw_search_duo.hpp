@@ -198,7 +198,7 @@ __device__ __forceinline__ bool duo_keep(const GraphView &g, uint64_t *Wbuf, Duo
         if (fl & DUO_FIN) {
 #pragma unroll
             for (int r = 0; r < R; ++r) Wbuf[r * 64 + lane] = w[r];
-            __builtin_amdgcn_wave_barrier();
+            lds_order();
             if (lane == 0) vb->nW = nW + (warm == 0x9E3779B9u && lane == 64 ? 1u : 0u);   // (keeps the prefetches alive)
             PH_MARK(ctr, 6);
             duo_reply(box, seq, lane);
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(128, 2) void k_search_duo(GraphView g, const float 
             for (uint32_t lc = lmax; lc >= 1; --lc) {  // core.rs:870-874: a handful of expansions each, the walker alone
                 search_level_lean<VEC, 1, BB, DB, WIDE>(g, Wbuf, vis, qr, ep, 1, lc, ctr, lane, &g.hdr->ctr_search[3]);
                 ep = key_id(Wbuf[0]);                  // core.rs:872
-                __builtin_amdgcn_wave_barrier();
+                lds_order();
             }
             nW = duo_walk<VEC, BB, DB, WIDE>(g, Wbuf, box, seq, vis, qr, ep, ef, 0, ctr, lane);   // core.rs:876
             if (nW == kEmpty)

@@ -31,7 +31,7 @@ __device__ __forceinline__ void tagset_clear(TagSet<BB, DB> &v, int lane)
     for (uint32_t i = 0; i < (1u << BB) / 64; ++i) t4[i * 64 + lane] = e;
     v.count = 0;
     v.lossy = false;
-    __builtin_amdgcn_wave_barrier();
+    lds_order();
 }
 
 // Test-and-set of one id per lane flagged `valid` (ids of one adjacency row: all distinct).  Returns "was not
@@ -236,14 +236,14 @@ __device__ __forceinline__ uint32_t merge_apply_lean(uint64_t (&w)[R], uint64_t 
 #pragma unroll
     for (int r = 0; r < R; ++r) Wbuf[(uint32_t)(r * 64 + lane) + up[r]] = w[r];
     Wbuf[take ? mypos : LeanW<R>::kTrash] = nk;
-    __builtin_amdgcn_wave_barrier();                    // one wave owns Wbuf; the LDS serves it in issue order
+    lds_order();                    // one wave owns Wbuf; the LDS serves it in issue order
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint64_t v = Wbuf[r * 64 + lane];
         w[r] = (uint32_t)(r * 64 + lane) < cap ? v : ~0ull;
     }
     worst = Wbuf[cap - 1];
-    __builtin_amdgcn_wave_barrier();
+    lds_order();
     return total;
 }
 
@@ -450,7 +450,7 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
     nW = merge_regs_lean<R>(w, Wbuf, nW, ef, pkey, ptake, lane, worst);
 #pragma unroll
     for (int r = 0; r < R; ++r) Wbuf[r * 64 + lane] = w[r];
-    __builtin_amdgcn_wave_barrier();
+    lds_order();
     (void)ckey;
     if constexpr (LOG) occ_finalize_search_log(ctr, log_start, lc, nW == ef ? Wbuf[ef - 1] : ~0ull, lane);
     else (void)log_start;
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(64, VEC::MIN_WAVES) void k_search_lean(GraphView g,
         for (uint32_t lc = lmax; lc >= 1; --lc) {  // core.rs:870-874
             search_level_lean<VEC, 1, BB, DB, WIDE>(g, Wbuf, vis, qr, ep, 1, lc, ctr, lane, &g.hdr->ctr_search[3]);
             ep = key_id(Wbuf[0]);                  // core.rs:872
-            __builtin_amdgcn_wave_barrier();
+            lds_order();
         }
         const uint32_t nW = search_level_lean<VEC, R, BB, DB, WIDE>(g, Wbuf, vis, qr, ep, ef, 0, ctr, lane, &g.hdr->ctr_search[3]); // core.rs:876
         // core.rs:878-890: nearest first, min(k, |W|) results; sim = -dist (metrics.rs:75)
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(64, VEC::MIN_WAVES) void k_search_lean(GraphView g,
             out_sims[(size_t)qi * k + i] = i < nres ? -key_dist(key) : -__builtin_inff();
         }
         if (lane == 0) out_n[qi] = nres;
-        __builtin_amdgcn_wave_barrier();
+        lds_order();
     }
     if (lane == 0) {
         atomicAdd(&g.hdr->ctr_search[0], (unsigned long long)ctr.n_dist);

@@ -2,6 +2,7 @@
 // k_search_duo<VEC,R,BB,DB,WIDE>, a walker and a W-keeper wavefront per query) for f32 rows, HNSW_VARIANT 0: rows
 // of <= 63 ids, 1: rows of 64..127 ids, and its launcher.  Chosen by try_launch_lean when few enough queries are
 // in flight that every query can have two SIMDs (hnsw_engine.hip).
+#define HNSW_SYNC_BLOCK   // search / engine unit: 64-thread workgroups handing over through LDS only (hnsw_device.hpp)
 #include "hnsw_host.hpp"
 #include "hnsw_search_duo.hpp"
 

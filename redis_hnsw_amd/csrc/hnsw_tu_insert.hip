@@ -1,6 +1,6 @@
 // hnsw_tu_insert.hip -- HNSW.NODE.ADD / HNSW.NODE.DEL kernels of one metric variant (HNSW_VARIANT, see
 // hnsw_host.hpp): k_insert_plan, k_insert_commit_exact, k_delete_exact, k_shrink_batch, and their launchers.
-#include "hnsw_wave_sync.hpp"   // one-wave workgroups: "__syncthreads()" = the wave's own full synchronisation
+#define HNSW_SYNC_WAVE_FULL   // the shared code is run by one wavefront per copy and hands over through HBM too (hnsw_wave_sync.hpp)
 #include "hnsw_host.hpp"
 
 namespace hnsw_host {
@@ -71,6 +71,7 @@ hnsw_status launch_delete_r(hnsw_index *h, const InsertCfg &c, uint32_t id)
         HNSW_DEL_CASE(4)
         HNSW_DEL_CASE(8)
         HNSW_DEL_CASE(16)
+        HNSW_DEL_CASE(64)                                 // ef_construction > 1024 (W in LDS), like launch_insert_r / occ_delete_r
     }
 #undef HNSW_DEL_CASE
     return fail(h, HNSW_ERR_INVALID, "bad R");

@@ -1,6 +1,7 @@
 // hnsw_tu_lean.hip -- the specialised dim-128 search kernel k_search_lean<VEC,R,BB,DB,WIDE> for one vector format
 // and row width (HNSW_VARIANT 0: f32 rows, the reference's data; 1: the bf16 serving copy; 2 / 3: the same two
 // for adjacency rows of 64..127 ids; 4 / 5: the fp8 serving copy, narrow / wide rows) and its launcher.
+#define HNSW_SYNC_BLOCK   // search / engine unit: 64-thread workgroups handing over through LDS only (hnsw_device.hpp)
 #include "hnsw_host.hpp"
 #include "hnsw_search_lean.hpp"
 

@@ -1,7 +1,7 @@
 // hnsw_tu_occ.hip -- the exact-order parallel insert (hnsw_occ.hpp) for one metric variant (HNSW_VARIANT, see
 // hnsw_host.hpp): k_occ_validate, k_occ_plan, k_occ_shrinks, k_occ_commit and the launcher of one round; k_occ_del_list,
 // k_occ_del_commit and the launcher of a delete.
-#include "hnsw_wave_sync.hpp"   // one-wave workgroups: "__syncthreads()" = the wave's own full synchronisation
+#define HNSW_SYNC_WAVE_FULL   // the shared code is run by one wavefront per copy and hands over through HBM too (hnsw_wave_sync.hpp)
 #include "hnsw_host.hpp"
 
 namespace hnsw_host {
@@ -41,7 +41,7 @@ static hnsw_status occ_round_t(hnsw_index *h, const InsertCfg &c, const OccBufs 
     hipLaunchKernelGGL(ks, dim3(count * kOccInsShr), dim3(64), c.lds, h->stream, gv, ob, head, count, h->m, c.lnb, c.lcap, h->d_spill,
                        h->spill_gnb, kEmpty, kOccInsShr);
     bool team = false;
-    if (h->commit_par && count > 1 && !h->occ_want_touched) {
+    if (count > 1 && !h->occ_want_touched && (h->commit_par == 2 || (h->commit_par == 1 && h->occ_yield * 10.0 >= (double)h->commit_par_min_x10))) {
         // the window's commits in validated parallel groups, one workgroup per window node (hnsw_occ_par.hpp)
         HIP_TRY(h, hipGetLastError());
         hnsw_status ps = occ_commit_par_r<MODE, T>(h, c, ob, count, end_node, &team);

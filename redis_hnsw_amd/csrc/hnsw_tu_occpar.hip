@@ -1,16 +1,67 @@
 // hnsw_tu_occpar.hip -- the round's commits in validated parallel groups (hnsw_occ_par.hpp: k_occ_commit_par) for one
 // metric variant (HNSW_VARIANT, see hnsw_host.hpp), and its launcher.
-#include "hnsw_wave_sync.hpp"   // one-wave workgroups: "__syncthreads()" of the shared insert code = the wave's own full synchronisation
+#define HNSW_SYNC_WAVE_FULL   // the shared code is run by one wavefront per copy and hands over through HBM too (hnsw_wave_sync.hpp)
 #include "hnsw_host.hpp"
 #include "hnsw_occ_par.hpp"
 
 namespace hnsw_host {
+
+constexpr int kParHelpers = 3;
+
+// the helpers' LDS share and visited table, from what the committing wave leaves of the CU's LDS (as hnsw_tu_occteam.hip)
+template <int T>
+static bool par_team_cfg(const hnsw_index *h, const InsertCfg &c, TeamCfg *tc, size_t *lds_total)
+{
+    const size_t cap = 160 * 1024 - 2048;
+    const size_t base = kOccScratchBytes + kParLdsBytes + c.lds + sizeof(TeamTask) + (size_t)kTeamCand * 8;
+    if (base >= cap) return false;
+    const size_t per = ((cap - base) / kParHelpers) & ~(size_t)63;
+    const size_t fixed = team_fixed_bytes(T, h->dim);
+    if (per < fixed + 2048) return false;
+    const size_t tb = per - fixed;
+    tc->hbytes = (uint32_t)per;
+    tc->lnb = (uint32_t)(tb / 32);
+    tc->lcap = tc->lnb * h->lds_fill_x2 / 2;
+    tc->tagcfg = 0;
+    if (c.tagcfg) {
+        const uint32_t idbits = c.tagcfg >> 8;
+        uint32_t bb = 0;
+        while (((size_t)16 << (bb + 1)) <= tb && bb + 1 <= 12) ++bb;
+        if (bb >= 2 && idbits >= bb && idbits - bb <= 13) {
+            tc->tagcfg = bb | (idbits << 8);
+            tc->lcap = (1u << bb) * 6u;
+        }
+    }
+    tc->gnb = h->spill_gnb;
+    *lds_total = base + per * kParHelpers;
+    return h->spill_slots >= 64u + 64u * kParHelpers;
+}
 
 template <int MODE, int T, int R>
 static hnsw_status commit_par_t(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t count, uint32_t end_node, bool *done)
 {
     const size_t lds = kOccScratchBytes + kParLdsBytes + c.lds;
     if (lds > 160 * 1024 - 2048 || count > 64 || !h->d_par) return HNSW_OK;          // (the in-order kernel takes the round)
+    ParBufs pb = {reinterpret_cast<OccPar *>(h->d_par), reinterpret_cast<OccDelta *>(h->d_par_delta), h->d_par_rows, h->par_ovstride};
+    TeamCfg tc;
+    size_t lds_team = 0;
+    if (h->commit_team && par_team_cfg<T>(h, c, &tc, &lds_team)) {
+        auto kt = k_occ_commit_par<MODE, T, R, kParHelpers>;
+        {
+            static std::mutex mu;
+            static bool attr_set[16] = {false};
+            std::lock_guard<std::mutex> lock(mu);
+            if (!attr_set[h->device & 15]) {
+                HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+                attr_set[h->device & 15] = true;
+            }
+        }
+        hipLaunchKernelGGL(kt, dim3(count), dim3(64 * (1 + kParHelpers)), lds_team, h->stream, view_tag(h, c.tagcfg), ob, pb, end_node, h->m, c.lnb,
+                           c.lcap, h->d_spill, h->spill_gnb, h->d_plan, h->m + 2 + h->occ_slack_extra, (uint32_t)c.lds, tc);
+        HIP_TRY(h, hipGetLastError());
+        *done = true;
+        return HNSW_OK;
+    }
     auto kc = k_occ_commit_par<MODE, T, R>;
     {
         static std::mutex mu;
@@ -21,9 +72,8 @@ static hnsw_status commit_par_t(hnsw_index *h, const InsertCfg &c, const OccBufs
             attr_set[h->device & 15] = true;
         }
     }
-    ParBufs pb = {reinterpret_cast<OccPar *>(h->d_par), reinterpret_cast<OccDelta *>(h->d_par_delta), h->d_par_rows, h->par_ovstride};
     hipLaunchKernelGGL(kc, dim3(count), dim3(64), lds, h->stream, view_tag(h, c.tagcfg), ob, pb, end_node, h->m, c.lnb, c.lcap, h->d_spill,
-                       h->spill_gnb, h->d_plan, h->m + 2 + h->occ_slack_extra);
+                       h->spill_gnb, h->d_plan, h->m + 2 + h->occ_slack_extra, 0u, TeamCfg{});
     HIP_TRY(h, hipGetLastError());
     *done = true;
     return HNSW_OK;

@@ -6,7 +6,7 @@
 // the block has four wavefronts that each run that code on their own, with loops of different lengths, so in THIS
 // unit a block-level synchronisation of the shared code is the wave's own, and the only s_barriers are the team's
 // hand-overs (team_bar).
-#include "hnsw_wave_sync.hpp"   // "__syncthreads()" = this wave's own full synchronisation
+#define HNSW_SYNC_WAVE_FULL   // the shared code is run by one wavefront per copy and hands over through HBM too (hnsw_wave_sync.hpp)
 #include "hnsw_host.hpp"
 
 namespace hnsw_host {

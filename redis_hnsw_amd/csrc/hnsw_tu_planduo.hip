@@ -7,7 +7,7 @@
 // the compiler drops the s_barrier.  Here the block has a second wave that takes no part in any of that, and the
 // only s_barriers the first wave may execute are the two of each hand-over with the keeper: in THIS unit a block-level
 // synchronisation of the shared code is the wave's own (same fences, a wave barrier instead of s_barrier).
-#include "hnsw_wave_sync.hpp"   // "__syncthreads()" = this wave's own full synchronisation
+#define HNSW_SYNC_WAVE_FULL   // the shared code is run by one wavefront per copy and hands over through HBM too (hnsw_wave_sync.hpp)
 #include "hnsw_host.hpp"
 #include "hnsw_plan_lean.hpp"
 

@@ -1,7 +1,7 @@
 // hnsw_tu_planlean.hip -- the insert plans that search with the specialised dim-128 routine (hnsw_plan_lean.hpp):
 // k_insert_plan_lean (single hnsw_add) and k_occ_plan_lean (windowed exact build), for adjacency rows of at most
 // 63 ids (HNSW_VARIANT 0) or 127 ids (HNSW_VARIANT 1), and their launchers.
-#include "hnsw_wave_sync.hpp"   // one-wave workgroups: "__syncthreads()" = the wave's own full synchronisation
+#define HNSW_SYNC_WAVE_FULL   // the shared code is run by one wavefront per copy and hands over through HBM too (hnsw_wave_sync.hpp)
 #include "hnsw_host.hpp"
 #include "hnsw_plan_lean.hpp"
 

@@ -1,5 +1,6 @@
 // hnsw_tu_search.hip -- the general search kernel k_search<MODE,T,R,FMT> for one metric variant (HNSW_VARIANT 0..3,
 // see hnsw_host.hpp) or one compressed storage format (4: bf16 rows, 5: fp8 rows) and its launcher.
+#define HNSW_SYNC_BLOCK   // search / engine unit: 64-thread workgroups handing over through LDS only (hnsw_device.hpp)
 #include "hnsw_host.hpp"
 #include "hnsw_kernels.hpp"
 

@@ -24,17 +24,17 @@ res = dict(nodes=N, build_seconds=round(dt, 1), inserts_per_s=round(N / dt, 1), 
            commits_per_round=round(out[0] / max(out[5], 1), 2), speculative_shrinks=int(out[1]), recomputed_shrinks=int(out[2]),
            stale_plans=int(out[3]), journal_deltas_per_commit=round(out[4] / max(out[0], 1), 1))
 try:
-    pz = (C.c_uint64 * 5)()
+    pz = (C.c_uint64 * 21)()
     lib.hnsw_debug_occ_par.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.hnsw_debug_occ_par(gi._h, pz)
     if pz[0]:
-        it = max(out[12], 1)
+        it = max(pz[11], 1)
         res["parallel_commit"] = dict(groups=int(pz[0]), groups_per_round=round(pz[0] / max(out[5], 1), 2), nodes_per_group=round(out[0] / pz[0], 2),
                                       dry_runs_per_commit=round(pz[1] / max(out[0], 1), 2),
                                       groups_closed_by=dict(stale_link_plan=int(pz[2]), record_used=int(pz[3]), row_rewritten=int(pz[4])),
-                                      iterations=int(it), iterations_without_a_group=int(out[13]),
+                                      iterations=int(it), launches=int(pz[12]),
                                       us_per_iteration_workgroup0=dict(zip(("dry_run", "wait", "validate", "wait2", "apply", "wait3"),
-                                                                           [round(out[6 + i] / it / 100.0, 1) for i in range(6)])))
+                                                                           [round(pz[5 + i] / it / 100.0, 1) for i in range(6)])))
 except AttributeError:
     pass
 fx = FIXTURES[(1_000_000, dim, M, ef)]

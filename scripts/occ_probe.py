@@ -37,13 +37,16 @@ try:
 except AttributeError:
     pass
 try:
-    pz = (C.c_uint64 * 5)()
+    pz = (C.c_uint64 * 21)()
     lib.hnsw_debug_occ_par.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.hnsw_debug_occ_par(gi._h, pz)
     if pz[0]:
-        it = max(out[6 + 6], 1)
-        print("group commit kernel, us per iteration (workgroup 0): dry run %.1f, wait %.1f, validate %.1f, wait %.1f, apply %.1f, wait %.1f; %d iterations (%.2f per round), %d of them without a group" % (
-            tuple(out[6 + i] / it / 100.0 for i in range(6)) + (it, it / max(out[5], 1), out[6 + 7])))
+        it = max(pz[5 + 6], 1)
+        print("group commit kernel, us per iteration (workgroup 0): dry run %.1f, wait %.1f, validate %.1f, wait %.1f, apply %.1f, wait %.1f; %d iterations in %d launches (%.2f per launch)" % (
+            tuple(pz[5 + i] / it / 100.0 for i in range(6)) + (it, pz[5 + 7], it / max(pz[5 + 7], 1))))
+        nd = max(pz[1], 1)
+        print("a dry run, us (mean of %d): hash + journal check %.1f, connect %.1f, record checks %.1f, row + speculative result %.1f, recompute %.1f, update_connections %.1f, finish %.1f; slowest of an iteration %.1f" % (
+            (nd,) + tuple(pz[13 + i] / nd / 100.0 for i in range(7)) + (pz[20] / it / 100.0,)))
         print("parallel group commits: %d groups (%.2f per round, %.2f nodes per group), %d dry runs (%.2f per commit); groups closed by a stale link plan %d, "
               "a record used %d, a row rewritten %d" % (pz[0], pz[0] / max(out[5], 1), out[0] / pz[0], pz[1], pz[1] / nc, pz[2], pz[3], pz[4]))
 except AttributeError:

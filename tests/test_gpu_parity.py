@@ -664,6 +664,38 @@ def test_ef_construction_beyond_1024(eng, oracle_mod, n, dim, m, ef, k):
     gi.close()
 
 
+@pytest.mark.parametrize("n,dim,m,ef,tunings", [
+    (900, 32, 32, 1500, {}),                       # nodes of level >= 1 hold more than 64 links over their layers: the speculative delete declines
+    (900, 32, 48, 1200, {"single_window": 0}),     # the serial delete kernel for every node
+    (700, 32, 16, 2000, {"occ_window": 0}),
+    (600, 32, 70, 1100, {}),                       # M > 64: serial kernels only
+])
+def test_deletes_beyond_ef_1024_take_the_serial_kernel_too(eng, oracle_mod, n, dim, m, ef, tunings):
+    """ef_construction > 1024 keeps W in LDS (R = 64).  HNSW.NODE.DEL falls back to the one-wave k_delete_exact whenever the
+    speculative form declines -- a node with more than 64 neighbours over all its layers, single_window = 0, no window,
+    M > 64 -- and that kernel has to exist for R = 64 as well (round 4's advisor finding: it did not)."""
+    V = make_data(n, dim, seed=85)
+    lv = oracle_mod.draw_levels(n, m, 9)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch(V, lv)
+    gi = eng.Index("del-bigef", dim, m, ef)
+    for key, val in tunings.items():
+        gi.set_tuning(key, val)
+    gi.add_batch(V, levels=lv, mode="exact")
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    upper = [int(i) for i in np.nonzero(lv >= 1)[0][:6]]
+    for v in upper + [5, 123, 400]:
+        if not o.is_live(v):
+            continue
+        o.delete(v)
+        gi.delete_node("node%d" % v)
+        ok, why = graphs_equal(o.export(), gi.export_graph())
+        assert ok, "after deleting %d: %s" % (v, why)
+    gi.close()
+    o.close()
+
+
 def test_restride_keeps_the_graph(eng, oracle_mod):
     """widening the adjacency tables (what the engine does when degrees approach the row capacity)
     in the middle of an exact build must not change anything"""
@@ -920,6 +952,54 @@ def test_windowed_exact_build_is_the_serial_graph(eng, oracle_mod, n, dim, m, ef
     ok, why = graphs_equal(o.export(), gi.export_graph())
     assert ok, why
     gi.close()
+
+
+@pytest.mark.parametrize("n,dim,m,ef,window", [
+    (2500, 128, 16, 200, 32),    # the C2 shape
+    (1500, 12, 4, 24, 16),       # scalar metric order, m = 4: enterpoint changes inside groups
+    (1200, 768, 32, 400, 16),    # wide rows, R = 8
+    (3000, 8, 2, 8, 16),         # m = 2: restrides between rounds, rows that do not fill
+    (12000, 32, 8, 64, 48),
+])
+def test_parallel_validated_commits_build_the_serial_graph(eng, oracle_mod, n, dim, m, ef, window):
+    """commit_par = 2: every round's commits go through k_occ_commit_par (hnsw_occ_par.hpp) -- one workgroup per window
+    node runs its whole commit in a private overlay of the rows it rewrites, nodes whose reads and rows the earlier
+    nodes' deltas do not touch are applied together as a group (the rules were proven on the CPU,
+    tests/experiments/occ_model.c PAR=1).  The graph must be the oracle's serial graph row for row, the same as with
+    the in-order commit wave (commit_par = 0), with groups of more than one node actually formed."""
+    import ctypes as C
+    V = make_data(n, dim, seed=91)
+    lv = oracle_mod.draw_levels(n, m, 5)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch(V, lv)
+    want = o.export()
+    lib = eng._capi.load()
+    lib.hnsw_debug_occ_par.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.hnsw_debug_occ.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    for par in (2, 0):
+        gi = eng.Index("p%d" % par, dim, m, ef)
+        gi.set_tuning("occ_window", window)
+        gi.set_tuning("commit_par", par)
+        half = n // 2
+        gi.add_batch(V[:half], levels=lv[:half], mode="exact")
+        gi.add_batch(V[half:], levels=lv[half:], mode="exact")
+        ok, why = graphs_equal(want, gi.export_graph())
+        assert ok, "commit_par=%d: %s" % (par, why)
+        pz, oc = (C.c_uint64 * 21)(), (C.c_uint64 * 16)()
+        assert lib.hnsw_debug_occ_par(gi._h, pz) == 0 and lib.hnsw_debug_occ(gi._h, oc) == 0
+        if par:
+            assert pz[0] > 0 and oc[0] > pz[0], "no group of more than one node was formed: %d commits in %d groups" % (oc[0], pz[0])
+        else:
+            assert pz[0] == 0
+        Q = make_data(16, dim, seed=3)
+        ids, sims, n_out = gi.search_batch(Q, 5)
+        oids, osims, on, _ = o.search_batch(Q, 5)
+        assert np.array_equal(n_out, on)
+        for i in range(len(Q)):
+            c = int(on[i])
+            assert np.array_equal(ids[i, :c], oids[i, :c]) and np.array_equal(_bits(sims[i, :c]), _bits(osims[i, :c]))
+        gi.close()
+    o.close()
 
 
 def test_windowed_exact_build_on_clustered_and_duplicated_data(eng, oracle_mod):
