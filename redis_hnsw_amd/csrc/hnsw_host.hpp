@@ -99,6 +99,8 @@ struct hnsw_index {
     void *d_par = nullptr, *d_par_delta = nullptr;
     uint32_t *d_par_rows = nullptr;
     uint32_t par_ovstride = 0;
+    bool plan_split = true;         // tuning: a far node's upper layers are planned a round early (OccSlot::stage, hnsw_plan_lean.hpp)
+    uint32_t plan_split_pos = 0xFFFFFFFFu;   // ... from this window position on, for the round being launched (set by add_exact_window)
     int commit_par = 1;             // tuning: a window's commits go in validated parallel groups (hnsw_occ_par.hpp): 0 never (the in-order commit
                                     // wave only), 1 when the window has been committing at least commit_par_min_x10 / 10 nodes per round (a group
                                     // costs one dry run whatever its size: below ~5 nodes per round the in-order wave is as fast), 2 always

@@ -359,6 +359,98 @@ __device__ __forceinline__ void update_connections(const GV &g, const WaveMem &m
                                    uint32_t *touched, uint32_t touched_cap, uint32_t &nt, int lane,
                                    OccJournal *jr = nullptr)
 {
+    // The rows of the lanes flagged in `mask` (x = each lane's row id) lose e (remove) or gain it (append).  Each row is
+    // edited by the whole wave -- one row load, one ballot, one store of the row's live words -- and the loads of up to
+    // four rows are in flight together (a lone wave pays a full memory round trip per dependent load; a shrink touches
+    // two to four rows).  The live words are rewritten whole: row_rewrite hands an overlay's scratch row out empty and
+    // this very store fills it.
+    auto edit_rows = [&](uint64_t mask, uint32_t x, bool remove) {
+        while (mask) {
+            const uint32_t *xs[4];
+            uint32_t *xr[4];
+            uint32_t wxs[4];
+            int n = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xs[u] = nullptr; xr[u] = nullptr;
+                if (mask) {
+                    const int j = __ffsll((unsigned long long)mask) - 1;
+                    mask &= mask - 1;
+                    const uint32_t xj = (uint32_t)__builtin_amdgcn_readlane((int)x, j);
+                    xr[u] = row_rewrite(g, xj, lc, lane, &xs[u]);
+                    n = u + 1;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) wxs[u] = (u < n && (uint32_t)lane < stride) ? xs[u][lane] : kEmpty;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u >= n) break;
+                const uint32_t *xsrc = xs[u];
+                uint32_t *xrow = xr[u];
+                const uint32_t wx = wxs[u];
+                uint32_t xc1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wx);   // (lane 0 = the count)
+                if (xc1 > stride - 1) xc1 = stride - 1;
+                if (remove) {
+                    if (xc1 <= 63) {                                    // rows of <= 63 ids: the 64 words just loaded are the row
+                        const uint64_t hit = __ballot(lane >= 1 && (uint32_t)lane <= xc1 && wx == e);
+                        if (!hit) {                                                            // reference panics, :150
+                            if (lane == 0) atomicOr(&g.hdr->status, ST_ASYMMETRIC);
+                            if ((uint32_t)lane <= xc1) xrow[lane] = wx;
+                        } else {
+                            const int pos = __ffsll((unsigned long long)hit) - 1;              // word index of e
+                            const uint32_t nxt = (uint32_t)__shfl_down((int)wx, 1, 64);         // word lane + 1
+                            if ((uint32_t)lane < xc1) xrow[lane] = lane == 0 ? xc1 - 1 : (lane >= pos ? nxt : wx);
+                        }
+                        continue;
+                    }
+                    if (xsrc != xrow) { for (uint32_t i = lane; i < stride; i += 64) xrow[i] = xsrc[i]; wave_sync(); }   // wide rows: copy, then edit in place
+                    const uint32_t xc = xc1;
+                    bool found = false;
+                    for (uint32_t b2 = 0; b2 < xc; b2 += 64) {          // rows wider than 63 ids: more than one pass
+                        const uint32_t p = b2 + lane;
+                        const uint32_t v = p < xc ? xrow[1 + p] : kEmpty;
+                        const uint32_t vnext = p + 1 < xc ? xrow[2 + p] : kEmpty;
+                        const uint64_t hit = __ballot(p < xc && v == e);
+                        if (!found && hit) {
+                            found = true;
+                            const uint32_t pos = b2 + (uint32_t)(__ffsll((unsigned long long)hit) - 1);
+                            wave_sync();
+                            if (p >= pos && p + 1 < xc) xrow[1 + p] = vnext;
+                        } else if (found) {
+                            wave_sync();
+                            if (p + 1 < xc) xrow[1 + p] = vnext;
+                        }
+                    }
+                    if (!found) { if (lane == 0) atomicOr(&g.hdr->status, ST_ASYMMETRIC); }   // reference panics, :150
+                    else if (lane == 0) xrow[0] = xc - 1;
+                } else {
+                    if (xc1 < 63) {                                     // the row and the appended slot are words 0..63
+                        const bool there = __ballot(lane >= 1 && (uint32_t)lane <= xc1 && wx == e) != 0;
+                        if (there || xc1 + 1 > stride - 1) {
+                            if (!there && lane == 0) atomicOr(&g.hdr->status, ST_ROW_OVERFLOW);
+                            if ((uint32_t)lane <= xc1) xrow[lane] = wx;
+                        } else {
+                            if ((uint32_t)lane <= xc1 + 1) xrow[lane] = lane == 0 ? xc1 + 1 : ((uint32_t)lane == xc1 + 1 ? e : wx);
+                            if (lane == 0) atomicMax(maxdeg, xc1 + 1);
+                        }
+                        continue;
+                    }
+                    if (xsrc != xrow) { for (uint32_t i = lane; i < stride; i += 64) xrow[i] = xsrc[i]; wave_sync(); }   // wide rows: copy, then edit in place
+                    const uint32_t xc = xc1;
+                    bool present = false;
+                    for (uint32_t b2 = 0; b2 < xc; b2 += 64) {
+                        const uint32_t p = b2 + lane;
+                        present |= __ballot(p < xc && xrow[1 + p] == e) != 0;
+                    }
+                    if (!present && lane == 0) {
+                        if (xc + 1 > stride - 1) atomicOr(&g.hdr->status, ST_ROW_OVERFLOW);
+                        else { xrow[1 + xc] = e; xrow[0] = xc + 1; atomicMax(maxdeg, xc + 1); }
+                    }
+                }
+            }
+        }
+    };
     uint32_t kept = 0;
     for (uint32_t base = 0; base < cnt; base += 64) {
         const uint32_t i = base + lane;
@@ -369,55 +461,9 @@ __device__ __forceinline__ void update_connections(const GV &g, const WaveMem &m
         const uint64_t kb = __ballot(inS);
         if (inS) erow[1 + kept + __popcll(kb & lanemask_lt(lane))] = x;
         kept += __popcll(kb);
-        // bidirectionally remove old-but-not-new (:805-819).  Each dropped neighbour's row is edited by the
-        // whole wave (one row load, one ballot, one shifted store) instead of one lane walking it word by word.
+        // bidirectionally remove old-but-not-new (:805-819)
         const bool drop = i < cnt && !inS && x != ignored;
-        uint64_t dm = __ballot(drop);
-        while (dm) {
-            const int j = __ffsll((unsigned long long)dm) - 1;
-            dm &= dm - 1;
-            const uint32_t xj = (uint32_t)__builtin_amdgcn_readlane((int)x, j);
-            // the first 64 words in one load (lane 0 = the count): rows of <= 63 ids need nothing else, one round
-            // trip instead of two.  The live words are rewritten whole (row_rewrite: an overlay's scratch row is filled
-            // by this very store)
-            const uint32_t *xsrc;
-            uint32_t *xrow = row_rewrite(g, xj, lc, lane, &xsrc);
-            const uint32_t wx = (uint32_t)lane < stride ? xsrc[lane] : kEmpty;
-            uint32_t xc1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wx);
-            if (xc1 > stride - 1) xc1 = stride - 1;
-            if (xc1 <= 63) {
-                const uint64_t hit = __ballot(lane >= 1 && (uint32_t)lane <= xc1 && wx == e);
-                if (!hit) {                                                                // reference panics, :150
-                    if (lane == 0) atomicOr(&g.hdr->status, ST_ASYMMETRIC);
-                    if ((uint32_t)lane <= xc1) xrow[lane] = wx;
-                } else {
-                    const int pos = __ffsll((unsigned long long)hit) - 1;                  // word index of e
-                    const uint32_t nxt = (uint32_t)__shfl_down((int)wx, 1, 64);             // word lane + 1
-                    if ((uint32_t)lane < xc1) xrow[lane] = lane == 0 ? xc1 - 1 : (lane >= pos ? nxt : wx);
-                }
-                continue;
-            }
-            if (xsrc != xrow) { for (uint32_t i = lane; i < stride; i += 64) xrow[i] = xsrc[i]; wave_sync(); }   // wide rows: copy, then edit in place
-            const uint32_t xc = xc1;
-            bool found = false;
-            for (uint32_t b2 = 0; b2 < xc; b2 += 64) {          // rows wider than 63 ids: more than one pass
-                const uint32_t p = b2 + lane;
-                const uint32_t v = p < xc ? xrow[1 + p] : kEmpty;
-                const uint32_t vnext = p + 1 < xc ? xrow[2 + p] : kEmpty;
-                const uint64_t hit = __ballot(p < xc && v == e);
-                if (!found && hit) {
-                    found = true;
-                    const uint32_t pos = b2 + (uint32_t)(__ffsll((unsigned long long)hit) - 1);
-                    wave_sync();
-                    if (p >= pos && p + 1 < xc) xrow[1 + p] = vnext;
-                } else if (found) {
-                    wave_sync();
-                    if (p + 1 < xc) xrow[1 + p] = vnext;
-                }
-            }
-            if (!found) { if (lane == 0) atomicOr(&g.hdr->status, ST_ASYMMETRIC); }   // reference panics, :150
-            else if (lane == 0) xrow[0] = xc - 1;
-        }
+        edit_rows(__ballot(drop), x, true);
         touch_push(touched, touched_cap, nt, x, drop, lane); // :816
         journal_push(jr, drop, e, lc, x, false, lane);
         journal_push(jr, drop, x, lc, e, false, lane);
@@ -431,39 +477,7 @@ __device__ __forceinline__ void update_connections(const GV &g, const WaveMem &m
             for (uint32_t i = 0; i < cnt; ++i) isNew &= m.aux[i] != x;
         const uint64_t nb = __ballot(isNew);
         if (isNew) erow[1 + kept + __popcll(nb & lanemask_lt(lane))] = x;
-        uint64_t am = nb;
-        while (am) {                                            // wave-cooperative append of e to each new neighbour's row
-            const int j = __ffsll((unsigned long long)am) - 1;
-            am &= am - 1;
-            const uint32_t xj = (uint32_t)__builtin_amdgcn_readlane((int)x, j);
-            const uint32_t *xsrc;
-            uint32_t *xrow = row_rewrite(g, xj, lc, lane, &xsrc);
-            const uint32_t wx = (uint32_t)lane < stride ? xsrc[lane] : kEmpty;
-            uint32_t xc1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wx);
-            if (xc1 > stride - 1) xc1 = stride - 1;
-            if (xc1 < 63) {                                         // the row and the appended slot are words 0..63
-                const bool there = __ballot(lane >= 1 && (uint32_t)lane <= xc1 && wx == e) != 0;
-                if (there || xc1 + 1 > stride - 1) {
-                    if (!there && lane == 0) atomicOr(&g.hdr->status, ST_ROW_OVERFLOW);
-                    if ((uint32_t)lane <= xc1) xrow[lane] = wx;
-                } else {
-                    if ((uint32_t)lane <= xc1 + 1) xrow[lane] = lane == 0 ? xc1 + 1 : ((uint32_t)lane == xc1 + 1 ? e : wx);
-                    if (lane == 0) atomicMax(maxdeg, xc1 + 1);
-                }
-                continue;
-            }
-            if (xsrc != xrow) { for (uint32_t i = lane; i < stride; i += 64) xrow[i] = xsrc[i]; wave_sync(); }   // wide rows: copy, then edit in place
-            const uint32_t xc = xc1;
-            bool present = false;
-            for (uint32_t b2 = 0; b2 < xc; b2 += 64) {
-                const uint32_t p = b2 + lane;
-                present |= __ballot(p < xc && xrow[1 + p] == e) != 0;
-            }
-            if (!present && lane == 0) {
-                if (xc + 1 > stride - 1) atomicOr(&g.hdr->status, ST_ROW_OVERFLOW);
-                else { xrow[1 + xc] = e; xrow[0] = xc + 1; atomicMax(maxdeg, xc + 1); }
-            }
-        }
+        edit_rows(nb, x, false);                                // e appended to each new neighbour's row
         kept += __popcll(nb);
         journal_push(jr, isNew, e, lc, x, true, lane);
         journal_push(jr, isNew, x, lc, e, true, lane);

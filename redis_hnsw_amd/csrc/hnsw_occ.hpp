@@ -43,6 +43,12 @@ struct OccShr {
 struct OccSlot {
     uint32_t node, planned, snap, epoch;
     uint32_t n_reads, n_shr, top, fail;     // fail: the plan could not be logged (log overflow, visited overflow)
+    // A plan in two stages (k_occ_plan_lean): a node with a level >= 1 that is far from the window's head has its upper
+    // layers searched a round EARLY (stage 1: descent, layers top..1, their plan rows and read-log entries, the entry
+    // point of layer 0); the next round's plan kernel does layer 0 only -- so no launch waits for one node's two full
+    // searches.  The reads of layers >= 1 date from snapU, those of layer 0 (and the speculative records) from snap:
+    // occ_check_range ignores layer-0 deltas older than snap.
+    uint32_t stage, snapU, ep_l0, n_reads_u;
 };
 enum { OCC_WHY_ROW = 1, OCC_WHY_OPEN = 2, OCC_WHY_ADD = 4, OCC_WHY_REMOVE = 8 };   // why a speculative shrink is stale (flags[2 + sub]; the first cause met, later entries are not looked at)
 enum { OCC_STOP_NONE = 0, OCC_STOP_REPLAN = 1, OCC_STOP_RESTRIDE = 2, OCC_STOP_SERIAL = 3 };
@@ -142,8 +148,10 @@ template <int MODE, int T>
 __device__ __forceinline__ void occ_check_range(const GraphView &g, const WaveMem &m, const OccScratch &sc, const OccBufs &ob,
                                                 const OccRead *reads, const OccShr *shr, uint32_t q, uint32_t from,
                                                 uint32_t to, int lane, bool shrinks_only = false, uint32_t own_base = kEmpty,
-                                                const OccDelta *src = nullptr)
+                                                const OccDelta *src = nullptr, uint32_t from0 = kEmpty)
 {
+    // from0 != kEmpty: the plan read layer 0 later than the upper layers (OccSlot): layer-0 deltas before journal index
+    // from0 were already in the graph when it did
     // src: the deltas come from this linear buffer (another node's dry run, hnsw_occ_par.hpp) instead of the journal ring
     (void)reads;
     const OccDelta *jsrc = src ? src : ob.ring;
@@ -159,7 +167,8 @@ __device__ __forceinline__ void occ_check_range(const GraphView &g, const WaveMe
         if (j < to) {
             // the committing node's own entries are mirrored in LDS (own_base = journal index of own[0])
             const OccDelta d = (j >= own_base && j - own_base < kOccOwn) ? sc.own[j - own_base] : jsrc[j & jmask];
-            const uint32_t key = (d.row << 5) | (d.lc_add & 31u);
+            const bool old0 = from0 != kEmpty && (d.lc_add & 31u) == 0u && (int32_t)(j - from0) < 0;
+            const uint32_t key = old0 ? kEmpty - 1u : (d.row << 5) | (d.lc_add & 31u);   // (a key no read has)
             const bool add = (d.lc_add & 256u) != 0;
             uint32_t h = occ_hash(key);
             while (sc.hkey[h] != kEmpty && sc.hkey[h] != key) h = (h + 1) & (kOccHash - 1);
@@ -214,14 +223,14 @@ __device__ __forceinline__ void occ_check_range(const GraphView &g, const WaveMe
             const uint64_t sm = __ballot(sel);
             const uint32_t nf = (uint32_t)__popcll(sm);
             const uint32_t idx = (uint32_t)__popcll(sm & lanemask_lt(lane));
-            wave_sync();
+            lds_order();                                  // (everything handed over in this loop lives in LDS or registers)
             if (sel) m.fresh[idx] = z;
             const uint32_t rid = rd ? sc.flags[2 + kOccMaxShr + rd - 1] : q;
             QReg<T> qr;
             load_query<MODE, T>(g.vec + (size_t)rid * g.dim, g.dim, qr, m.qlds, lane);
-            wave_sync();
+            lds_order();                                  // the reader's vector and the gather below are in flight together
             compute_dists<MODE, T>(g, qr, m, nf, lane);
-            wave_sync();
+            lds_order();
             if (sel && __float_as_uint(m.dsc[idx]) <= bound) {
                 if (rd) atomicOr(&sc.flags[1 + rd], was_add ? OCC_WHY_ADD : OCC_WHY_REMOVE);
                 else sc.flags[0] = 1;
@@ -237,7 +246,7 @@ __device__ __forceinline__ void occ_check_range(const GraphView &g, const WaveMe
 // them speculatively, one wave each), then the slot is published.  Shared by k_occ_plan and k_occ_plan_lean.
 __device__ __forceinline__ void occ_plan_finish(const GraphView &g, const OccBufs &ob, OccSlot *sl, OccShr *shr, const uint32_t *pl0,
                                                 WorkCtr &ctr, uint32_t id, uint32_t top, uint32_t mlinks, uint32_t log_cap,
-                                                uint32_t snap, uint32_t epoch, bool fail, Visited &vis, int lane)
+                                                uint32_t snap, uint32_t epoch, bool fail, Visited &vis, int lane, uint32_t snapU = kEmpty)
 {
     (void)ob;
     // ---- the shrinks the connect will trigger (core.rs:560-561): listed here, computed speculatively by
@@ -280,6 +289,7 @@ __device__ __forceinline__ void occ_plan_finish(const GraphView &g, const OccBuf
     __threadfence();
     if (lane == 0) {
         sl->node = id; sl->snap = snap; sl->epoch = epoch;
+        sl->snapU = snapU == kEmpty ? snap : snapU; sl->stage = 0u;
         sl->n_reads = ctr.log_n < kOccMaxReads ? ctr.log_n : kOccMaxReads;
         sl->n_shr = n_shr; sl->top = top; sl->fail = fail ? 1u : 0u;
         sl->planned = 1;
@@ -469,11 +479,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_validate(GraphView g, OccBufs ob,
     if (blockIdx.x >= count) return;
     const uint32_t id = first_node + blockIdx.x;
     OccSlot *sl = &ob.slots[id % ob.W];
-    if (!sl->planned || sl->node != id) return;
     const uint32_t nJ = ob.ctl->nJ;
-    if (sl->fail) return;                                   // the commit hands it to the serial path
-    if (sl->epoch != ob.ctl->epoch) { if (lane == 0) sl->planned = 0; return; }
-    if (sl->snap == nJ) return;
     OccScratch sc = occ_carve(smem);
     WaveMem m = {};
     unsigned char *p = smem + kOccScratchBytes;
@@ -482,14 +488,31 @@ __global__ __launch_bounds__(64, 1) void k_occ_validate(GraphView g, OccBufs ob,
     m.qlds = reinterpret_cast<float *>(p);
     const OccRead *reads = ob.reads + (size_t)(id % ob.W) * kOccMaxReads;
     const OccShr *shr = ob.shr + (size_t)(id % ob.W) * kOccMaxShr;
+    if (!sl->planned || sl->node != id) {
+        // a plan whose upper layers were searched a round early (stage 1): what it read so far against the journal
+        if (sl->node != id || sl->stage != 1u) return;
+        if (sl->epoch != ob.ctl->epoch) { if (lane == 0) sl->stage = 0u; return; }
+        if (sl->snapU == nJ) return;
+        occ_init_hash(sc, lane);
+        occ_build_hash(sc, reads, sl->n_reads_u, shr, 0u, lane);
+        occ_check_range<MODE, T>(g, m, sc, ob, reads, shr, id, sl->snapU, nJ, lane, false, kEmpty, nullptr, nJ);   // nothing of layer 0 was read yet
+        if (lane == 0) {
+            if (sc.flags[0]) { sl->stage = 0u; atomicAdd(&ob.ctl->n_stale, 1ull); }
+            else sl->snapU = nJ;
+        }
+        return;
+    }
+    if (sl->fail) return;                                   // the commit hands it to the serial path
+    if (sl->epoch != ob.ctl->epoch) { if (lane == 0) { sl->planned = 0; sl->stage = 0u; } return; }
+    if (sl->snap == nJ && sl->snapU == nJ) return;
     occ_init_hash(sc, lane);
     occ_build_hash(sc, reads, sl->n_reads, shr, sl->n_shr, lane);
-    occ_check_range<MODE, T>(g, m, sc, ob, reads, shr, id, sl->snap, nJ, lane);
+    occ_check_range<MODE, T>(g, m, sc, ob, reads, shr, id, sl->snapU, nJ, lane, false, kEmpty, nullptr, sl->snap);
     bool bad = sc.flags[0] != 0;
     for (uint32_t k = 0; k < sl->n_shr; ++k) bad |= sc.flags[2 + k] != 0;
     if (lane == 0) {
-        if (bad) { sl->planned = 0; atomicAdd(&ob.ctl->n_stale, 1ull); }
-        else sl->snap = nJ;
+        if (bad) { sl->planned = 0; sl->stage = 0u; atomicAdd(&ob.ctl->n_stale, 1ull); }
+        else { sl->snap = nJ; sl->snapU = nJ; }
     }
 }
 
@@ -703,14 +726,14 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit(GraphView g, Oc
         OCC_T(6);
         occ_build_hash(sc, reads, sl->n_reads, shr, n_shr, lane);
         OCC_T(0);
-        uint32_t checked = sl->snap;
-        occ_check_range<MODE, T>(g, m, sc, ob, reads, shr, id, checked, jr.n, lane);
+        uint32_t checked = sl->snapU;
+        occ_check_range<MODE, T>(g, m, sc, ob, reads, shr, id, checked, jr.n, lane, false, kEmpty, nullptr, sl->snap);
         checked = jr.n;
         OCC_T(1);
         if (sc.flags[0]) {                                   // the link plan is stale: re-plan (end of the round)
             wave_sync();
             occ_clear_hash(sc, sl->n_reads, lane);
-            if (lane == 0) sl->planned = 0;
+            if (lane == 0) { sl->planned = 0; sl->stage = 0u; }
             stop = OCC_STOP_REPLAN;
             break;
         }

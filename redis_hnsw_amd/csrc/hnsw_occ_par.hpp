@@ -295,9 +295,9 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g
                 live = 0; n_delta = 0; promotes = 0; n_spec = n_fallback = n_norec = 0; w_dist = w_ids = w_skipped = 0;
                 n_hash = sl->n_reads;
                 occ_build_hash(sc, reads, n_hash, shr, n_shr, lane);
-                occ_check_range<MODE, T>(g, m, sc, ob, reads, shr, id, sl->snap, nJ, lane);
+                occ_check_range<MODE, T>(g, m, sc, ob, reads, shr, id, sl->snapU, nJ, lane, false, kEmpty, nullptr, sl->snap);
                 if (sc.flags[0]) {                           // the link plan is stale against what is committed: re-plan
-                    if (lane == 0) sl->planned = 0;
+                    if (lane == 0) { sl->planned = 0; sl->stage = 0u; }
                     state = PAR_REPLAN;
                 } else {
                     n_dry += 1;

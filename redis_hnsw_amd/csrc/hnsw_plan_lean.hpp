@@ -165,8 +165,10 @@ template <int R, int DB, bool WIDE, bool DUO = false>
 __global__ __launch_bounds__(DUO ? 128 : 64, 1) void k_occ_plan_lean(GraphView g, OccBufs ob, uint32_t first_node, uint32_t count, uint32_t ef,
                                                       uint32_t mlinks, uint32_t lnb, uint32_t lcap, uint32_t *__restrict__ gspill,
                                                       uint32_t gnb, uint32_t *__restrict__ plan, uint32_t shortcut, uint32_t log_cap,
-                                                      uint32_t lean_off, uint32_t idbits)
+                                                      uint32_t lean_off, uint32_t idbits, uint32_t split_pos = kEmpty)
 {
+    // split_pos: a node at window position >= split_pos with a level >= 1 gets its UPPER layers planned now and layer 0 in
+    // the next round's launch (OccSlot::stage), so that no launch lasts two full searches for one node's sake
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const uint32_t id = first_node + blockIdx.x;
@@ -202,18 +204,30 @@ __global__ __launch_bounds__(DUO ? 128 : 64, 1) void k_occ_plan_lean(GraphView g
     const uint32_t ep0 = (uint32_t)g.hdr->enterpoint;       // core.rs:508
     const uint32_t l = g.levels[id];
     uint32_t *pl0 = plan + (size_t)slot * kMaxLayers * g.plan_stride;
+    const uint32_t top = lmax < l ? lmax : l;
+    // stage 1 done a round ago and still valid (k_occ_validate checked it against the journal): layer 0 only
+    const bool resume = sl->stage == 1u && sl->node == id && sl->epoch == epoch && top >= 1;
+    // far from the head, two or more layers to search: the upper ones now, layer 0 next round
+    const bool split = !resume && top >= 1 && blockIdx.x >= split_pos;
+    uint32_t snapU = snap;
 
     QReg<4> qr;
     load_query<MODE_AVX, 4>(g.vec + (size_t)id * g.dim, g.dim, qr, m.qlds, lane);
     PlanLean<R, DB, WIDE, true, DUO> pl_;
     pl_.init(smem + lean_off, idbits, qr);
     m.W = pl_.Wbuf;
-    bool fail = false;
+    bool fail = false, staged = false;
     uint32_t ep = ep0;
-    for (uint32_t lc = lmax; lc > l; --lc) ep = pl_.nearest(g, ep, lc, ctr, lane);       // core.rs:511-520
-    const uint32_t top = lmax < l ? lmax : l;
-    for (uint32_t lc1 = top + 1; lc1-- > 0 && !fail;) {     // core.rs:523
+    if (resume) {
+        ep = sl->ep_l0;
+        ctr.log_n = sl->n_reads_u;
+        snapU = sl->snapU;
+    } else {
+        for (uint32_t lc = lmax; lc > l; --lc) ep = pl_.nearest(g, ep, lc, ctr, lane);   // core.rs:511-520
+    }
+    for (uint32_t lc1 = resume ? 1u : top + 1; lc1-- > 0 && !fail;) {     // core.rs:523
         const uint32_t lc = lc1;
+        if (split && lc == 0 && ctr.log_n <= log_cap) { staged = true; break; }
         const uint32_t nW = pl_.search(g, ep, ef, lc, ctr, lane);                        // :524
         wave_sync();
         const uint32_t wnearest = key_id(m.W[0]);
@@ -243,10 +257,26 @@ __global__ __launch_bounds__(DUO ? 128 : 64, 1) void k_occ_plan_lean(GraphView g
         ep = wnearest;                                      // core.rs:576
         wave_sync();
     }
+    if (staged && !fail) {
+        // stage 1 ends here: the upper layers' plan rows, own rows and log entries are written; layer 0 starts from ep
+        pl_.finish(lane);
+        if (vis.glob_dirty) visited_clear(vis, lane);
+        __threadfence();
+        wave_sync();
+        if (lane == 0) {
+            sl->node = id; sl->planned = 0u; sl->epoch = epoch; sl->fail = 0u;
+            sl->snapU = snap; sl->ep_l0 = ep; sl->n_reads_u = ctr.log_n; sl->top = top;
+            sl->stage = 1u;
+            atomicAdd(&g.hdr->ctr_insert[0], (unsigned long long)ctr.n_dist);
+            atomicAdd(&g.hdr->ctr_insert[1], (unsigned long long)ctr.n_ids);
+            atomicAdd(&g.hdr->ctr_insert[2], (unsigned long long)ctr.n_expand);
+        }
+        return;
+    }
     pl_.finish(lane);
     __threadfence();
     wave_sync();
-    occ_plan_finish(g, ob, sl, shr, pl0, ctr, id, top, mlinks, log_cap, snap, epoch, fail, vis, lane);
+    occ_plan_finish(g, ob, sl, shr, pl0, ctr, id, top, mlinks, log_cap, snap, epoch, fail, vis, lane, snapU);
 }
 
 } // namespace hnsw

@@ -45,7 +45,7 @@ static hnsw_status occ_plan_duo_t(hnsw_index *h, const InsertCfg &c, const OccBu
         }
     }
     hipLaunchKernelGGL(kern, dim3(count), dim3(128), lds, h->stream, view_tag(h, c.tagcfg), ob, head, count, h->efc, h->m, c.lnb, c.lcap,
-                       h->d_spill, h->spill_gnb, h->d_plan, h->select_shortcut ? 1u : 0u, h->occ_log_cap, (uint32_t)c.lds, idbits);
+                       h->d_spill, h->spill_gnb, h->d_plan, h->select_shortcut ? 1u : 0u, h->occ_log_cap, (uint32_t)c.lds, idbits, h->plan_split_pos);
     HIP_TRY(h, hipGetLastError());
     return HNSW_OK;
 }

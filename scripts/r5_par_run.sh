@@ -1,9 +1,8 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r5f
-timeout 900 python -m pytest tests/test_bench_gpu.py -m gpu -x -q > gpurun_out/r5f/tests.log 2>&1
-tail -5 gpurun_out/r5f/tests.log
-timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/r5f/bench.json 2> gpurun_out/r5f/bench.err
-tail -4 gpurun_out/r5f/bench.err; python -c "
-import json; d=json.loads(open('gpurun_out/r5f/bench.json').read().strip().splitlines()[-1])
-print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'], d['setup_seconds'])
-print(d['gpu_exact_build_at_1m']); print(d['gpu_exact_build']['inserts_per_s'], d['single_add']['gpu_ms'], d['single_delete']['gpu_ms'])"
+mkdir -p gpurun_out/r5c
+for T in "occ_ahead_x10=20" "occ_ahead_x10=18,commit_par_min_x10=60"; do
+  TUNING=$T timeout 900 python scripts/exact_build_check.py > gpurun_out/r5c/build2_$T.json 2> gpurun_out/r5c/build2_$T.err
+  echo "$T: $(python -c "
+import json,sys; d=json.load(open('gpurun_out/r5c/build2_$T.json')); p=d.get('parallel_commit',{})
+print(d['build_seconds'], d['rounds'], d['commits_per_round'], d['stale_plans'], p.get('groups_per_round'), p.get('nodes_per_group'), p.get('dry_runs_per_commit'), p.get('us_per_iteration_workgroup0'), d.get('identical_to_oracle_serial_build'))")"
+done

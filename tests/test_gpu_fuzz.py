@@ -176,6 +176,12 @@ def test_random_op_sequences_match_the_oracle(eng, oracle_mod, kind, dim, m, ef,
     ("dupes", 100, 31, 200, 40, 70010, (("select_shortcut", 0), ("visited_bounded", 1), ("waves_per_cu", 1))),
     ("dupes", 96, 16, 200, 40, 70119, (("visited_bounded", 0), ("occ_min_batch", 2), ("occ_ahead_x10", 30), ("waves_per_cu", 1))),
     ("uniform", 128, 32, 700, 30, 5, (("waves_per_cu", 1),)),
+    # round 5: the windowed inserts of these sequences commit in validated parallel groups whatever their yield
+    # (commit_par = 2; tiny dense graphs, where nearly every node conflicts with its predecessor)
+    ("uniform", 128, 16, 200, 80, 500001, (("commit_par", 2), ("occ_min_batch", 2))),
+    ("lattice", 32, 4, 24, 120, 500002, (("commit_par", 2), ("occ_min_batch", 2), ("occ_window", 16))),
+    ("dupes", 12, 2, 8, 120, 500003, (("commit_par", 2), ("occ_min_batch", 2), ("commit_team", 0))),
+    ("clustered", 768, 32, 100, 40, 500004, (("commit_par", 2), ("occ_min_batch", 2))),
 ])
 def test_random_op_sequences_under_non_default_tunings(eng, oracle_mod, kind, dim, m, ef, n_ops, seed, tunings):
     test_random_op_sequences_match_the_oracle(eng, oracle_mod, kind, dim, m, ef, n_ops, seed, tunings)
