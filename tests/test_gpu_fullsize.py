@@ -1,7 +1,8 @@
 """Full-size evidence for the configurations BASELINE.json names, run by the driver with -m gpu:
 
   * C3 (1M x 768, M=32, ef=400, k=100, B=4096) -- the only configuration served by the dim-768 kernel
-    (k_search<MODE_AVX,24,8>): size-independent properties on the whole batch + bit-exact sampled parity.
+    (k_search<MODE_AVX,24,8>): size-independent properties on the whole batch + bit-exact sampled parity, on a fast-built
+    1 M graph and on a REFERENCE-ORDER 100 k graph (data/c3_ref_graph_100k.npz, the oracle's serial build).
   * the graph bench.py's headline is timed on -- the REFERENCE-ORDER fixture data/c2_ref_graph_1m.npz (the CPU
     oracle's serial build, core.rs:489-599) -- in the bench's launch shape (three 1024-query calls in flight on
     three streams, the bounded 16 KB visited table), through the engine's own pipeline (host buffers,
@@ -145,6 +146,59 @@ def test_reference_order_fixture_parity_in_the_bench_launch_shape(eng, oracle_mo
     assert np.array_equal(got, ids8[:4 * B]) and np.array_equal(_bits(gots), _bits(sims8[:4 * B]))
     info = gi.pipeline_info()
     assert info["overlap"] == 1, "the pipeline's streams serialise on this box: %r" % (info,)
+    gi.close(); o.close()
+
+
+FIXTURE_C3 = os.path.join(ROOT, "data", "c3_ref_graph_100k.npz")
+
+
+@pytest.mark.skipif(not os.path.exists(FIXTURE_C3), reason="data/c3_ref_graph_100k.npz is missing")
+def test_c3_search_on_a_reference_order_graph(eng, oracle_mod):
+    """C3's kernel (dim 768, M = 32, ef = 400, k = 100, B = 4096: k_search<MODE_AVX,24,8>) on a REFERENCE-ORDER graph: the
+    oracle's serial build (core.rs:489-599) of 100 k x 768 vectors, a committed fixture (tests/fixtures/make_ref_graph.py
+    --nodes 100000 --dim 768 --m 32 --ef 400; ~1 h on one core -- the windowed GPU build manages 415 inserts/s at this
+    shape, DESIGN 4.2f, so the graph cannot be built inside a test).  Unlike the fast-built graphs C3 was searched on
+    before, this one has what the reference's insert leaves behind: rows above m_max0 = 64 (third parties gain links
+    without a shrink, core.rs:790-796) and the stored order of the serial build.  Whole-batch properties in C3's launch
+    shape, then sampled parity with the oracle searching the same graph: ids, similarity bits, n_out, work counters."""
+    import torch
+    from bench import load_graph_fixture
+    N, dim, M, ef, k, B = 100_000, 768, 32, 400, 100, 4096
+    V = np.random.default_rng(1).random((N, dim), dtype=np.float32)
+    Q = np.random.default_rng(2).random((B, dim), dtype=np.float32)
+    graph, _ = load_graph_fixture(FIXTURE_C3, V)
+    deg0 = np.diff(graph["row_ptr"][0].astype(np.int64))
+    assert deg0.max() > 2 * M                                              # over-degree rows: a reference-shaped graph
+    gi = eng.Index("c3-ref", dim, M, ef)
+    gi.import_graph(graph)
+    ids, sims, n_out = gi.search_batch(Q, k)                               # through the engine's pipeline (4 chunks of 1024)
+    assert np.all(n_out == k) and np.all(ids < N)
+    assert np.all(sims[:, :-1] >= sims[:, 1:]) and np.all(sims <= 0)
+    assert all(len(set(r.tolist())) == k for r in ids[::32])
+    dev = torch.device("cuda", 0)
+    dQ = torch.from_numpy(Q).to(dev)
+    d_ids = torch.empty((B, k), dtype=torch.int32, device=dev)
+    d_sims = torch.empty((B, k), dtype=torch.float32, device=dev)
+    d_n = torch.empty((B,), dtype=torch.int32, device=dev)
+    gi.search_batch_device(dQ.data_ptr(), B, k, d_ids.data_ptr(), d_sims.data_ptr(), d_n.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()                                               # ... and as ONE launch of 4096 queries (C3's shape)
+    assert np.array_equal(d_ids.cpu().numpy().view(np.uint32), ids) and np.array_equal(_bits(d_sims.cpu().numpy()), _bits(sims))
+    o = oracle_mod.OracleIndex.from_graph(dim, M, ef, graph)
+    sel = np.arange(0, B, B // 48)[:48]
+    oids, osims, on, _ = o.search_batch(Q[sel], k, threads=8)
+    assert np.array_equal(ids[sel], oids) and np.array_equal(_bits(sims[sel]), _bits(osims)) and np.array_equal(n_out[sel], on)
+    gi.set_tuning("visited_bounded", 0)                                    # the exact set: the counters equal the reference's
+    gi.reset_counters()
+    sids, ssims, sn = gi.search_batch(Q[sel[:16]], k)
+    oids, osims, on, oct = o.search_batch(Q[sel[:16]], k, threads=8)
+    assert np.array_equal(sids, oids) and np.array_equal(_bits(ssims), _bits(osims)) and np.array_equal(sn, on)
+    sc, _ = gi.counters()
+    assert (sc.n_dist, sc.n_ids, sc.n_expand) == (oct.n_dist, oct.n_ids, oct.n_expand)
+    # where a decision of these searches meets a tie, the Rust binary's own heap order is asked as well
+    for qi in sel[:16]:
+        if o.tie_census(Q[qi:qi + 1], k)["queries_with_any_tie"]:
+            rid, rsim = o.search_std_heap(Q[qi], k)
+            assert np.array_equal(ids[qi], rid) and np.array_equal(_bits(sims[qi]), _bits(rsim))
     gi.close(); o.close()
 
 

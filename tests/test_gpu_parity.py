@@ -966,7 +966,8 @@ def test_parallel_validated_commits_build_the_serial_graph(eng, oracle_mod, n, d
     node runs its whole commit in a private overlay of the rows it rewrites, nodes whose reads and rows the earlier
     nodes' deltas do not touch are applied together as a group (the rules were proven on the CPU,
     tests/experiments/occ_model.c PAR=1).  The graph must be the oracle's serial graph row for row, the same as with
-    the in-order commit wave (commit_par = 0), with groups of more than one node actually formed."""
+    the in-order commit wave (commit_par = 0), with groups of more than one node actually formed -- and the same again
+    with and without the two-stage plans (plan_split: the dim-128 shapes, where the specialised plan kernel runs)."""
     import ctypes as C
     V = make_data(n, dim, seed=91)
     lv = oracle_mod.draw_levels(n, m, 5)
@@ -976,15 +977,16 @@ def test_parallel_validated_commits_build_the_serial_graph(eng, oracle_mod, n, d
     lib = eng._capi.load()
     lib.hnsw_debug_occ_par.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.hnsw_debug_occ.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
-    for par in (2, 0):
-        gi = eng.Index("p%d" % par, dim, m, ef)
+    for par, split in ((2, 1), (2, 0), (0, 1)):          # split: a far node's upper layers are planned a round early (OccSlot::stage)
+        gi = eng.Index("p%d%d" % (par, split), dim, m, ef)
         gi.set_tuning("occ_window", window)
         gi.set_tuning("commit_par", par)
+        gi.set_tuning("plan_split", split)
         half = n // 2
         gi.add_batch(V[:half], levels=lv[:half], mode="exact")
         gi.add_batch(V[half:], levels=lv[half:], mode="exact")
         ok, why = graphs_equal(want, gi.export_graph())
-        assert ok, "commit_par=%d: %s" % (par, why)
+        assert ok, "commit_par=%d plan_split=%d: %s" % (par, split, why)
         pz, oc = (C.c_uint64 * 21)(), (C.c_uint64 * 16)()
         assert lib.hnsw_debug_occ_par(gi._h, pz) == 0 and lib.hnsw_debug_occ(gi._h, oc) == 0
         if par:
