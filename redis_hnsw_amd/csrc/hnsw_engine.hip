@@ -726,7 +726,9 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
     if (!std::strcmp(key, "lean")) { h->lean = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "duo")) { h->duo = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "plan_duo")) { h->plan_duo = value != 0; return HNSW_OK; }
+    if (!std::strcmp(key, "occ_chain")) { h->occ_chain = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 16); return HNSW_OK; }
     if (!std::strcmp(key, "plan_split")) { h->plan_split = value != 0; return HNSW_OK; }
+    if (!std::strcmp(key, "plan_split_x10")) { h->plan_split_x10 = (uint32_t)std::max<int64_t>(value, 0); return HNSW_OK; }
     if (!std::strcmp(key, "commit_par")) { h->commit_par = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return HNSW_OK; }
     if (!std::strcmp(key, "commit_par_min_x10")) { h->commit_par_min_x10 = (uint32_t)std::max<int64_t>(value, 0); return HNSW_OK; }
     if (!std::strcmp(key, "commit_team")) { h->commit_team = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return HNSW_OK; }

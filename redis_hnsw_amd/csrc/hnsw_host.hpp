@@ -100,11 +100,14 @@ struct hnsw_index {
     uint32_t *d_par_rows = nullptr;
     uint32_t par_ovstride = 0;
     bool plan_split = true;         // tuning: a far node's upper layers are planned a round early (OccSlot::stage, hnsw_plan_lean.hpp)
+    uint32_t plan_split_x10 = 7;   // ... for nodes at window positions >= this/10 x the running yield + 2
     uint32_t plan_split_pos = 0xFFFFFFFFu;   // ... from this window position on, for the round being launched (set by add_exact_window)
     int commit_par = 1;             // tuning: a window's commits go in validated parallel groups (hnsw_occ_par.hpp): 0 never (the in-order commit
                                     // wave only), 1 when the window has been committing at least commit_par_min_x10 / 10 nodes per round (a group
                                     // costs one dry run whatever its size: below ~5 nodes per round the in-order wave is as fast), 2 always
     uint32_t commit_par_min_x10 = 45;
+    bool occ_chained = false;       // the round being launched was enqueued ahead of the host: its kernels take the window from the control block
+    uint32_t occ_chain = 4;         // tuning: rounds of the windowed insert enqueued per host synchronisation
     bool occ_fresh_slots = false;   // the round about to be launched starts from cleared slots (single hnsw_add)
     bool occ_want_touched = false;  // the commit kernel records the update_fn list (a single hnsw_add through a one-node window)
     bool single_window = true;      // tuning: a single hnsw_add runs as a one-node window (speculative shrinks in parallel) instead of the serial kernels

@@ -64,6 +64,7 @@ struct OccCtl {
     uint32_t bar, bar_start;                // grid barrier of k_occ_commit_par: arrivals ever / the count the next launch starts from
     unsigned long long n_groups, n_dry, n_conf_link, n_conf_rec, n_conf_row;   // groups committed, dry runs made, groups closed by: a stale link plan / a record used / a changed row
     unsigned long long dry_prof[8];         // all workgroups' dry runs, 100 MHz ticks: hash + journal check, connect, record checks, row load + spec apply, recompute, update_connections, finish; [7] = sum over iterations of the slowest dry run
+    uint32_t end_node, rounds;              // rounds enqueued ahead of the host (occ_round_window): where the chunk ends; commit launches that ran
     unsigned long long par_prof[8];         // k_occ_commit_par, workgroup 0, 100 MHz ticks: dry run, wait, validate, wait, apply, wait; [6] iterations, [7] launches
 };
 
@@ -75,6 +76,20 @@ struct OccBufs {
     OccCtl *ctl;
     uint32_t W;
 };
+
+// A round enqueued AHEAD of the host (first_node == kEmpty): the host queues a few rounds back to back and synchronises
+// once; such a round starts where the previous one stopped (ctl->head), and does nothing once a round has asked for the
+// host (restride, a serial insert) or the chunk is done.  False = nothing to do for this launch.
+__device__ __forceinline__ bool occ_round_window(const OccBufs &ob, uint32_t &first_node, uint32_t &count)
+{
+    if (first_node != kEmpty) return true;
+    if (ob.ctl->stop >= OCC_STOP_RESTRIDE) return false;
+    first_node = ob.ctl->head;
+    const uint32_t end_node = ob.ctl->end_node;
+    if (first_node >= end_node) return false;
+    if (count > end_node - first_node) count = end_node - first_node;
+    return true;
+}
 
 // LDS scratch of a validation
 struct OccScratch {
@@ -309,6 +324,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_plan(GraphView g, OccBufs ob, uin
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
+    if (!occ_round_window(ob, first_node, count)) return;
     const uint32_t id = first_node + blockIdx.x;
     if (blockIdx.x >= count) return;
     const uint32_t slot = id % ob.W;
@@ -397,6 +413,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_shrinks(GraphView g, OccBufs ob, 
     // del_id != kEmpty: the slot lists the re-selections of HNSW.NODE.DEL (k_occ_del_list): the row as it is, del_id ignored
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
+    if (!occ_round_window(ob, first_node, count)) return;
     const uint32_t b = blockIdx.x / per, k = blockIdx.x % per;   // `per` records launched per slot (kOccInsShr / kOccMaxShr)
     if (b >= count) return;
     const uint32_t id = first_node + b;
@@ -476,6 +493,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_validate(GraphView g, OccBufs ob,
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
+    if (!occ_round_window(ob, first_node, count)) return;
     if (blockIdx.x >= count) return;
     const uint32_t id = first_node + blockIdx.x;
     OccSlot *sl = &ob.slots[id % ob.W];
@@ -666,10 +684,12 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit(GraphView g, Oc
                                                    uint32_t lcap, uint32_t *__restrict__ gspill, uint32_t gnb,
                                                    const uint32_t *__restrict__ plan, uint32_t slack,
                                                    uint32_t *__restrict__ touched, uint32_t touched_cap,
-                                                   uint32_t own_lds = 0, TeamCfg tc = TeamCfg{}, uint32_t *__restrict__ hspill = nullptr)
+                                                   uint32_t own_lds = 0, TeamCfg tc = TeamCfg{}, uint32_t *__restrict__ hspill = nullptr,
+                                                   uint32_t chained = 0)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;
+    if (chained && (ob.ctl->stop >= OCC_STOP_RESTRIDE || ob.ctl->head >= end_node)) return;   // a round enqueued ahead of the host (occ_round_window)
     OccScratch sc = occ_carve(smem);
     WaveMem m;
     Visited vis;
@@ -862,6 +882,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit(GraphView g, Oc
         ob.ctl->head = head;
         ob.ctl->nJ = jr.n;
         ob.ctl->stop = stop;
+        ob.ctl->rounds += 1;
         ob.ctl->n_commit += n_commit;
         ob.ctl->n_spec += n_spec;
         ob.ctl->n_fallback += n_fallback;

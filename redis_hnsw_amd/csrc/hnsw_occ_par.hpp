@@ -207,10 +207,11 @@ template <int MODE, int T, int R, int HW = 0>
 __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g, OccBufs ob, ParBufs pb, uint32_t end_node, uint32_t mlinks,
                                                        uint32_t lnb, uint32_t lcap, uint32_t *__restrict__ gspill, uint32_t gnb,
                                                        const uint32_t *__restrict__ plan, uint32_t slack, uint32_t own_lds = 0,
-                                                       TeamCfg tc = TeamCfg{})
+                                                       TeamCfg tc = TeamCfg{}, uint32_t chained = 0)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;
+    if (chained && (ob.ctl->stop >= OCC_STOP_RESTRIDE || ob.ctl->head >= end_node)) return;   // a round enqueued ahead of the host (occ_round_window)
     const uint32_t b = blockIdx.x, nwg = gridDim.x;
     OccScratch sc = occ_carve(smem);
     OverlayView ov;
@@ -604,6 +605,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g
     if (b == 0 && lane == 0) atomicAdd(&ob.ctl->dry_prof[7], dprof[7]);
     if (b == 0 && lane == 0) {
         ob.ctl->bar_start = bar_target;
+        ob.ctl->rounds += 1;
         ob.ctl->n_groups += n_groups;
         ob.ctl->n_conf_link += n_conf_link;
         ob.ctl->n_conf_rec += n_conf_rec;

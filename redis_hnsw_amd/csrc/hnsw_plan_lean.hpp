@@ -171,6 +171,7 @@ __global__ __launch_bounds__(DUO ? 128 : 64, 1) void k_occ_plan_lean(GraphView g
     // the next round's launch (OccSlot::stage), so that no launch lasts two full searches for one node's sake
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;
+    if (!occ_round_window(ob, first_node, count)) return;
     const uint32_t id = first_node + blockIdx.x;
     if (blockIdx.x >= count) return;
     const uint32_t slot = id % ob.W;

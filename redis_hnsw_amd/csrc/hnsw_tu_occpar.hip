@@ -57,7 +57,7 @@ static hnsw_status commit_par_t(hnsw_index *h, const InsertCfg &c, const OccBufs
             }
         }
         hipLaunchKernelGGL(kt, dim3(count), dim3(64 * (1 + kParHelpers)), lds_team, h->stream, view_tag(h, c.tagcfg), ob, pb, end_node, h->m, c.lnb,
-                           c.lcap, h->d_spill, h->spill_gnb, h->d_plan, h->m + 2 + h->occ_slack_extra, (uint32_t)c.lds, tc);
+                           c.lcap, h->d_spill, h->spill_gnb, h->d_plan, h->m + 2 + h->occ_slack_extra, (uint32_t)c.lds, tc, h->occ_chained ? 1u : 0u);
         HIP_TRY(h, hipGetLastError());
         *done = true;
         return HNSW_OK;
@@ -73,7 +73,7 @@ static hnsw_status commit_par_t(hnsw_index *h, const InsertCfg &c, const OccBufs
         }
     }
     hipLaunchKernelGGL(kc, dim3(count), dim3(64), lds, h->stream, view_tag(h, c.tagcfg), ob, pb, end_node, h->m, c.lnb, c.lcap, h->d_spill,
-                       h->spill_gnb, h->d_plan, h->m + 2 + h->occ_slack_extra, 0u, TeamCfg{});
+                       h->spill_gnb, h->d_plan, h->m + 2 + h->occ_slack_extra, 0u, TeamCfg{}, h->occ_chained ? 1u : 0u);
     HIP_TRY(h, hipGetLastError());
     *done = true;
     return HNSW_OK;

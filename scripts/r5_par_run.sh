@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r5k
-timeout 1500 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_parity.py -m gpu -x -q -k "c3_search or parallel_validated or exact_insert_builds or delete" --durations=5 > gpurun_out/r5k/tests.log 2>&1
-tail -12 gpurun_out/r5k/tests.log
+mkdir -p gpurun_out/r5suite
+python -m pytest tests/test_gpu_pipeline.py tests/test_gpu_robustness.py tests/test_gpu_group.py tests/test_bench_gpu.py -m gpu -x -q > gpurun_out/r5suite/gpu_rest.log 2>&1; tail -5 gpurun_out/r5suite/gpu_rest.log
