@@ -1172,7 +1172,7 @@ class Bench:
                                         roofline=insert_roofline(c1_.n_dist - c0_[0], c1_.n_ids - c0_[1], NS, tg, s.dim,
                                                                  "the oracle making the same %d inserts on the same graph" % NS),
                                         note="the rate of the reference-order build where BASELINE config 5 ends; the whole build from an "
-                                             "empty index: profiles/r5_c5_exact_build_1m.json (133.8 s = 7 476 inserts/s, identical)")
+                                             "empty index: profiles/r5_c5_exact_build_1m.json (123.6 s = 8 090 inserts/s, identical)")
                 ix.close()
                 s.log("reference-order inserts at 1 M nodes: %.0f inserts/s (CPU oracle %.0f), graphs identical" % (NS / tg, NS / tc_))
             o.close()
