@@ -29,7 +29,8 @@ while time.time() - t0 < budget:
     n = int(rng.choice([8000, 20000, 40000]))
     tun = []
     for key, vals in (("occ_window", [8, 32, 64]), ("occ_ahead_x10", [10, 15, 40]), ("select_shortcut", [0, 1]),
-                      ("occ_log_cap", [500, 3072]), ("plan_lean", [0, 1])):
+                      ("occ_log_cap", [500, 3072]), ("plan_lean", [0, 1]), ("commit_par", [0, 2, 2]), ("plan_split", [0, 1]),
+                      ("occ_chain", [1, 8]), ("commit_team", [0, 1])):
         if rng.random() < 0.3:
             tun.append((key, int(rng.choice(vals))))
     case = dict(seed=seed, kind=kind, dim=dim, m=m, ef=ef, n=n, tun=tun)
