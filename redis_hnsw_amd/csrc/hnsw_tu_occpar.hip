@@ -41,7 +41,8 @@ template <int MODE, int T, int R>
 static hnsw_status commit_par_t(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t count, uint32_t end_node, bool *done)
 {
     const size_t lds = kOccScratchBytes + kParLdsBytes + c.lds;
-    if (lds > 160 * 1024 - 2048 || count > 64 || !h->d_par) return HNSW_OK;          // (the in-order kernel takes the round)
+    // (else the in-order kernel takes the round.  The overlay's keys are row << 5 | layer: ids must stay below 2^27)
+    if (lds > 160 * 1024 - 2048 || count > 64 || !h->d_par || h->cap > (1u << 27)) return HNSW_OK;
     ParBufs pb = {reinterpret_cast<OccPar *>(h->d_par), reinterpret_cast<OccDelta *>(h->d_par_delta), h->d_par_rows, h->par_ovstride};
     TeamCfg tc;
     size_t lds_team = 0;
