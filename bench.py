@@ -1061,7 +1061,7 @@ class Bench:
             o.search_batch(Qs[:64], s.k, threads=1)              # warm-up
             done = 0
             tc = time.perf_counter()
-            chunk = 128
+            chunk = min(128, s.B)                          # (C1's preset has one query per batch)
             while True:
                 lo = done % s.B
                 o.search_batch(Qs[lo:lo + chunk], s.k, threads=1)
