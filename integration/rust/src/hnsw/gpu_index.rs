@@ -280,7 +280,9 @@ impl GpuIndex {
             return Err(self.last_error());
         }
         self.ids.remove(name); // status OK = the node is gone from the graph (see add_node)
-        self.gone.insert(name.to_owned(), id);
+        // keep the FIRST id removed under this name since the last sync_redis: that is the element the stored value
+        // still holds (del X(id1), add X(id2), del X(id2) must leave gone[X] = id1)
+        self.gone.entry(name.to_owned()).or_insert(id);
         self.names[id as usize] = None;
         self.pending.push(Change::Removed(id));
         if nt as usize > touched.len() {

@@ -213,7 +213,7 @@ typedef struct {
     /* tie census (hnsw_oracle_tie_census): decisions of search_level that met EQUAL similarities of two
      * different nodes -- the only places where the reference's sim-only order (core.rs:292-300) and this
      * file's (sim, id) order can part */
-    uint64_t tie_stop, tie_accept;
+    uint64_t tie_stop, tie_accept, tie_select;
 } scratch;
 
 struct hnsw_oracle {                                   /* core.rs:303-319  */
@@ -435,6 +435,14 @@ static void select_neighbors(hnsw_oracle *o, scratch *s, uint32_t query,
         if (p.id == query || (ignored >= 0 && p.id == (uint32_t)ignored)) continue;
         heap_push(r, p);
     }
+    if (r->n == m && m) {                               /* census: equal similarities across the cut (:733 / :741) */
+        float worst = r->a[0].sim;
+        for (uint32_t i = 1; i < r->n; i++) if (r->a[i].sim < worst) worst = r->a[i].sim;
+        int tie = 0;
+        for (uint32_t i = 0; i < wd->n && !tie; i++) tie = wd->a[i].sim == worst && wd->a[i].id != query && !(ignored >= 0 && wd->a[i].id == (uint32_t)ignored);
+        for (uint32_t i = 0; i < w->n && !tie; i++) tie = w->a[i].sim == worst && w->a[i].id != query && !(ignored >= 0 && w->a[i].id == (uint32_t)ignored);
+        s->tie_select += (uint64_t)tie;
+    }
 }
 
 /* core.rs:759-774 */
@@ -636,6 +644,7 @@ int64_t hnsw_oracle_add(hnsw_oracle *o, const float *v, int32_t level,
     uint32_t id = o->node_count;
     ensure_cap(o);                                      /* before touch_reset sizes its stamps */
     touch_reset(o);
+    o->sc.tie_stop = o->sc.tie_accept = o->sc.tie_select = 0;   /* census of this insert (hnsw_oracle_last_add_ties) */
     insert(o, v, l);
     if (touched) {
         uint32_t n = o->n_touch < touched_cap ? o->n_touch : touched_cap;
@@ -814,6 +823,202 @@ uint32_t hnsw_oracle_search_std_heap(const hnsw_oracle *o, const float *q, uint3
     return n;
 }
 
+/* ------------------------------------------------------------------------------------------------------------ */
+/* HNSW.NODE.ADD in the RUST BINARY's tie order (test infrastructure): core.rs:489-599 with every heap a std           */
+/* BinaryHeap (rheap above) and every comparison the reference's own -- :635 c.sim < f.sim, :657 e.sim > f.sim, :733  */
+/* e.sim > r.peek().sim -- so that equal similarities are ordered by the heap's sift procedures exactly as the binary */
+/* orders them: BinaryHeap::clone = the array copied as it is (:685, :690, :698, :765, :784), into_vec / into_iter =   */
+/* the array in place (:670-673, :785).  Pinned row for row against the transcription's "rust" golden on 20 k x 128     */
+/* (tests/golden/transcribed_20k_dim128.npz: 18 decision ties), tests/test_golden_cpu.py.                              */
+/* ------------------------------------------------------------------------------------------------------------ */
+static void rh_clone(rheap *dst, const rheap *src)
+{
+    if (dst->cap < src->n + 1) { dst->cap = src->n + 64; dst->a = (simpair *)realloc(dst->a, (size_t)dst->cap * sizeof(simpair)); }
+    memcpy(dst->a, src->a, (size_t)src->n * sizeof(simpair));
+    dst->n = src->n; dst->reverse = src->reverse;
+}
+typedef struct { rheap C, W, res, w, wd, ccopy, nbrs, econn, enew, t; } rscratch;
+static void rscratch_free(rscratch *z)
+{
+    free(z->C.a); free(z->W.a); free(z->res.a); free(z->w.a); free(z->wd.a); free(z->ccopy.a);
+    free(z->nbrs.a); free(z->econn.a); free(z->enew.a); free(z->t.a);
+}
+/* core.rs:677-757; c: a nearest-top std heap; result in *r.  Counts a tie when the cut of :733 / :741-754 fell between
+ * equal similarities of different nodes (which one is selected is then the heap's choice). */
+static void select_neighbors_std(hnsw_oracle *o, scratch *s, rscratch *z, uint32_t query, const rheap *c, uint32_t m, uint32_t lc,
+                                 int64_t ignored, rheap *r, hnsw_oracle_counters *ct)
+{
+    rheap *w = &z->w, *wd = &z->wd, *ccopy = &z->ccopy;
+    r->n = 0; r->reverse = 0;                               /* :684 */
+    rh_clone(w, c);                                         /* :685 */
+    wd->n = 0; wd->reverse = 0;                             /* :686 */
+    visited_reset(s, o->node_count);                        /* :692 */
+    for (uint32_t i = 0; i < c->n; i++) visited_test_and_set(s, c->a[i].id);   /* :690-696 (a set: the pop order is immaterial) */
+    rh_clone(ccopy, c);                                     /* :698 */
+    const float *qv = vec(o, query);
+    while (ccopy->n) {                                      /* :699 */
+        simpair e = rh_pop(ccopy);
+        const nrow *nb = row_of(o, e.id, lc);
+        for (uint32_t i = 0; i < nb->n; i++) {              /* :702 */
+            uint32_t en = nb->ids[i];
+            ct->n_ids++;
+            if (en == query || (ignored >= 0 && en == (uint32_t)ignored)) continue;   /* :704-708 */
+            if (!visited_test(s, en)) {                     /* :710 */
+                simpair p = { hnsw_oracle_euclidean(qv, vec(o, en), o->dim), en };
+                ct->n_dist++;
+                rh_push(w, p);                              /* :717 */
+                visited_test_and_set(s, en);                /* :718 */
+            }
+        }
+    }
+    while (w->n && r->n < m) {                              /* :724-738 */
+        simpair e = rh_pop(w);
+        if (e.id == query || (ignored >= 0 && e.id == (uint32_t)ignored)) continue;
+        if (r->n == 0 || e.sim > r->a[0].sim) rh_push(r, e);    /* :733 (r.peek() is r's NEAREST: only the first passes) */
+        else rh_push(wd, e);
+    }
+    while (wd->n && r->n < m) {                             /* :741-754 */
+        simpair p = rh_pop(wd);
+        if (p.id == query || (ignored >= 0 && p.id == (uint32_t)ignored)) continue;
+        rh_push(r, p);
+    }
+    if (r->n == m && m) {                                   /* census: equal similarities across the cut */
+        float worst = r->a[0].sim;
+        for (uint32_t i = 1; i < r->n; i++) if (r->a[i].sim < worst) worst = r->a[i].sim;
+        int tie = 0;
+        for (uint32_t i = 0; i < wd->n && !tie; i++) tie = wd->a[i].sim == worst && wd->a[i].id != query && !(ignored >= 0 && wd->a[i].id == (uint32_t)ignored);
+        for (uint32_t i = 0; i < w->n && !tie; i++) tie = w->a[i].sim == worst && w->a[i].id != query && !(ignored >= 0 && w->a[i].id == (uint32_t)ignored);
+        s->tie_select += (uint64_t)tie;
+    }
+}
+/* core.rs:776-822 with std heaps (the removal order, :805-806, is result-neutral: Vec::remove keeps the rest in order) */
+static void update_node_connections_std(hnsw_oracle *o, rscratch *z, uint32_t node, const rheap *new_neighbors, const rheap *old_neighbors,
+                                        uint32_t level, int64_t ignored)
+{
+    rheap *newconn = &z->t;
+    rh_clone(newconn, new_neighbors);                       /* :784 */
+    uint32_t n_rm = old_neighbors->n;                       /* :785 into_vec: the array as it is */
+    simpair *rmconn = (simpair *)malloc((size_t)(n_rm ? n_rm : 1) * sizeof(simpair));
+    memcpy(rmconn, old_neighbors->a, (size_t)n_rm * sizeof(simpair));
+    touch_add(o, node);                                     /* :787 */
+    while (newconn->n) {                                    /* :790 */
+        simpair np = rh_pop(newconn);
+        add_neighbor(o, node, level, np.id);                /* :793 */
+        add_neighbor(o, np.id, level, node);                /* :794-795 */
+        touch_add(o, np.id);
+        for (uint32_t i = 0; i < n_rm; i++)                 /* :799-801 */
+            if (rmconn[i].id == np.id) { memmove(rmconn + i, rmconn + i + 1, (size_t)(n_rm - i - 1) * sizeof(simpair)); n_rm--; break; }
+    }
+    while (n_rm) {                                          /* :805 */
+        simpair rp = rmconn[--n_rm];
+        rm_neighbor(o, node, level, rp.id);                 /* :808 */
+        if (ignored >= 0 && rp.id == (uint32_t)ignored) continue;
+        rm_neighbor(o, rp.id, level, node);                 /* :815 */
+        touch_add(o, rp.id);
+    }
+    free(rmconn);
+}
+/* search_level_std with the insert's counters and the tie census of :635 / :657 */
+static void search_level_std_ct(const hnsw_oracle *o, scratch *s, const float *query, uint32_t ep, uint32_t ef, uint32_t level,
+                                rheap *C, rheap *W, rheap *res, hnsw_oracle_counters *ct)
+{
+    visited_reset(s, o->node_count);
+    visited_test_and_set(s, ep);
+    simpair qpair = { hnsw_oracle_euclidean(query, vec(o, ep), o->dim), ep };
+    ct->n_dist++;
+    C->n = W->n = res->n = 0; C->reverse = 0; W->reverse = 1; res->reverse = 0;
+    rh_push(C, qpair); rh_push(W, qpair);
+    while (C->n) {
+        simpair c = rh_pop(C);
+        simpair f = W->a[0];
+        if (c.sim == f.sim && c.id != f.id) s->tie_stop++;
+        if (c.sim < f.sim) break;                           /* :635 */
+        ct->n_expand++;
+        const nrow *nb = row_of(o, c.id, level);
+        for (uint32_t i = 0; i < nb->n; i++) {
+            uint32_t e = nb->ids[i];
+            ct->n_ids++;
+            if (visited_test_and_set(s, e)) continue;
+            f = W->a[0];
+            simpair e2 = { hnsw_oracle_euclidean(query, vec(o, e), o->dim), e };
+            ct->n_dist++;
+            if (W->n >= ef && e2.sim == f.sim) s->tie_accept++;
+            if (e2.sim > f.sim || W->n < ef) {              /* :657 */
+                rh_push(C, e2); rh_push(W, e2);
+                if (W->n > ef) rh_pop(W);
+            }
+        }
+    }
+    for (uint32_t i = 0; i < W->n; i++) rh_push(res, W->a[i]);   /* :670-674 */
+}
+/* core.rs:489-599 */
+static void insert_std(hnsw_oracle *o, const float *data, uint32_t l)
+{
+    scratch *s = &o->sc;
+    hnsw_oracle_counters *ct = &o->ins;
+    rscratch z; memset(&z, 0, sizeof z);
+    uint32_t l_max = o->max_layer;                          /* :496 */
+    uint32_t query = store_node(o, data, l);                /* :498-507 */
+    const float *qv = vec(o, query);
+    uint32_t ep = (uint32_t)o->enterpoint;                  /* :508 */
+    uint32_t lc = l_max;                                    /* :511 */
+    while (lc > l) {                                        /* :512 */
+        search_level_std_ct(o, s, qv, ep, 1, lc, &z.C, &z.W, &z.res, ct);   /* :513 */
+        ep = z.res.a[0].id;                                 /* :514 w.pop(): the root */
+        if (lc == 0) break;
+        lc--;
+    }
+    uint32_t top = l_max < l ? l_max : l;
+    for (uint32_t lcc = top + 1; lcc-- > 0;) {              /* :523 */
+        search_level_std_ct(o, s, qv, ep, o->ef_construction, lcc, &z.C, &z.W, &z.res, ct);   /* :524 */
+        select_neighbors_std(o, s, &z, query, &z.res, o->m, lcc, -1, &z.nbrs, ct);          /* :525-531 */
+        {                                                   /* :532 connect_neighbors (core.rs:759-774) */
+            rheap *t = &z.t;
+            rh_clone(t, &z.nbrs);
+            while (t->n) { simpair n = rh_pop(t); add_neighbor(o, query, lcc, n.id); add_neighbor(o, n.id, lcc, query); }
+        }
+        for (uint32_t i = 0; i < z.nbrs.n; i++) touch_add(o, z.nbrs.a[i].id);   /* :535-537 */
+        while (z.nbrs.n) {                                  /* :540 */
+            simpair e = rh_pop(&z.nbrs);
+            rheap *econn = &z.econn;                        /* :544-558 */
+            econn->n = 0; econn->reverse = 0;
+            const nrow *er = row_of(o, e.id, lcc);
+            const float *ev = vec(o, e.id);
+            for (uint32_t i = 0; i < er->n; i++) {
+                simpair p = { hnsw_oracle_euclidean(ev, vec(o, er->ids[i]), o->dim), er->ids[i] };   /* :550 */
+                ct->n_dist++; ct->n_ids++;
+                rh_push(econn, p);
+            }
+            uint32_t m_max = lcc == 0 ? o->m_max0 : o->m_max;   /* :560 */
+            if (econn->n > m_max) {                         /* :561 */
+                select_neighbors_std(o, s, &z, e.id, econn, m_max, lcc, -1, &z.enew, ct);   /* :568 */
+                update_node_connections_std(o, &z, e.id, &z.enew, econn, lcc, -1);          /* :569 */
+            }
+        }
+        ep = z.res.a[0].id;                                 /* :576 w.peek() */
+    }
+    if (l > l_max) { o->max_layer = l; o->enterpoint = query; }   /* :587-593 */
+    rscratch_free(&z);
+}
+/* core.rs:383-412 in the Rust binary's tie order; ties[3] (may be NULL) += decisions of THIS insert that met equal
+ * similarities of two different nodes: [0] the stop test :635, [1] the accept test :657 with W full, [2] a select cut :733 */
+int64_t hnsw_oracle_add_std_heap(hnsw_oracle *o, const float *v, int32_t level, uint64_t *ties)
+{
+    if (o->node_count - o->n_dead == 0) {                   /* :393-405 */
+        uint32_t id = store_node(o, v, 0);
+        o->enterpoint = id;
+        return id;
+    }
+    uint32_t l = level >= 0 ? (uint32_t)level : gen_random_level(o);
+    uint32_t id = o->node_count;
+    ensure_cap(o);
+    touch_reset(o);
+    o->sc.tie_stop = o->sc.tie_accept = o->sc.tie_select = 0;
+    insert_std(o, v, l);
+    if (ties) { ties[0] += o->sc.tie_stop; ties[1] += o->sc.tie_accept; ties[2] += o->sc.tie_select; }
+    return id;
+}
+
 /* Baseline B: T independent searches at a time over the shared read-only graph.  The
  * workers are persistent and each keeps its own scratch (visited stamps + heaps) across calls -- a
  * fresh scratch per call costs a node_count-sized memset per thread, which at 256 threads and 1024
@@ -985,6 +1190,11 @@ int hnsw_oracle_delete(hnsw_oracle *o, uint32_t id, uint32_t *touched, uint32_t 
         o->max_layer = best >= 0 ? best_level : 0;
     }
     return 0;
+}
+
+void hnsw_oracle_last_add_ties(const hnsw_oracle *o, uint64_t out[3])
+{
+    out[0] = o->sc.tie_stop; out[1] = o->sc.tie_accept; out[2] = o->sc.tie_select;
 }
 
 uint32_t hnsw_oracle_live_count(const hnsw_oracle *o) { return o->node_count - o->n_dead; }

@@ -82,6 +82,10 @@ def lib():
     L.hnsw_oracle_tie_census.restype = None
     L.hnsw_oracle_search_std_heap.argtypes = [C.c_void_p, fp, C.c_uint32, u32p, fp]
     L.hnsw_oracle_search_std_heap.restype = C.c_uint32
+    L.hnsw_oracle_add_std_heap.restype = C.c_int64
+    L.hnsw_oracle_add_std_heap.argtypes = [C.c_void_p, fp, C.c_int32, u64p]
+    L.hnsw_oracle_last_add_ties.restype = None
+    L.hnsw_oracle_last_add_ties.argtypes = [C.c_void_p, u64p]
     _lib = L
     return L
 
@@ -164,6 +168,32 @@ class OracleIndex:
         V = _f32(V)
         for i in range(V.shape[0]):
             self.add(V[i], -1 if levels is None else int(levels[i]))
+
+    def add_batch_std_heap(self, V, levels=None):
+        """HNSW.NODE.ADD x N in the Rust binary's own tie order (sim-only comparisons on std's BinaryHeap, restated):
+        -> (stop-test ties, accept-test ties, select-cut ties) met by the build's decisions"""
+        V = _f32(V)
+        ties = np.zeros(3, dtype=np.uint64)
+        for i in range(V.shape[0]):
+            lib().hnsw_oracle_add_std_heap(self._h, _fp(V[i]), -1 if levels is None else int(levels[i]), _u64p(ties))
+        return tuple(int(x) for x in ties)
+
+    def add_batch_census(self, V, levels=None):
+        """add_batch (the (sim, id) total order) with the tie census of every insert: -> (inserts that met a decision
+        tie, stop-test ties, accept-test ties, select-cut ties)"""
+        V = _f32(V)
+        tot = np.zeros(3, dtype=np.uint64)
+        one = np.zeros(3, dtype=np.uint64)
+        n_ins = 0
+        for i in range(V.shape[0]):
+            first = self.live_count == 0
+            self.add(V[i], -1 if levels is None else int(levels[i]))
+            if first:
+                continue
+            lib().hnsw_oracle_last_add_ties(self._h, _u64p(one))
+            tot += one
+            n_ins += int(one.sum() != 0)
+        return (n_ins,) + tuple(int(x) for x in tot)
 
     # -- delete (core.rs:414-475) ----------------------------------------------
     def delete(self, i, want_touched=False):

@@ -731,6 +731,7 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
     if (!std::strcmp(key, "plan_split_x10")) { h->plan_split_x10 = (uint32_t)std::max<int64_t>(value, 0); return HNSW_OK; }
     if (!std::strcmp(key, "commit_par")) { h->commit_par = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return HNSW_OK; }
     if (!std::strcmp(key, "commit_par_min_x10")) { h->commit_par_min_x10 = (uint32_t)std::max<int64_t>(value, 0); return HNSW_OK; }
+    if (!std::strcmp(key, "par_max_resident")) { h->par_max_resident = value <= 0 ? 0xFFFFFFFFu : (uint32_t)value; return HNSW_OK; }
     if (!std::strcmp(key, "commit_team")) { h->commit_team = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return HNSW_OK; }
     if (!std::strcmp(key, "plan_duo_max")) { h->plan_duo_max = (uint32_t)std::max<int64_t>(value, 0); return HNSW_OK; }
     if (!std::strcmp(key, "duo_max")) { h->duo_max = (uint32_t)std::max<int64_t>(value, 0); return HNSW_OK; }

@@ -99,6 +99,11 @@ struct hnsw_index {
     void *d_par = nullptr, *d_par_delta = nullptr;
     uint32_t *d_par_rows = nullptr;
     uint32_t par_ovstride = 0;
+    // k_occ_commit_par's grid barrier needs every workgroup resident: the co-resident count of the kernel / LDS size last asked for
+    const void *par_res_kernel = nullptr;
+    size_t par_res_lds = 0;
+    uint32_t par_res_n = 0;
+    uint32_t par_max_resident = 0xFFFFFFFFu;   // tests: pretend the device holds at most this many (tuning "par_max_resident")
     bool plan_split = true;         // tuning: a far node's upper layers are planned a round early (OccSlot::stage, hnsw_plan_lean.hpp)
     uint32_t plan_split_x10 = 7;   // ... for nodes at window positions >= this/10 x the running yield + 2
     uint32_t plan_split_pos = 0xFFFFFFFFu;   // ... from this window position on, for the round being launched (set by add_exact_window)

@@ -320,7 +320,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g
                     const uint32_t l = g.levels[id];
                     const uint32_t top = sl->top;
                     const uint32_t *pl0 = plan + (size_t)slot * kMaxLayers * g.plan_stride;
-                    for (uint32_t lc1 = top + 1; lc1-- > 0 && !fail;) {     // core.rs:523
+                    for (uint32_t lc1 = top + 1; lc1-- > 0 && !fail && !overflow;) {     // core.rs:523
                         const uint32_t lc = lc1;
                         const uint32_t stride = lc ? g.strideU : g.stride0;
                         const uint32_t mmax = lc ? mlinks : 2 * mlinks;     // core.rs:560
@@ -344,7 +344,10 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g
                         wave_sync_full();
                         DRY_T(1);
 
-                        for (uint32_t si = 0; si < nsel && !fail; ++si) {   // shrink loop (core.rs:540-574), e nearest first
+                        for (uint32_t si = 0; si < nsel && !fail && !overflow; ++si) {   // shrink loop (core.rs:540-574), e nearest first
+                            // more deltas than the private buffer holds (journal_push counts them, it does not write them): the
+                            // dry run is void from here on -- and nothing may read mydelta[] past its end
+                            if (jr.n > kParMaxDelta) { overflow = true; break; }
                             const uint32_t e = pl[1 + si];
                             uint32_t *erow = row_mut(ov, e, lc, lane);       // (in the overlay since the connect)
                             uint32_t cnt = erow[0];

@@ -37,12 +37,32 @@ static bool par_team_cfg(const hnsw_index *h, const InsertCfg &c, TeamCfg *tc, s
     return h->spill_slots >= 64u + 64u * kParHelpers;
 }
 
+// The iterations of k_occ_commit_par are separated by a spin barrier over the whole grid (par_barrier): every
+// workgroup must be RESIDENT, or the ones that are spin for ever.  A workgroup asks for nearly a CU's whole LDS, so the
+// co-resident count is (workgroups per CU at this block size and LDS) x (CUs of this device or partition -- 32 in CPX
+// mode).  Asked once per (kernel, LDS size) and handle; a round with more window nodes than that goes to the in-order
+// commit kernel.
+template <typename Kern>
+static hnsw_status par_resident(hnsw_index *h, Kern kern, int block, size_t lds, uint32_t *out)
+{
+    const void *kp = reinterpret_cast<const void *>(kern);
+    if (h->par_res_kernel == kp && h->par_res_lds == lds) { *out = h->par_res_n; return HNSW_OK; }
+    int per_cu = 0, cus = 0;
+    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kp, block, lds));
+    HIP_TRY(h, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+    h->par_res_kernel = kp;
+    h->par_res_lds = lds;
+    h->par_res_n = (uint32_t)std::max(per_cu, 0) * (uint32_t)std::max(cus, 0);
+    *out = h->par_res_n;
+    return HNSW_OK;
+}
+
 template <int MODE, int T, int R>
 static hnsw_status commit_par_t(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t count, uint32_t end_node, bool *done)
 {
     const size_t lds = kOccScratchBytes + kParLdsBytes + c.lds;
     // (else the in-order kernel takes the round.  The overlay's keys are row << 5 | layer: ids must stay below 2^27)
-    if (lds > 160 * 1024 - 2048 || count > 64 || !h->d_par || h->cap > (1u << 27)) return HNSW_OK;
+    if (lds > 160 * 1024 - 2048 || count > 64 || !h->d_par || !h->d_par_delta || !h->d_par_rows || h->cap > (1u << 27)) return HNSW_OK;
     ParBufs pb = {reinterpret_cast<OccPar *>(h->d_par), reinterpret_cast<OccDelta *>(h->d_par_delta), h->d_par_rows, h->par_ovstride};
     TeamCfg tc;
     size_t lds_team = 0;
@@ -57,6 +77,10 @@ static hnsw_status commit_par_t(hnsw_index *h, const InsertCfg &c, const OccBufs
                 attr_set[h->device & 15] = true;
             }
         }
+        uint32_t resident = 0;
+        hnsw_status rs = par_resident(h, kt, 64 * (1 + kParHelpers), lds_team, &resident);
+        if (rs != HNSW_OK) return rs;
+        if (count > std::min(resident, h->par_max_resident)) return HNSW_OK;      // not all workgroups would be resident: the in-order commit
         hipLaunchKernelGGL(kt, dim3(count), dim3(64 * (1 + kParHelpers)), lds_team, h->stream, view_tag(h, c.tagcfg), ob, pb, end_node, h->m, c.lnb,
                            c.lcap, h->d_spill, h->spill_gnb, h->d_plan, h->m + 2 + h->occ_slack_extra, (uint32_t)c.lds, tc, h->occ_chained ? 1u : 0u);
         HIP_TRY(h, hipGetLastError());
@@ -73,6 +97,10 @@ static hnsw_status commit_par_t(hnsw_index *h, const InsertCfg &c, const OccBufs
             attr_set[h->device & 15] = true;
         }
     }
+    uint32_t resident = 0;
+    hnsw_status rs = par_resident(h, kc, 64, lds, &resident);
+    if (rs != HNSW_OK) return rs;
+    if (count > std::min(resident, h->par_max_resident)) return HNSW_OK;          // not all workgroups would be resident: the in-order commit
     hipLaunchKernelGGL(kc, dim3(count), dim3(64), lds, h->stream, view_tag(h, c.tagcfg), ob, pb, end_node, h->m, c.lnb, c.lcap, h->d_spill,
                        h->spill_gnb, h->d_plan, h->m + 2 + h->occ_slack_extra, 0u, TeamCfg{}, h->occ_chained ? 1u : 0u);
     HIP_TRY(h, hipGetLastError());
