@@ -720,6 +720,9 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
     if (!std::strcmp(key, "single_window")) { h->single_window = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "occ_window")) { h->occ_window = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), kOccMaxW); return HNSW_OK; }
     if (!std::strcmp(key, "occ_ahead_x10")) { h->occ_ahead_x10 = (uint32_t)std::max<int64_t>(value, 5); return HNSW_OK; }
+    if (!std::strcmp(key, "occ_stage_ahead")) { h->occ_stage_ahead = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), kOccMaxW); return HNSW_OK; }
+    if (!std::strcmp(key, "occ_depth_x10")) { h->occ_depth_x10 = (uint32_t)std::max<int64_t>(value, 0); return HNSW_OK; }
+    if (!std::strcmp(key, "occ_front_max")) { h->occ_front_max = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 2), kOccMaxW); return HNSW_OK; }
     if (!std::strcmp(key, "occ_slack_extra")) { h->occ_slack_extra = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 64); return HNSW_OK; }
     if (!std::strcmp(key, "occ_log_cap")) { h->occ_log_cap = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), kOccMaxReads); return HNSW_OK; }
     if (!std::strcmp(key, "occ_min_batch")) { h->occ_min_batch = (uint32_t)std::max<int64_t>(value, 1); return HNSW_OK; }
@@ -1056,6 +1059,14 @@ hnsw_status hnsw_debug_occ_par(hnsw_index *h, uint64_t *out5 /* [21] */)
     out5[3] = h->occ_last.n_conf_rec; out5[4] = h->occ_last.n_conf_row;
     for (int i = 0; i < 8; ++i) out5[5 + i] = h->occ_last.par_prof[i];   // workgroup 0's phase clocks (100 MHz), iterations, launches
     for (int i = 0; i < 8; ++i) out5[13 + i] = h->occ_last.dry_prof[i];  // all dry runs' phase clocks; [7] sum of the slowest per iteration
+    return HNSW_OK;
+}
+
+// ... more of the same (development aid): [0] rounds that ended right after a group, without an iteration spent on finding the head not ready
+hnsw_status hnsw_debug_occ_par2(hnsw_index *h, uint64_t *out4)
+{
+    if (!h || !out4) return HNSW_ERR_INVALID;
+    out4[0] = h->occ_last.n_early; out4[1] = out4[2] = out4[3] = 0;
     return HNSW_OK;
 }
 

@@ -116,11 +116,16 @@ struct hnsw_index {
     bool occ_fresh_slots = false;   // the round about to be launched starts from cleared slots (single hnsw_add)
     bool occ_want_touched = false;  // the commit kernel records the update_fn list (a single hnsw_add through a one-node window)
     bool single_window = true;      // tuning: a single hnsw_add runs as a one-node window (speculative shrinks in parallel) instead of the serial kernels
-    uint32_t occ_window = 32;       // tuning: window slots (0 = the serial path only)
+    uint32_t occ_window = 64;       // tuning: window slots (0 = the serial path only)
     uint32_t occ_min_batch = 64;    // batches smaller than this take the serial path
     uint32_t occ_log_cap = hnsw::kOccMaxReads;   // tests: a tiny read log sends every node of the window to the serial kernels
     uint32_t occ_slack_extra = 0;   // tests: demand this much more free room per row (exercises the restride stop)
-    uint32_t occ_ahead_x10 = 15;    // tuning: look-ahead = this/10 x running yield + 3
+    uint32_t occ_ahead_x10 = 15;    // tuning: FRONT of the group commit (nodes dry-run side by side) = this/10 x running yield + 3, at most occ_front_max
+    uint32_t occ_front_max = 64;
+    uint32_t occ_depth_x10 = 0;     // tuning: DEPTH of the planned window = this/10 x running yield + 6 (>= the front, <= occ_window); 0 = the front
+    uint32_t occ_stage_ahead = 32;  // tuning: nodes beyond the window whose layers above 0 are planned ahead (k_occ_plan_lean `far`; 0 = off)
+    uint32_t occ_far = 0;           // ... for the round being launched (set by add_exact_window)
+    uint32_t occ_front = 0;         // the front of the round being launched (0: the whole window, as a single hnsw_add / a delete have it)
     double occ_yield = 4.0;         // commits per round, running average (sizes the look-ahead)
     uint64_t occ_rounds = 0;
     hnsw::OccCtl occ_last = {};     // counters of the last windowed build (hnsw_debug_occ)

@@ -63,6 +63,7 @@ struct OccCtl {
     // parallel validated commits (hnsw_occ_par.hpp)
     uint32_t bar, bar_start;                // grid barrier of k_occ_commit_par: arrivals ever / the count the next launch starts from
     unsigned long long n_groups, n_dry, n_conf_link, n_conf_rec, n_conf_row;   // groups committed, dry runs made, groups closed by: a stale link plan / a record used / a changed row
+    unsigned long long n_early;             // rounds that ended right after a group: the next head was known not to be able to commit
     unsigned long long dry_prof[8];         // all workgroups' dry runs, 100 MHz ticks: hash + journal check, connect, record checks, row load + spec apply, recompute, update_connections, finish; [7] = sum over iterations of the slowest dry run
     uint32_t end_node, rounds;              // rounds enqueued ahead of the host (occ_round_window): where the chunk ends; commit launches that ran
     unsigned long long par_prof[8];         // k_occ_commit_par, workgroup 0, 100 MHz ticks: dry run, wait, validate, wait, apply, wait; [6] iterations, [7] launches
@@ -489,13 +490,14 @@ __global__ __launch_bounds__(64, 1) void k_occ_shrinks(GraphView g, OccBufs ob, 
 // they reach the head).  A slot that passes moves its snapshot forward.
 // ---------------------------------------------------------------------------------------------------------
 template <int MODE, int T>
-__global__ __launch_bounds__(64, 1) void k_occ_validate(GraphView g, OccBufs ob, uint32_t first_node, uint32_t count)
+__global__ __launch_bounds__(64, 1) void k_occ_validate(GraphView g, OccBufs ob, uint32_t first_node, uint32_t count, uint32_t far = 0)
 {
+    // far: the slots of the nodes beyond the window whose upper layers were planned ahead (k_occ_plan_lean) are checked too
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
     if (!occ_round_window(ob, first_node, count)) return;
-    if (blockIdx.x >= count) return;
     const uint32_t id = first_node + blockIdx.x;
+    if (blockIdx.x >= count && (blockIdx.x >= count + far || id >= ob.ctl->end_node)) return;
     OccSlot *sl = &ob.slots[id % ob.W];
     const uint32_t nJ = ob.ctl->nJ;
     OccScratch sc = occ_carve(smem);

@@ -248,6 +248,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g
     uint32_t bar_target = ob.ctl->bar_start;
     occ_init_hash(sc, lane);
     unsigned long long n_groups = 0, n_dry = 0, n_conf_link = 0, n_conf_rec = 0, n_conf_row = 0;   // (groups: workgroup 0 keeps the round's)
+    unsigned long long n_early = 0;                          // rounds ended right after a group (no iteration spent on finding the head not ready)
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // workgroup 0, 100 MHz ticks: dry run, wait, validate, wait, apply, wait; [6] iterations, [7] launches
     unsigned long long t_ = wall_clock64();
 #define PAR_T(i) do { const unsigned long long n_ = wall_clock64(); prof[i] += n_ - t_; t_ = n_; } while (0)
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g
         redo = false;
         if (lane == 0) {
             me->state = state; me->conflict = 0u; me->promotes = state == PAR_READY ? promotes : 0u; me->n_delta = state == PAR_READY ? n_delta : 0u;
-            me->why = 0u; me->pad0 = (uint32_t)(dry_ticks < 0xFFFFFFu ? dry_ticks : 0u);
+            me->why = 0u; me->pad0 = (uint32_t)(dry_ticks < 0xFFFFFFu ? dry_ticks : 0u); me->pad1 = 0u;
         }
         PAR_T(0);
         par_barrier(&ob.ctl->bar, bar_target, nwg, lane);
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g
         PAR_T(3);
 
         // ------------------------------------------------------------------ the group: the longest conflict-free prefix
-        uint32_t p = 0, my_off = 0, total = 0, promoter = kEmpty, close_why = 0, st0 = PAR_NONE;
+        uint32_t p = 0, my_off = 0, total = 0, promoter = kEmpty, close_why = 0, st0 = PAR_NONE, stp = PAR_NONE;
         {
             const bool in = (uint32_t)lane < nwg;
             const OccPar *pp = &pb.par[in ? (head + (uint32_t)lane) % nwg : 0u];     // lane = position in the window
@@ -519,6 +520,22 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g
             my_off = (uint32_t)__shfl((int)excl, (int)(pos < 64 ? pos : 0), 64);
             close_why = p < nwg ? (uint32_t)__shfl((int)wy, (int)p, 64) : 0u;
             st0 = (uint32_t)__shfl((int)st, 0, 64);
+            stp = p < nwg ? (uint32_t)__shfl((int)st, (int)p, 64) : PAR_NONE;   // the node that closed the group: the next head
+        }
+        // ---- does the round end with this group?  The next iteration would start by finding out whether the node that
+        // closed the group -- the next head -- can still commit, after every window node has made its dry run (~250 us
+        // nobody needs: every round ends that way).  Most of the answer is known now: a next head that needs a new plan or
+        // wider rows ends the round whatever happens, and whether its LINK PLAN survives the group is one more look at the
+        // group's deltas -- the validate phase stopped at the first member it conflicts with, the members after that are
+        // checked here, by that node's own workgroup, while the members write their rows.
+        if (p && pos == p && state == PAR_READY) {
+            bool stale = why == 1u;
+            for (uint32_t x = fc + 1u; x < p && !stale; ++x) {
+                const uint32_t wx = (head + x) % nwg;
+                occ_check_range<MODE, T>(g, m, sc, ob, reads, shr, id, 0u, pb.par[wx].n_delta, lane, false, kEmpty, pb.delta + (size_t)wx * kParMaxDelta);
+                stale = sc.flags[0] != 0u;
+            }
+            if (stale && lane == 0) { me->pad1 = 1u; sl->planned = 0; sl->stage = 0u; }
         }
         if (state == PAR_READY && pos < p) {
             // write the overlay rows back, eight at a time
@@ -596,6 +613,15 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g
         PAR_T(5);
         prof[6] += 1;
         if (p == 0 || head + p >= end_node) break;
+        {   // the next head cannot commit: the round ends here (see above)
+            uint32_t nstop = stp == PAR_REPLAN ? (uint32_t)OCC_STOP_REPLAN : stp == PAR_RESTRIDE ? (uint32_t)OCC_STOP_RESTRIDE : (uint32_t)OCC_STOP_NONE;
+            if (nstop == OCC_STOP_NONE && p < nwg && stp == PAR_READY && pb.par[(head + p) % nwg].pad1) nstop = OCC_STOP_REPLAN;
+            if (nstop != OCC_STOP_NONE) {
+                if (b == 0 && lane == 0) ob.ctl->stop = nstop;
+                if (b == 0) n_early += 1;
+                break;
+            }
+        }
     }
     if constexpr (HW > 0) {
         if (lane == 0) task->op = TEAM_EXIT;
@@ -613,6 +639,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g
         ob.ctl->n_conf_link += n_conf_link;
         ob.ctl->n_conf_rec += n_conf_rec;
         ob.ctl->n_conf_row += n_conf_row;
+        ob.ctl->n_early += n_early;
         prof[7] = 1;
         for (int i = 0; i < 8; ++i) ob.ctl->par_prof[i] += prof[i];
     }

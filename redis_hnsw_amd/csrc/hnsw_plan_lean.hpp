@@ -165,18 +165,25 @@ template <int R, int DB, bool WIDE, bool DUO = false>
 __global__ __launch_bounds__(DUO ? 128 : 64, 1) void k_occ_plan_lean(GraphView g, OccBufs ob, uint32_t first_node, uint32_t count, uint32_t ef,
                                                       uint32_t mlinks, uint32_t lnb, uint32_t lcap, uint32_t *__restrict__ gspill,
                                                       uint32_t gnb, uint32_t *__restrict__ plan, uint32_t shortcut, uint32_t log_cap,
-                                                      uint32_t lean_off, uint32_t idbits, uint32_t split_pos = kEmpty)
+                                                      uint32_t lean_off, uint32_t idbits, uint32_t split_pos = kEmpty, uint32_t far = 0)
 {
     // split_pos: a node at window position >= split_pos with a level >= 1 gets its UPPER layers planned now and layer 0 in
-    // the next round's launch (OccSlot::stage), so that no launch lasts two full searches for one node's sake
+    // the next round's launch (OccSlot::stage), so that no launch lasts two full searches for one node's sake.
+    // far (round 6): the launch carries `far` more workgroups, for the nodes BEYOND the window (blockIdx.x in
+    // [count, count + far)): everything ABOVE layer 0 -- the greedy descent, and for a node with a level >= 1 the layer
+    // searches down to layer 1 with their plan rows -- is done for them now, rounds before they enter the window, so
+    // that the plan a round waits for is one layer-0 search whatever the node's level.  Upper layers change only when
+    // a node with a level >= 1 commits (one in M), and k_occ_validate keeps checking a staged slot's reads every round.
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     if (!occ_round_window(ob, first_node, count)) return;
     const uint32_t id = first_node + blockIdx.x;
-    if (blockIdx.x >= count) return;
+    const bool is_far = blockIdx.x >= count;
+    if (is_far && (blockIdx.x >= count + far || id >= ob.ctl->end_node || g.hdr->max_layer == 0u)) return;
     const uint32_t slot = id % ob.W;
     OccSlot *sl = &ob.slots[slot];
     if (sl->planned && sl->node == id) return;              // (both waves of a DUO plan take the same way out)
+    if (is_far && sl->node == id && sl->stage == 1u && sl->epoch == ob.ctl->epoch) return;   // staged already (k_occ_validate resets a stale one)
     if constexpr (DUO) {
         if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= 64) {
             PlanLean<R, DB, WIDE, true, true>::keep(g, smem + lean_off, ef, lane);
@@ -207,9 +214,10 @@ __global__ __launch_bounds__(DUO ? 128 : 64, 1) void k_occ_plan_lean(GraphView g
     uint32_t *pl0 = plan + (size_t)slot * kMaxLayers * g.plan_stride;
     const uint32_t top = lmax < l ? lmax : l;
     // stage 1 done a round ago and still valid (k_occ_validate checked it against the journal): layer 0 only
-    const bool resume = sl->stage == 1u && sl->node == id && sl->epoch == epoch && top >= 1;
-    // far from the head, two or more layers to search: the upper ones now, layer 0 next round
-    const bool split = !resume && top >= 1 && blockIdx.x >= split_pos;
+    const bool resume = sl->stage == 1u && sl->node == id && sl->epoch == epoch && lmax >= 1;
+    // far from the head, two or more layers to search: the upper ones now, layer 0 next round; beyond the window:
+    // whatever lies above layer 0 (the descent alone for a node of level 0)
+    const bool split = !resume && (is_far ? lmax >= 1 : (top >= 1 && blockIdx.x >= split_pos));
     uint32_t snapU = snap;
 
     QReg<4> qr;

@@ -30,7 +30,7 @@ static hnsw_status occ_round_t(hnsw_index *h, const InsertCfg &c, const OccBufs 
     const GraphView gv = view_tag(h, c.tagcfg);
     if (h->occ_chained) head = kEmpty;                    // a round enqueued ahead of the host: the kernels start at ctl->head (occ_round_window)
     if (!h->occ_fresh_slots)                              // a one-node window starts from cleared slots: nothing to validate
-        hipLaunchKernelGGL(kv, dim3(count), dim3(64), lds_val, h->stream, gv, ob, head, count);
+        hipLaunchKernelGGL(kv, dim3(count + h->occ_far), dim3(64), lds_val, h->stream, gv, ob, head, count, h->occ_far);
     bool lean_plan = false;
     if constexpr (MODE == MODE_AVX && T == 4) {
         hnsw_status ls = launch_occ_plan_lean(h, c, ob, head, count, &lean_plan);   // the specialised search routine where the index allows it
@@ -45,7 +45,8 @@ static hnsw_status occ_round_t(hnsw_index *h, const InsertCfg &c, const OccBufs 
     if (count > 1 && !h->occ_want_touched && (h->commit_par == 2 || (h->commit_par == 1 && h->occ_yield * 10.0 >= (double)h->commit_par_min_x10))) {
         // the window's commits in validated parallel groups, one workgroup per window node (hnsw_occ_par.hpp)
         HIP_TRY(h, hipGetLastError());
-        hnsw_status ps = occ_commit_par_r<MODE, T>(h, c, ob, count, end_node, &team);
+        // (the commit's grid is the FRONT; the plans above cover the whole depth of the window, add_exact_window)
+        hnsw_status ps = occ_commit_par_r<MODE, T>(h, c, ob, h->occ_front ? std::min(h->occ_front, count) : count, end_node, &team);
         if (ps != HNSW_OK) return ps;
     }
     if (!team && h->commit_team) {

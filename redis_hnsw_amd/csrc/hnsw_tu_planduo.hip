@@ -44,8 +44,9 @@ static hnsw_status occ_plan_duo_t(hnsw_index *h, const InsertCfg &c, const OccBu
             attr_set[h->device & 15] = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(count), dim3(128), lds, h->stream, view_tag(h, c.tagcfg), ob, head, count, h->efc, h->m, c.lnb, c.lcap,
-                       h->d_spill, h->spill_gnb, h->d_plan, h->select_shortcut ? 1u : 0u, h->occ_log_cap, (uint32_t)c.lds, idbits, h->plan_split_pos);
+    hipLaunchKernelGGL(kern, dim3(count + h->occ_far), dim3(128), lds, h->stream, view_tag(h, c.tagcfg), ob, head, count, h->efc, h->m, c.lnb, c.lcap,
+                       h->d_spill, h->spill_gnb, h->d_plan, h->select_shortcut ? 1u : 0u, h->occ_log_cap, (uint32_t)c.lds, idbits, h->plan_split_pos,
+                       h->occ_far);
     HIP_TRY(h, hipGetLastError());
     return HNSW_OK;
 }

@@ -18,6 +18,9 @@ gi.set_tuning("occ_window", W)
 if os.environ.get("PLAN_LEAN"): gi.set_tuning("plan_lean", int(os.environ["PLAN_LEAN"]))
 if os.environ.get("COMMIT_PAR"): gi.set_tuning("commit_par", int(os.environ["COMMIT_PAR"]))
 if os.environ.get("OCC_AHEAD"): gi.set_tuning("occ_ahead_x10", int(os.environ["OCC_AHEAD"]))
+for kv in os.environ.get("TUNING", "").split(","):          # e.g. TUNING=occ_depth_x10=30,occ_front_max=12
+    if kv:
+        gi.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
 t = time.time(); gi.add_batch(V, levels=lv, mode="exact"); dt = time.time() - t
 lib = _capi.load()
 out = (C.c_uint64 * 16)()

@@ -36,12 +36,15 @@ static void jpush(uint32_t row, uint32_t lc, uint32_t z, int add)
     J[nJ++] = (delta){row, lc, z, add};
 }
 
-static uint64_t why[2][2][2]; static int g_count_why; static int g_refine = 1; static int g_tight = 1;
+static int g_diag; static uint32_t g_diag_n0;
+static uint64_t why[2][2][2]; static int g_count_why; static int g_refine = 1; static int g_tight = 1; static uint64_t st_hot_hits;
 enum { RK_SEARCH = 0, RK_SELECT = 1, RK_SHRINK_NB = 2, RK_SHRINK_ROW = 3 };
 typedef struct { uint32_t row, lc; simpair bound; int full, kind, sub; int32_t t; } rd;
 typedef struct { uint32_t lc, e; simpair S[64]; uint32_t nS; int valid; } shr;
 typedef struct {
     int planned; uint32_t snap, snap_hdr;
+    int hot_seen;
+    uint32_t hot_end;              /* AHEAD: the plan was made WHILE the commits journalled in [snap, hot_end) were being applied */
     rd *r; uint32_t nr, capr;
     int32_t *hhead, *hnext; uint32_t hsize;
     uint64_t *vkey; int32_t *vt; uint32_t vsize, vcount; int32_t tclock;
@@ -131,7 +134,7 @@ static void plan_txn(hnsw_oracle *o, uint32_t q, txn *t)
 {
     scratch *s = &o->sc;
     hnsw_oracle_counters ct = {0, 0, 0};
-    t->nr = 0; t->nsh = 0; t->planned = 1; t->snap = nJ; t->snap_hdr = hdr_epoch; vmap_reset(t);
+    t->nr = 0; t->nsh = 0; t->planned = 1; t->snap = nJ; t->snap_hdr = hdr_epoch; t->hot_end = 0; vmap_reset(t);
     const float *qv = vec(o, q);
     uint32_t l = o->nodes[q].level, l_max = o->max_layer, ep = (uint32_t)o->enterpoint, lc = l_max;
     while (lc > l) { search_level_log(o, s, qv, ep, 1, lc, t); ep = nearest_of_W(s).id; if (lc == 0) break; lc--; }
@@ -194,6 +197,14 @@ static int validate_range(hnsw_oracle *o, uint32_t q, txn *t, const delta *arr, 
         for (int32_t i = t->hhead[hh]; i >= 0; i = t->hnext[i]) {
             const rd *r = &t->r[i];
             if (r->row != d->row || r->lc != d->lc) continue;
+            if (arr == J && ji < t->hot_end) {
+                /* a HOT delta: the row was being rewritten while the plan ran -- the plan may have seen it before, after or
+                   torn (two cache lines).  Whatever it saw of that row is void: no distance test */
+                if (r->kind == RK_SHRINK_ROW || r->kind == RK_SHRINK_NB) t->sh[r->sub].valid = 0;
+                else ok = 0;
+                st_hot_hits++;
+                continue;
+            }
             if (r->kind == RK_SHRINK_ROW) {
                 if (d->z == q && d->add && own_from_valid) continue;   /* this node's own connect */
                 t->sh[r->sub].valid = 0;
@@ -211,7 +222,11 @@ static int validate_range(hnsw_oracle *o, uint32_t q, txn *t, const delta *arr, 
             int relevant = !r->full || !nearer(r->bound, pk);     /* key(z) <= bound */
             if (!relevant) continue;
             if (r->kind == RK_SHRINK_NB) t->sh[r->sub].valid = 0;
-            else { ok = 0; if (g_count_why) why[r->kind][r->full][d->add]++; }
+            else {
+                ok = 0; if (g_count_why) why[r->kind][r->full][d->add]++;
+                if (g_diag) fprintf(stderr, "stale kind=%d lc=%u add=%d t=%d/%d rowdeg=%u z_new=%d row_new=%d age=%u\n", r->kind, d->lc, d->add, r->t, t->tclock,
+                                    row_of(o, d->row, d->lc)->n, d->z >= g_diag_n0, d->row >= g_diag_n0, ji - from);
+            }
         }
     }
     return ok;
@@ -223,6 +238,7 @@ static int validate(hnsw_oracle *o, uint32_t q, txn *t, uint32_t from, int own_f
 }
 
 static uint64_t st_spec_applied, st_fallback, st_noshrink_spec_unused, st_commits, st_rounds, st_replans, st_plans;
+static uint64_t st_hot_plans, st_hot_killed, st_hot_rec_killed, st_crit_plans, st_rounds_nocrit, st_crit_head;
 
 /* ---- parallel validated commits (PAR=1) -------------------------------------------------------
  * Every window node whose link plan holds runs its WHOLE commit (connect, shrink loop with its own validations and
@@ -493,25 +509,41 @@ int main(int argc, char **argv)
     g_par_norowcheck = getenv("PAR_NOROWCHECK") != NULL;     /* (unsound on purpose: drops rule 2) */
     g_par_noreclog = getenv("PAR_NORECLOG") != NULL;         /* (unsound on purpose: recomputations inside a dry run are not logged) */
     dry *D = calloc(Wn + 1, sizeof(dry));
+    /* AHEAD=f: the nodes that will ENTER the window next round are planned while this round's commits are
+       being applied (on the GPU: a second stream).  Such a plan saw every row in some state between "before the round's
+       commits" and "after" -- possibly torn -- so its snapshot is the journal position at the START of the commits, and
+       every delta journalled during them that sits on a row it read voids that read outright (validate_range, hot rule).
+       Modelled here by planning them after the round's FIRST group has been applied (a state in between). */
+    const double g_ahead = getenv("AHEAD") ? atof(getenv("AHEAD")) : 0.0;
+    double yield_ema = 4.0;
     while (head < K) {
         st_rounds++;
         uint32_t wend = head + Wn < K ? head + Wn : K;
         /* (re)plan everything in the window that has no valid plan */
+        uint32_t crit = 0;
         for (uint32_t j = head; j < wend; j++) {
             if (T[j].planned) {
                 int ok = validate(B, N0 + j, &T[j], T[j].snap, 0);
                 int shok = 1; for (uint32_t k = 0; k < T[j].nsh; k++) shok &= T[j].sh[k].valid;
+                if (T[j].hot_end && !T[j].hot_seen) { T[j].hot_seen = 1; if (!ok) st_hot_killed++; else if (!shok) st_hot_rec_killed++; }
                 if (ok && shok) continue;
                 st_replans++;
             }
-            plan_txn(B, N0 + j, &T[j]); st_plans++;
+            plan_txn(B, N0 + j, &T[j]); st_plans++; crit++;
+            if (j == head) st_crit_head++;
         }
+        st_crit_plans += crit;
+        if (!crit) st_rounds_nocrit++;
+        const uint32_t j0 = nJ;                            /* journal position at the start of this round's commits */
+        uint32_t hot_lo = wend, hot_hi = wend;
+        int hot_done = g_ahead <= 0.0;
         uint32_t run = 0;
         while (g_par && head < wend) {
             /* one iteration of the parallel commit: dry runs of the whole window, then the longest conflict-free group */
             uint32_t n = wend - head, nd = 0, pfx = 0;
             st_par_iter++;
             for (uint32_t b = 0; b < n; b++) { dry_run(B, N0 + head + b, &T[head + b], &D[b]); nd++; if (!D[b].ready) break; }
+            if (getenv("DIAG") && !D[0].ready && T[head].planned) { g_diag = 1; g_diag_n0 = N0; validate(B, N0 + head, &T[head], T[head].snap, 0); g_diag = 0; }
             for (uint32_t b = 0; b < nd; b++) {
                 if (!D[b].ready) { if (b) st_par_notready++; break; }
                 int conflict = 0;
@@ -528,6 +560,17 @@ int main(int argc, char **argv)
                 st_spec_applied += d->n_spec; st_fallback += d->n_fallback; st_commits++;
             }
             for (uint32_t b = 0; b < nd; b++) dry_free(&T[head + b], &D[b], b < pfx);
+            if (!hot_done && pfx) {
+                /* the look-ahead plans, made against the graph as it stands in the middle of the round's commits */
+                hot_done = 1;
+                uint32_t X = (uint32_t)(yield_ema * g_ahead) + 2;
+                hot_hi = wend + X < K ? wend + X : K;
+                for (uint32_t j = hot_lo; j < hot_hi; j++) {
+                    if (T[j].planned) continue;
+                    plan_txn(B, N0 + j, &T[j]); st_plans++; st_hot_plans++;
+                    T[j].snap = j0; T[j].hot_end = 0xFFFFFFFFu; T[j].hot_seen = 0;     /* (the end is set when the commits are over) */
+                }
+            }
             if (!pfx) break;
             head += pfx; run += pfx;
             { int gb = pfx <= 1 ? 0 : pfx <= 2 ? 1 : pfx <= 4 ? 2 : pfx <= 8 ? 3 : pfx <= 16 ? 4 : pfx <= 32 ? 5 : pfx <= 64 ? 6 : 7; grp_hist[gb]++; }
@@ -540,6 +583,8 @@ int main(int argc, char **argv)
             commit_txn(B, N0 + head, t);
             head++; run++;
         }
+        for (uint32_t j = hot_lo; j < hot_hi; j++) if (T[j].hot_end == 0xFFFFFFFFu) T[j].hot_end = nJ;
+        yield_ema = 0.8 * yield_ema + 0.2 * run;
         int b = run <= 1 ? 0 : run <= 2 ? 1 : run <= 4 ? 2 : run <= 8 ? 3 : run <= 16 ? 4 : run <= 32 ? 5 : run <= 64 ? 6 : 7;
         run_hist[b]++;
     }
@@ -555,6 +600,13 @@ int main(int argc, char **argv)
                (unsigned long)st_par_conf_row, (unsigned long)st_par_conf_promote, (unsigned long)st_par_notready);
         printf("  group-size histogram (<=1,2,4,8,16,32,64,>64):"); for (int i = 0; i < 8; i++) printf(" %lu", (unsigned long)grp_hist[i]); printf("\n");
     }
+    if (g_ahead > 0.0)
+        printf("  look-ahead plans (made during the commits): %lu, of which voided by a hot delta on a row they read: link plan %lu, a record only %lu; plans on the critical path: %.2f per round (%.1f %% of the rounds none; the head itself in %.1f %%)\n",
+               (unsigned long)st_hot_plans, (unsigned long)st_hot_killed, (unsigned long)st_hot_rec_killed, (double)st_crit_plans / st_rounds,
+               100.0 * st_rounds_nocrit / st_rounds, 100.0 * st_crit_head / st_rounds);
+    else
+        printf("  plans on the critical path: %.2f per round (%.1f %% of the rounds none; the head itself in %.1f %%)\n", (double)st_crit_plans / st_rounds,
+               100.0 * st_rounds_nocrit / st_rounds, 100.0 * st_crit_head / st_rounds);
     printf("  head-invalid reasons [kind][full][add]: search nf- %lu nf+ %lu f- %lu f+ %lu | select nf- %lu nf+ %lu f- %lu f+ %lu\n", (unsigned long)why[0][0][0],(unsigned long)why[0][0][1],(unsigned long)why[0][1][0],(unsigned long)why[0][1][1],(unsigned long)why[1][0][0],(unsigned long)why[1][0][1],(unsigned long)why[1][1][0],(unsigned long)why[1][1][1]);
     /* predicted build rate: round overhead 1.5 ms, commit 15 us, spec shrink 2 us, fallback 52 us */
     double tsec = st_rounds * 1.5e-3 + K * 15e-6 + st_spec_applied * 2e-6 + st_fallback * 52e-6;
