@@ -327,7 +327,59 @@ class Bench:
         s.n_qbatches = 8
         s.Qall = np.random.default_rng(2).random((s.n_qbatches * s.B * s.world, s.dim), dtype=np.float32)
         s.levels = draw_levels(s.N, s.M, 7)
+        s.first_contact()
 
+    def first_contact(self):
+        """N > 1: within the first seconds every rank says what it sees -- its device, the RCCL world, which peers it can
+        reach directly, and how the two ways of moving one step's [2, B, k] result block compare (all-gather over RCCL vs a
+        plain D2H copy) -- and the run FAILS if the world is not the --gpus it was asked for.  The driver's multi-GPU node is
+        the first hardware this path meets: the report is what tells a broken fabric from a slow one."""
+        s = self
+        want = int(getattr(s.args, "gpus", 1) or 1)
+        if want != s.world:
+            raise SystemExit("bench.py --gpus %d but WORLD_SIZE is %d: launch with torch.distributed.run --nproc-per-node %d (rank %d)"
+                             % (want, s.world, want, s.rank))
+        s.first_contact_rows = None
+        if s.world == 1:
+            return
+        t = s.torch
+        if s.dist.get_world_size() != s.world or s.dist.get_rank() != s.rank:
+            raise SystemExit("process group disagrees with the environment: world %d/%d rank %d/%d"
+                             % (s.dist.get_world_size(), s.world, s.dist.get_rank(), s.rank))
+        nd = t.cuda.device_count()
+        if not s.one_device and nd < s.world:
+            raise SystemExit("rank %d: %d ranks but only %d visible GPUs (one process per GPU; HNSW_BENCH_ONE_DEVICE=1 only for dry control-flow runs)"
+                             % (s.rank, s.world, nd))
+        dev = t.device("cuda", s.local_rank)
+        peers = None
+        if not s.one_device and nd > 1:
+            try:
+                peers = [int(t.cuda.can_device_access_peer(s.local_rank, d)) if d != s.local_rank else 1 for d in range(nd)]
+            except (RuntimeError, AssertionError):
+                peers = None
+        blk = t.zeros((2, s.B, s.k), dtype=t.int32, device=dev if s.backend == "nccl" else "cpu")
+        outb = t.empty((s.world * 2, s.B, s.k), dtype=t.int32, device=blk.device)
+        times = {}
+        for name, fn in (("all_gather_us", lambda: s.dist.all_gather_into_tensor(outb, blk)),
+                         ("d2h_copy_us", lambda: blk.cpu() if blk.is_cuda else blk.clone())):
+            fn()
+            t.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                fn()
+            t.cuda.synchronize()
+            times[name] = round(1e6 * (time.perf_counter() - t0) / 5, 1)
+        mine = dict(first_contact=True, rank=s.rank, local_rank=s.local_rank, device=t.cuda.get_device_name(s.local_rank),
+                    visible_gpus=nd, backend=s.backend, rccl_world=s.dist.get_world_size() if s.backend == "nccl" else None,
+                    peer_access_row=peers, result_block_bytes=int(blk.numel() * 4), **times)
+        rows = [None] * s.world
+        s.dist.all_gather_object(rows, mine)
+        if s.rank == 0:
+            for r_ in rows:
+                print("[bench first-contact] " + json.dumps(r_), file=sys.stderr, flush=True)
+            if s.backend == "nccl" and any(r_["rccl_world"] != want for r_ in rows):
+                raise SystemExit("rccl_world != --gpus %d on some rank" % want)
+        s.first_contact_rows = rows
 
     def build_index(self):
         """the graph the headline runs on (--graph): rank 0 imports / builds it, the replicas receive it over RCCL"""
@@ -1231,7 +1283,7 @@ class Bench:
             "gather_verified": s.gather_ok,
             "rccl_world": s.world if (s.world > 1 and s.backend == "nccl") else None,
             "collective_backend": s.backend if s.world > 1 else None,
-            "per_rank": s.per_rank, "index_replication": s.replication, "topk_exchange": s.gather_cmp,
+            "per_rank": s.per_rank, "index_replication": s.replication, "topk_exchange": s.gather_cmp, "first_contact": s.first_contact_rows,
             "recall_at_%d" % s.k: None if s.recall is None else round(s.recall, 4),
             "build_seconds": None if s.t_build is None else round(s.t_build, 2),
             "host_buffers_qps": round(s.host_qps, 1), "host_buffers": s.host, "single_process_group": s.group_leg, "device_call": s.dev_calls,

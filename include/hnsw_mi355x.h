@@ -253,7 +253,8 @@ hnsw_status hnsw_deserialize(const void *buf, uint64_t bytes, uint64_t seed, int
  *             "waves_per_cu" (residency the visited table is sized for, default 8), "visited_bounded"
  *             (1: a full LDS visited table stops recording -- exact results, distance evaluations may
  *             exceed the reference's; 0: the table continues in HBM -- counters equal the reference's),
- *             "lean" (specialised dim-128 kernel on/off), "grid_stride", "query_in_lds", "time_launches",
+ *             "lean" (specialised dim-128 kernel on/off), "tie_census" (1: searches run the census form of that
+ *             kernel, see hnsw_get_tie_counters), "grid_stride", "query_in_lds", "time_launches",
  *             "lds_buckets" / "lds_hash_bits" / "tag_table" / "tag_bb" / "idbits" / "grid" (tests)
  *   build     "occ_window" (slots of the exact parallel insert, 0 = serial), "occ_min_batch",
  *             "occ_ahead_x10", "select_shortcut" (1: select_neighbors after search_level is the head
@@ -270,6 +271,20 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value);
 
 hnsw_status hnsw_get_counters(hnsw_index *h, hnsw_counters *search, hnsw_counters *insert);
 hnsw_status hnsw_reset_counters(hnsw_index *h);
+
+/* Tie census (since the last hnsw_reset_counters).  The reference orders SimPair by similarity ALONE (core.rs:292-300)
+ * and leaves equal similarities to std::collections::BinaryHeap; the engine (like the parity oracle) breaks them by
+ * the smaller id.  The two can only part where a DECISION compared equal distances of two different nodes: the stop
+ * test (core.rs:635), the accept test with W full (:657), a select_neighbors cut (:733, :741-754), or equal distances
+ * among the k + 1 nearest of an answer.  The kernels count every such comparison they make -- a superset of the
+ * reference's own (a whole adjacency row is merged at once where the reference walks it id by id), never fewer:
+ *   out[0] events in searches      (only while tuning "tie_census" = 1: the census form of the dim-128 search kernel)
+ *   out[1] queries with at least one
+ *   out[2] events in inserts / deletes: the plans' search_level + select_neighbors, the speculative and the recomputed
+ *          select_neighbors of the shrink loop (always counted by the dim-128 plan kernels and by every select)
+ *   out[3] insert plans with at least one (a node planned twice counts twice)
+ * Zero means: every answer / every link is what the reference's binary produces, whatever its heap does with ties.  */
+hnsw_status hnsw_get_tie_counters(hnsw_index *h, uint64_t *out4);
 
 /* Timing of the most recent search kernel launch measured with HIP events on
  * the stream it ran on (milliseconds); synchronises that stream.             */

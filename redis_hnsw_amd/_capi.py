@@ -74,6 +74,7 @@ SIGNATURES = {
     "hnsw_set_tuning": (C.c_int, [H, C.c_char_p, C.c_int64]),
     "hnsw_get_counters": (C.c_int, [H, C.POINTER(Counters), C.POINTER(Counters)]),
     "hnsw_reset_counters": (C.c_int, [H]),
+    "hnsw_get_tie_counters": (C.c_int, [H, u64p]),
     "hnsw_last_search_kernel_ms": (C.c_int, [H, fp]),
     "hnsw_metric_pairs": (C.c_int, [C.c_int, fp, fp, C.c_uint32, C.c_uint32, fp]),
     # one process, several GPUs

@@ -43,6 +43,11 @@ struct DevHeader {
     unsigned long long ctr_search[4]; // n_dist, n_ids, n_expand, n_spill
     unsigned long long ctr_insert[4];
     unsigned long long prof[8];       // HNSW_PHASE_TIMERS builds: cycles per phase
+    // Tie census (hnsw_get_tie_counters): decisions that compared EQUAL distances of two different nodes -- the only places
+    // where the engine's (distance, id) order and the reference's sim-only order on std's BinaryHeap (core.rs:292-300, :635,
+    // :657, :733) can part.  [0] events in searches (tuning "tie_census"), [1] queries with at least one, [2] events in
+    // inserts (plan searches, select_neighbors cuts of plans / speculative records / recomputed shrinks), [3] plans with one.
+    unsigned long long ctr_tie[4];
 };
 
 // The synchronisation point of the code in this file -- lanes of ONE wavefront handing each other data.  The file is
@@ -567,8 +572,12 @@ __device__ __forceinline__ bool visited_reserve(Visited &v, int lane, unsigned l
 // ---------------------------------------------------------------------------
 template <int R>
 __device__ __forceinline__ uint32_t merge_sorted(uint64_t *W, uint32_t nW, uint32_t cap, uint64_t nk,
-                                                 bool take, int lane)
+                                                 bool take, int lane, uint32_t *ties = nullptr)
 {
+    // ties: += 1 when, after this merge, the list's last key and the nearest key the merge pushed OUT of it have equal
+    // distances (a select_neighbors cut between equal similarities, core.rs:733 / :741-754: which of the two stays is the
+    // heap's choice in the reference).  Together with the callers' count of arrivals REJECTED at an equal distance this
+    // sees every tie across the final cut (the pair (cap-1, cap) of the union is checked at every eviction).
     const uint64_t tmask = __ballot(take);
     if (tmask == 0) return nW;
     uint64_t w[R];
@@ -607,6 +616,16 @@ __device__ __forceinline__ uint32_t merge_sorted(uint64_t *W, uint32_t nW, uint3
     if (take && mypos < cap) W[mypos] = nk;
     const uint32_t total = nW + (uint32_t)__popcll(tmask);
     dev_sync();
+    if (ties && total > cap) {
+        const uint32_t bd = (uint32_t)(W[cap - 1] >> 32);                 // the list's last distance now
+        bool eq = take && mypos == cap && (uint32_t)(nk >> 32) == bd;     // the key that landed right behind it
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t i = r * 64 + lane;
+            eq |= i < nW && i + up[r] == cap && (uint32_t)(w[r] >> 32) == bd;
+        }
+        *ties += __ballot(eq) ? 1u : 0u;
+    }
     return total < cap ? total : cap;
 }
 
@@ -686,6 +705,7 @@ __host__ __device__ inline uint32_t occ_meta(uint32_t lc, uint32_t kind, uint32_
 
 struct WorkCtr {
     uint32_t n_dist, n_ids, n_expand;
+    uint32_t n_tie;          // tie census (DevHeader::ctr_tie): counted by the routines instantiated with TIES
     OccRead *log;            // nullptr: no read log
     uint32_t log_n, log_cap; // entries written / capacity (log_n keeps counting past the capacity)
 #ifdef HNSW_PHASE_TIMERS

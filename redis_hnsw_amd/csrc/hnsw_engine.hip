@@ -462,7 +462,7 @@ hnsw_status try_launch_lean(hnsw_index *h, const float *dQ, uint32_t B, uint32_t
     }
     const bool wide = h->stride0 > 64 || h->strideU > 64;   // rows of 64..127 ids: two row words per lane
     h->last_search_duo = false;
-    if (h->duo && h->fmt == FMT_F32 && (uint64_t)B * std::max(h->cur_conc, 1u) <= h->duo_max && idbits - 11 <= 14) {
+    if (h->duo && !h->tie_census && h->fmt == FMT_F32 && (uint64_t)B * std::max(h->cur_conc, 1u) <= h->duo_max && idbits - 11 <= 14) {
         // few enough queries in flight that each can have two SIMDs: a walker wave and a W-keeper wave per query
         const uint32_t db2 = idbits - 11 > 13 ? 2u : 3u;
         hnsw_status s2 = wide ? launch_duo_v<true>(h, R, db2, dQ, B, k, idbits, d_ids, d_sims, d_nout, st, done)
@@ -727,6 +727,7 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
     if (!std::strcmp(key, "occ_log_cap")) { h->occ_log_cap = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), kOccMaxReads); return HNSW_OK; }
     if (!std::strcmp(key, "occ_min_batch")) { h->occ_min_batch = (uint32_t)std::max<int64_t>(value, 1); return HNSW_OK; }
     if (!std::strcmp(key, "lean")) { h->lean = value != 0; return HNSW_OK; }
+    if (!std::strcmp(key, "tie_census")) { h->tie_census = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "duo")) { h->duo = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "plan_duo")) { h->plan_duo = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "occ_chain")) { h->occ_chain = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 16); return HNSW_OK; }
@@ -1020,7 +1021,18 @@ hnsw_status hnsw_reset_counters(hnsw_index *h)
     if (!h) return HNSW_ERR_INVALID;
     ON_DEVICE(h);
     HIP_TRY(h, hipDeviceSynchronize());
-    HIP_TRY(h, hipMemset((char *)h->d_hdr + offsetof(DevHeader, ctr_search), 0, sizeof(unsigned long long) * 16));
+    static_assert(offsetof(DevHeader, ctr_tie) == offsetof(DevHeader, ctr_search) + sizeof(unsigned long long) * 16, "counters are contiguous");
+    HIP_TRY(h, hipMemset((char *)h->d_hdr + offsetof(DevHeader, ctr_search), 0, sizeof(unsigned long long) * 20));
+    return HNSW_OK;
+}
+
+hnsw_status hnsw_get_tie_counters(hnsw_index *h, uint64_t *out)
+{
+    if (!h || !out) return HNSW_ERR_INVALID;
+    ON_DEVICE(h);
+    DevHeader hd;
+    HIP_TRY(h, hipMemcpy(&hd, h->d_hdr, sizeof hd, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; ++i) out[i] = hd.ctr_tie[i];
     return HNSW_OK;
 }
 

@@ -145,6 +145,7 @@ struct hnsw_index {
     bool bf16 = false;               // fmt == FMT_BF16 (the specialised dim-128 kernel has a bf16 form)
     bool select_shortcut = true;     // select_neighbors after search_level = the head of W (hnsw_insert.hpp); 0 = the full extension
     bool plan_lean = true;           // dim-128 insert plans (single adds, the windowed exact build) search with the specialised routine (hnsw_plan_lean.hpp)
+    bool tie_census = false;         // tuning: searches run the census form of the specialised kernel (hnsw_get_tie_counters; f32 rows, one wave per query)
     bool lean = true;                // dim-128 searches use the specialised kernel (hnsw_search_lean.hpp) when its preconditions hold
     bool duo = true;                 // ... in its two-wave form (hnsw_search_duo.hpp) when at most duo_max queries are in flight
     uint32_t duo_max = 1024;         // 4 workgroups of two waves per CU: every query gets two SIMD slots

@@ -31,10 +31,19 @@ constexpr uint32_t kMaxLayers = 32;       // levels 0..31
 // untouched.  Result in m.S[0..n), sorted; returns n.
 // ---------------------------------------------------------------------------
 // S holds up to kSelMax keys (m_max0 = 2M): one register slice per 64; the four-slice form serves M > 64 only
+// ties (tie census, DevHeader::ctr_tie): += the select_neighbors cuts that fell between equal distances (core.rs:733,
+// :741-754) -- an arrival rejected at the list's own last distance, or (merge_sorted) pushed out next to an equal one
+__device__ __forceinline__ uint32_t merge_S(uint64_t *S, uint32_t nS, uint32_t mcap, uint64_t key, bool have, uint64_t worst, int lane,
+                                            uint32_t *ties)
+{
+    const bool take = have && key < worst;
+    if (ties) *ties += __ballot(have && !take && (uint32_t)(key >> 32) == (uint32_t)(worst >> 32)) ? 1u : 0u;
+    if (mcap > 128) return merge_sorted<4>(S, nS, mcap, key, take, lane, ties);
+    return mcap > 64 ? merge_sorted<2>(S, nS, mcap, key, take, lane, ties) : merge_sorted<1>(S, nS, mcap, key, take, lane, ties);
+}
 __device__ __forceinline__ uint32_t merge_S(uint64_t *S, uint32_t nS, uint32_t mcap, uint64_t key, bool take, int lane)
 {
-    if (mcap > 128) return merge_sorted<4>(S, nS, mcap, key, take, lane);
-    return mcap > 64 ? merge_sorted<2>(S, nS, mcap, key, take, lane) : merge_sorted<1>(S, nS, mcap, key, take, lane);
+    return merge_S(S, nS, mcap, key, take, ~0ull, lane, nullptr);
 }
 
 // GV: the graph (GraphView) or a private overlay of it (OverlayView, hnsw_occ_par.hpp): rows are reached through
@@ -69,6 +78,9 @@ __device__ __forceinline__ uint32_t select_topm(const GV &g, const WaveMem &m, V
         if (nS > mcap) nS = mcap;
     }
     wave_sync();
+    // tie census: the candidate list itself is cut between equal distances (cand is sorted; `ignored` aside)
+    if (ncand > mcap && nS == mcap && (uint32_t)(cand[mcap] >> 32) == (uint32_t)(m.S[mcap - 1] >> 32) && key_id(cand[mcap]) != ignored)
+        ctr.n_tie += 1u;
 
     const uint32_t stride = lc ? g.strideU : g.stride0;
     if constexpr (MODE == MODE_AVX) {
@@ -102,7 +114,7 @@ __device__ __forceinline__ uint32_t select_topm(const GV &g, const WaveMem &m, V
                 for (int r = 0; r < 8; ++r)
                     if (sub == r && live[r]) { key = pack_key(dd[r], idr[r]); have = true; }
                 const uint64_t worst = nS == mcap ? m.S[mcap - 1] : ~0ull;
-                nS = merge_S(m.S, nS, mcap, key, have && key < worst, lane);   // core.rs:717
+                nS = merge_S(m.S, nS, mcap, key, have, worst, lane, &ctr.n_tie);   // core.rs:717
                 return;
             }
             for (uint32_t pass = 0; pass * 32 < count; ++pass) {
@@ -126,7 +138,7 @@ __device__ __forceinline__ uint32_t select_topm(const GV &g, const WaveMem &m, V
                         if (sub == r0 + rr && live[rr]) { key = pack_key(dd[rr], idr[rr]); have = true; }
                 }
                 const uint64_t worst = nS == mcap ? m.S[mcap - 1] : ~0ull;
-                nS = merge_S(m.S, nS, mcap, key, have && key < worst, lane);   // core.rs:717
+                nS = merge_S(m.S, nS, mcap, key, have, worst, lane, &ctr.n_tie);   // core.rs:717
             }
         };
         auto drain = [&](uint32_t keep_below) {             // evaluate blocks of 64 until fewer than keep_below wait
@@ -218,7 +230,7 @@ __device__ __forceinline__ uint32_t select_topm(const GV &g, const WaveMem &m, V
             const bool have = (uint32_t)lane < nf;
             const uint64_t key = have ? pack_key(m.dsc[lane], m.fresh[lane]) : ~0ull;
             const uint64_t worst = nS == mcap ? m.S[mcap - 1] : ~0ull;
-            nS = merge_S(m.S, nS, mcap, key, have && key < worst, lane); // core.rs:717
+            nS = merge_S(m.S, nS, mcap, key, have, worst, lane, &ctr.n_tie); // core.rs:717
         }
     }
     wave_sync();
@@ -241,10 +253,12 @@ __device__ __forceinline__ uint32_t select_topm(const GV &g, const WaveMem &m, V
 // extension (its work counters then equal the reference's).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ bool select_is_head_of_W(uint32_t ef, uint32_t mcap, uint32_t nW) { return ef >= mcap || nW < ef; }
-__device__ __forceinline__ uint32_t select_head_of_W(const WaveMem &m, uint32_t nW, uint32_t mcap, int lane)
+__device__ __forceinline__ uint32_t select_head_of_W(const WaveMem &m, uint32_t nW, uint32_t mcap, int lane, uint32_t *ties = nullptr)
 {
     const uint32_t nS = nW < mcap ? nW : mcap;
     for (uint32_t i = lane; i < nS; i += 64) m.S[i] = m.W[i] & ~1ull;
+    // tie census: the cut falls between equal distances (core.rs:733: which of the two is linked is the heap's choice)
+    if (ties && nW > mcap && mcap && (uint32_t)(m.W[mcap - 1] >> 32) == (uint32_t)(m.W[mcap] >> 32)) *ties += 1u;
     wave_sync();
     return nS;
 }

@@ -312,6 +312,7 @@ __device__ __forceinline__ void occ_plan_finish(const GraphView &g, const OccBuf
         atomicAdd(&g.hdr->ctr_insert[0], (unsigned long long)ctr.n_dist);
         atomicAdd(&g.hdr->ctr_insert[1], (unsigned long long)ctr.n_ids);
         atomicAdd(&g.hdr->ctr_insert[2], (unsigned long long)ctr.n_expand);
+        if (ctr.n_tie) { atomicAdd(&g.hdr->ctr_tie[2], (unsigned long long)ctr.n_tie); atomicAdd(&g.hdr->ctr_tie[3], 1ull); }   // tie census
     }
 }
 
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_plan(GraphView g, OccBufs ob, uin
         uint32_t nS;
         if (shortcut && select_is_head_of_W(ef, mlinks, nW)) {
             // the selection is the head of W (see select_head_of_W): it reads nothing the search did not read
-            nS = select_head_of_W(m, nW, mlinks, lane);
+            nS = select_head_of_W(m, nW, mlinks, lane, &ctr.n_tie);
         } else {
             // select's reads: the rows of all members of W (logged before S exists; the bound is patched in below)
             const uint32_t sel_log0 = ctr.log_n;
@@ -473,6 +474,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_shrinks(GraphView g, OccBufs ob, 
         return;
     }
     if (lane == 0) { sp->w_dist = nolog.n_dist; sp->w_ids = nolog.n_ids; }
+    if (lane == 0 && nolog.n_tie) atomicAdd(&g.hdr->ctr_tie[2], (unsigned long long)nolog.n_tie);   // tie census: a cut between equal distances
     const uint32_t bound = (uint32_t)(m.S[nS - 1] >> 32);
     for (uint32_t i = lane; i < nS; i += 64) sp->S[i] = key_id(m.S[i]);
     // reads: row e itself, and the rows of econn's members
@@ -553,7 +555,7 @@ constexpr uint32_t TEAM_SELECT = 1u, TEAM_EXIT = 2u;
 constexpr uint32_t kTeamCand = 256;                   // a share of econn: a row holds at most 1 023 ids, a team has >= 4 waves
 struct TeamTask {
     uint32_t op, e, lc, mmax, nE, ignored, pad0, pad1;
-    uint32_t nS[4], fail[4], n_dist[4], n_ids[4];
+    uint32_t nS[4], fail[4], n_dist[4], n_ids[4], n_tie[4];
 };
 struct TeamCfg {                                      // helper LDS layout (the same for every helper), set by the host
     uint32_t hbytes;                                  // bytes per helper
@@ -630,6 +632,7 @@ __device__ __forceinline__ void team_helper(const GV &g, volatile TeamTask *task
             task->fail[wave] = fail ? 1u : 0u;
             task->n_dist[wave] = c.n_dist;
             task->n_ids[wave] = c.n_ids;
+            task->n_tie[wave] = c.n_tie;
         }
         team_bar();                                         // the results are there
     }
@@ -656,6 +659,7 @@ __device__ __forceinline__ uint32_t team_select(const GV &g, const WaveMem &m, V
         fail |= __builtin_amdgcn_readfirstlane(task->fail[w]) != 0u;
         ctr.n_dist += __builtin_amdgcn_readfirstlane(task->n_dist[w]);
         ctr.n_ids += __builtin_amdgcn_readfirstlane(task->n_ids[w]);
+        ctr.n_tie += __builtin_amdgcn_readfirstlane(task->n_tie[w]);
         const uint64_t *Sw = reinterpret_cast<const uint64_t *>(hmem0 + (size_t)(w - 1) * tc.hbytes + (size_t)kTeamCand * 8 + 64 * 4 + 64 * 4);
         for (uint32_t base = 0; base < nSw; base += 64) {
             const bool have = base + (uint32_t)lane < nSw;
@@ -670,7 +674,7 @@ __device__ __forceinline__ uint32_t team_select(const GV &g, const WaveMem &m, V
             const bool dup = have && lo < nS && m.S[lo] == key;
             const uint64_t worst = nS == mmax ? m.S[mmax - 1] : ~0ull;
             wave_sync();
-            nS = merge_S(m.S, nS, mmax, key, have && !dup && key < worst, lane);
+            nS = merge_S(m.S, nS, mmax, key, have && !dup, worst, lane, &ctr.n_tie);
         }
     }
     return nS;
@@ -846,6 +850,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit(GraphView g, Oc
                     if (fail) break;
                     w_dist += cnt + nolog.n_dist;
                     w_ids += cnt + nolog.n_ids;
+                    if (lane == 0 && nolog.n_tie) atomicAdd(&g.hdr->ctr_tie[2], (unsigned long long)nolog.n_tie);   // tie census
                     n_fallback += 1;
                     if (k < 0) n_norec += 1;
                     {
@@ -1089,6 +1094,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_del_commit(GraphView g
                 if (fail) break;
                 w_dist += cnt + nolog.n_dist;
                 w_ids += cnt + nolog.n_ids;
+                if (lane == 0 && nolog.n_tie) atomicAdd(&g.hdr->ctr_tie[2], (unsigned long long)nolog.n_tie);   // tie census
                 n_fallback += 1;
             }
 #ifdef HNSW_OCC_DEBUG

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g
     uint64_t live = 0;                                       // sub-operations whose reads stand for the dry run
     uint32_t n_hash = 0;                                     // entries in the LDS hash
     uint32_t n_delta = 0, promotes = 0;
-    uint32_t n_spec = 0, n_fallback = 0, n_norec = 0;
+    uint32_t n_spec = 0, n_fallback = 0, n_norec = 0, n_tie = 0;
     unsigned long long w_dist = 0, w_ids = 0, w_skipped = 0;
 
     for (;;) {
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g
                 const uint32_t n_shr = sl->n_shr;
                 d_ = wall_clock64();
                 dry_ticks = d_;
-                live = 0; n_delta = 0; promotes = 0; n_spec = n_fallback = n_norec = 0; w_dist = w_ids = w_skipped = 0;
+                live = 0; n_delta = 0; promotes = 0; n_spec = n_fallback = n_norec = n_tie = 0; w_dist = w_ids = w_skipped = 0;
                 n_hash = sl->n_reads;
                 occ_build_hash(sc, reads, n_hash, shr, n_shr, lane);
                 occ_check_range<MODE, T>(g, m, sc, ob, reads, shr, id, sl->snapU, nJ, lane, false, kEmpty, nullptr, sl->snap);
@@ -403,6 +403,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g
                                 if (fail) break;
                                 w_dist += cnt + nolog.n_dist;
                                 w_ids += cnt + nolog.n_ids;
+                                n_tie += nolog.n_tie;            // tie census (counted when the dry run commits)
                                 n_fallback += 1;
                                 if (k < 0) n_norec += 1;
                                 // what it read, for the nodes committed alongside: the rows of e's members, bound = the last
@@ -583,6 +584,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g
                 atomicAdd(&g.hdr->ctr_insert[0], w_dist);
                 atomicAdd(&g.hdr->ctr_insert[1], w_ids);
                 atomicAdd(&g.hdr->ctr_insert[3], w_skipped);
+                if (n_tie) atomicAdd(&g.hdr->ctr_tie[2], (unsigned long long)n_tie);
                 atomicAdd(&ob.ctl->n_spec, (unsigned long long)n_spec);
                 atomicAdd(&ob.ctl->n_fallback, (unsigned long long)n_fallback);
                 atomicAdd(&ob.ctl->n_norec, (unsigned long long)n_norec);

@@ -83,7 +83,7 @@ struct PlanLean {
     {
         DuoSeq ks = {0};
         WorkCtr kc = {};
-        while (duo_keep<R, WIDE>(g, wbuf_of(lds), box_of(lds), ef, ks, lane, kc)) {}
+        while (duo_keep<R, WIDE, LOG>(g, wbuf_of(lds), box_of(lds), ef, ks, lane, kc)) {}
     }
 };
 
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(DUO ? 128 : 64, 1) void k_occ_plan_lean(GraphView g
         const uint32_t wnearest = key_id(m.W[0]);
         uint32_t nS;
         if (shortcut && select_is_head_of_W(ef, mlinks, nW)) {
-            nS = select_head_of_W(m, nW, mlinks, lane);
+            nS = select_head_of_W(m, nW, mlinks, lane, &ctr.n_tie);
         } else {
             // select's reads: the rows of all members of W (logged before S exists; the bound is patched in below)
             const uint32_t sel_log0 = ctr.log_n;
@@ -279,6 +279,7 @@ __global__ __launch_bounds__(DUO ? 128 : 64, 1) void k_occ_plan_lean(GraphView g
             atomicAdd(&g.hdr->ctr_insert[0], (unsigned long long)ctr.n_dist);
             atomicAdd(&g.hdr->ctr_insert[1], (unsigned long long)ctr.n_ids);
             atomicAdd(&g.hdr->ctr_insert[2], (unsigned long long)ctr.n_expand);
+            if (ctr.n_tie) { atomicAdd(&g.hdr->ctr_tie[2], (unsigned long long)ctr.n_tie); atomicAdd(&g.hdr->ctr_tie[3], 1ull); }
         }
         return;
     }

@@ -45,6 +45,7 @@ struct DuoBox {
     uint64_t rkey;             // keeper -> walker: W's first unexpanded entry, ~0 = none
     uint32_t nW;               // |W| (read by the walker after DUO_FIN)
     uint32_t sseq;             // messages processed so far (polled forms)
+    uint32_t ties, pad;        // keeper -> walker with DUO_FIN: the tie census of this search's merges (TIES keepers)
 };
 constexpr size_t kDuoBoxBytes = (sizeof(DuoBox) + 63) & ~(size_t)63;
 // The mailbox is polled: its accesses are volatile, and they must stay LDS instructions.  A volatile access through a
@@ -154,10 +155,11 @@ __device__ __forceinline__ void duo_reply(DuoBox *box, DuoSeq &seq, int lane)
 // ---- the keeper ------------------------------------------------------------------------------------------
 // Serves ONE search_level: from its DUO_INIT message to its DUO_FIN.  Leaves W sorted in Wbuf[0 .. nW) and returns
 // true; returns false if the first message was DUO_EXIT instead.
-template <int R, bool WIDE>
+template <int R, bool WIDE, bool TIES = false>
 __device__ __forceinline__ bool duo_keep(const GraphView &g, uint64_t *Wbuf, DuoBox *box, uint32_t ef, DuoSeq &seq, int lane,
                                          WorkCtr &ctr)
 {
+    uint32_t ties = 0;                                 // tie census of this search (merge_apply_lean, tie_stop_test)
     PH_T0();
     DuoBoxLds vb = duo_lds(box);
     uint32_t lc = 0, stride = g.stride0;
@@ -193,13 +195,16 @@ __device__ __forceinline__ bool duo_keep(const GraphView &g, uint64_t *Wbuf, Duo
                 for (int r = 0; r < R; ++r) w[r] += ((uint32_t)w[r] == nlo) ? 1ull : 0ull;
                 kk += (take && (uint32_t)kk == nlo) ? 1ull : 0ull;
             }
-            nW = merge_regs_lean<R>(w, Wbuf, nW, ef, kk, take, lane, worst);      // core.rs:659-664
+            nW = merge_regs_lean<R, TIES>(w, Wbuf, nW, ef, kk, take, lane, worst, &ties);      // core.rs:659-664
+            // the candidate the walker expands next, against W's last key with everything merged (core.rs:635)
+            if constexpr (TIES) { if (nk != ~0ull && !(fl & DUO_INIT)) tie_stop_test<R>(Wbuf, nW, nk, &ties); }
         }
         if (fl & DUO_FIN) {
 #pragma unroll
             for (int r = 0; r < R; ++r) Wbuf[r * 64 + lane] = w[r];
             lds_order();
             if (lane == 0) vb->nW = nW + (warm == 0x9E3779B9u && lane == 64 ? 1u : 0u);   // (keeps the prefetches alive)
+            if (lane == 0) vb->ties = ties;
             PH_MARK(ctr, 6);
             duo_reply(box, seq, lane);
             return true;
@@ -228,7 +233,7 @@ __device__ __forceinline__ bool duo_keep(const GraphView &g, uint64_t *Wbuf, Duo
 // ---- the walker ------------------------------------------------------------------------------------------
 // Returns |W| (W itself is in Wbuf once the keeper has answered DUO_FIN), or kEmpty when the visited table stopped
 // recording: the caller redoes the search with search_level_lean (ctr is left as it was on entry).
-template <class VEC, int BB, int DB, bool WIDE, bool LOG = false>
+template <class VEC, int BB, int DB, bool WIDE, bool LOG = false, bool TIES = LOG>
 __device__ __forceinline__ uint32_t duo_walk(const GraphView &g, uint64_t *Wbuf, DuoBox *box, DuoSeq &seq, TagSet<BB, DB> &vis,
                                              const typename VEC::Q &qr, uint32_t ep, uint32_t ef, uint32_t lc, WorkCtr &ctr,
                                              int lane)
@@ -345,6 +350,8 @@ __device__ __forceinline__ uint32_t duo_walk(const GraphView &g, uint64_t *Wbuf,
             duo_wait(box, seq, worst, rkey);
             PH_MARK(ctr, 4);  // waiting for the keeper
             const bool take = mine && key < worst;                // core.rs:657
+            if constexpr (TIES)                                   // an arrival rejected at W's own last distance
+                ctr.n_tie += (uint32_t)__popcll(__ballot(mine && !take && (uint32_t)(key >> 32) == (uint32_t)(worst >> 32)));
             if (!last) {
                 duo_send(box, seq, key, take, ~0ull, 0u, lane);        // core.rs:659-664, by the keeper
             } else {
@@ -377,6 +384,7 @@ __device__ __forceinline__ uint32_t duo_walk(const GraphView &g, uint64_t *Wbuf,
     uint64_t wv, rv;
     duo_wait(box, seq, wv, rv);                                        // the keeper has written W out
     const uint32_t nW = __builtin_amdgcn_readfirstlane(duo_lds(box)->nW);
+    if constexpr (TIES) ctr.n_tie += __builtin_amdgcn_readfirstlane(duo_lds(box)->ties);
     if constexpr (LOG) occ_finalize_search_log(ctr, log_start, lc, nW == ef ? Wbuf[ef - 1] : ~0ull, lane);
     else (void)log_start;
     return nW;

@@ -226,17 +226,39 @@ struct LeanW {
     static constexpr size_t kBytes = (size_t)kSlots * 8;
 };
 
-template <int R>
+// TIES (the tie census, DevHeader::ctr_tie).  Every accept test the reference makes while it walks this row one neighbour
+// at a time (core.rs:657, e.sim == f.sim with W full) compares an ARRIVING key with the key that is W's last at that
+// moment; that key can only have moved outwards by the end of the row, so after the merge the two are neighbours in the
+// stretch from W's last slot outwards (or the arrival was rejected against the row's first threshold: counted by the
+// caller).  Counted: arrivals with an equal neighbour there, and an equal pair across W's end.
+template <int R, bool TIES = false>
 __device__ __forceinline__ uint32_t merge_apply_lean(uint64_t (&w)[R], uint64_t *Wbuf, uint32_t nW, uint32_t cap, uint64_t nk,
                                                      bool take, const uint32_t (&up)[R], uint32_t mypos, uint32_t n_new,
-                                                     int lane, uint64_t &worst)
+                                                     int lane, uint64_t &worst, uint32_t *ties = nullptr)
 {
     uint32_t total = nW + n_new;
+    const uint32_t all = total;
     if (total > cap) total = cap;
 #pragma unroll
     for (int r = 0; r < R; ++r) Wbuf[(uint32_t)(r * 64 + lane) + up[r]] = w[r];
     Wbuf[take ? mypos : LeanW<R>::kTrash] = nk;
     lds_order();                    // one wave owns Wbuf; the LDS serves it in issue order
+    if constexpr (TIES) {
+        if (all >= cap) {
+            // (i) W's new last key and the nearest key left outside: which of two equal ones stays is the heap's choice, and
+            // the one outside may still be a candidate (core.rs:635)
+            if (all > cap && (uint32_t)(Wbuf[cap - 1u] >> 32) == (uint32_t)(Wbuf[cap] >> 32)) *ties += 1u;
+            // (ii) an arriving key next to an equal one at or beyond W's last slot: the accept test it met (or set up for a
+            // later arrival of the row) compared equal distances
+            bool ev = false;
+            if (take) {
+                const uint32_t d = (uint32_t)(nk >> 32);
+                if (mypos + 1u < all && mypos + 2u >= cap) ev = (uint32_t)(Wbuf[mypos + 1u] >> 32) == d;
+                if (mypos >= cap) ev |= (uint32_t)(Wbuf[mypos - 1u] >> 32) == d;
+            }
+            *ties += (uint32_t)__popcll(__ballot(ev));
+        }
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint64_t v = Wbuf[r * 64 + lane];
@@ -247,15 +269,24 @@ __device__ __forceinline__ uint32_t merge_apply_lean(uint64_t (&w)[R], uint64_t 
     return total;
 }
 
-template <int R>
+template <int R, bool TIES = false>
 __device__ __forceinline__ uint32_t merge_regs_lean(uint64_t (&w)[R], uint64_t *Wbuf, uint32_t nW, uint32_t cap, uint64_t nk,
-                                                    bool take, int lane, uint64_t &worst)
+                                                    bool take, int lane, uint64_t &worst, uint32_t *ties = nullptr)
 {
     const uint64_t mm = __ballot(take);
     if (mm == 0) return nW;
     uint32_t up[R], mypos;
     merge_rank<R>(w, nk, take, up, mypos, lane);
-    return merge_apply_lean<R>(w, Wbuf, nW, cap, nk, take, up, mypos, (uint32_t)__popcll(mm), lane, worst);
+    return merge_apply_lean<R, TIES>(w, Wbuf, nW, cap, nk, take, up, mypos, (uint32_t)__popcll(mm), lane, worst, ties);
+}
+// tie census, stop test (core.rs:635, c.sim == f.sim): the candidate about to be expanded against W's last key as the
+// list stands (every key of the previous expansion merged); W need not be full
+template <int R>
+__device__ __forceinline__ void tie_stop_test(const uint64_t *Wbuf, uint32_t nW, uint64_t ckey, uint32_t *ties)
+{
+    if (nW < 2u) return;
+    const uint64_t f = Wbuf[nW - 1u];
+    if ((uint32_t)(f >> 32) == (uint32_t)(ckey >> 32) && (uint32_t)f >> 1 != (uint32_t)ckey >> 1) *ties += 1u;
 }
 
 // search_level (core.rs:607-675) with W in registers; leaves w[] sorted (also copied to Wbuf) and returns |W|.
@@ -265,7 +296,9 @@ __device__ __forceinline__ uint32_t merge_regs_lean(uint64_t (&w)[R], uint64_t *
 // widen an M = 16 index past 64: those stay on this kernel instead of falling back to the general one.
 // LOG: the caller is a plan of the exact-order parallel insert (hnsw_occ.hpp) -- every expanded row goes to its
 // read log with the popped candidate's distance, turned into the row's threshold by occ_finalize_search_log.
-template <class VEC, int R, int BB, int DB, bool WIDE, bool LOG = false>
+// TIES: the tie census (DevHeader::ctr_tie) -- ctr.n_tie += the decisions of this search that compared equal distances of
+// two different nodes; always on for the plans of an insert (LOG), on request for searches (tuning "tie_census")
+template <class VEC, int R, int BB, int DB, bool WIDE, bool LOG = false, bool TIES = LOG>
 __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64_t *Wbuf, TagSet<BB, DB> &vis,
                                                       const typename VEC::Q &qr, uint32_t ep, uint32_t ef, uint32_t lc,
                                                       WorkCtr &ctr, int lane, unsigned long long *lossy_ctr)
@@ -367,10 +400,11 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
                 ctr.n_dist += nf;                                 // the reference evaluates the fresh ones (core.rs:652)
                 PH_MARK(ctr, 2);  // visited filter
                 if (pn) {
-                    nW = merge_apply_lean<R>(w, Wbuf, nW, ef, pkey, ptake, pup, ppos, pn, lane, worst);
+                    nW = merge_apply_lean<R, TIES>(w, Wbuf, nW, ef, pkey, ptake, pup, ppos, pn, lane, worst, &ctr.n_tie);
                     ptake = false;
                     pn = 0;
                 }
+                if constexpr (TIES) { if (c0 == 0) tie_stop_test<R>(Wbuf, nW, ckey, &ctr.n_tie); }
                 if (last) {
                     // W is complete: its first unexpanded entry is the next candidate unless one of this chunk's
                     // keys beats it.  (Requesting that entry's row here, one round trip early, was measured:
@@ -393,19 +427,22 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
                 const bool mine = sub < NR && myslot < nch && ((fm >> ((base + myslot) & 63u)) & 1ull);
                 key = pack_key(dsel, idsel);
                 take = mine && key < worst;                       // core.rs:657
+                if constexpr (TIES)                               // an arrival rejected at W's own last distance
+                    ctr.n_tie += (uint32_t)__popcll(__ballot(mine && !take && (uint32_t)(key >> 32) == (uint32_t)(worst >> 32)));
                 if (vis.lossy) take = drop_members<R>(w, key, take, lane);
                 PH_MARK(ctr, 4);  // waiting for the vectors + distances + accept
             } else {
                 if (pn) {
-                    nW = merge_apply_lean<R>(w, Wbuf, nW, ef, pkey, ptake, pup, ppos, pn, lane, worst);
+                    nW = merge_apply_lean<R, TIES>(w, Wbuf, nW, ef, pkey, ptake, pup, ppos, pn, lane, worst, &ctr.n_tie);
                     ptake = false;
                     pn = 0;
                 }
+                if constexpr (TIES) { if (c0 == 0) tie_stop_test<R>(Wbuf, nW, ckey, &ctr.n_tie); }
                 int r2, l2;
                 if (!first_unexpanded<R>(w, rkey, r2, l2)) rkey = ~0ull;
             }
             if (!last) {
-                nW = merge_regs_lean<R>(w, Wbuf, nW, ef, key, take, lane, worst);   // core.rs:659-664
+                nW = merge_regs_lean<R, TIES>(w, Wbuf, nW, ef, key, take, lane, worst, &ctr.n_tie);   // core.rs:659-664
             } else {
                 // The next candidate is known before these keys are merged: the nearest accepted new key if
                 // it beats the first unexpanded entry of W, else that entry.  Its row is requested now; the
@@ -447,7 +484,7 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
         word = word_next;
         word2 = word2_next;
     }
-    nW = merge_regs_lean<R>(w, Wbuf, nW, ef, pkey, ptake, lane, worst);
+    nW = merge_regs_lean<R, TIES>(w, Wbuf, nW, ef, pkey, ptake, lane, worst, &ctr.n_tie);
 #pragma unroll
     for (int r = 0; r < R; ++r) Wbuf[r * 64 + lane] = w[r];
     lds_order();
@@ -458,7 +495,7 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
 }
 
 // HNSW.SEARCH (core.rs:477-486 -> :865-892): one wave per query, grid-stride over the batch.
-template <class VEC, int R, int BB, int DB, bool WIDE>
+template <class VEC, int R, int BB, int DB, bool WIDE, bool TIES = false>
 __global__ __launch_bounds__(64, VEC::MIN_WAVES) void k_search_lean(GraphView g, const float *__restrict__ Q, uint32_t B, uint32_t k,
                                                     uint32_t ef, uint32_t lcap, uint32_t idbits,
                                                     uint32_t *__restrict__ out_ids, float *__restrict__ out_sims,
@@ -480,14 +517,24 @@ __global__ __launch_bounds__(64, VEC::MIN_WAVES) void k_search_lean(GraphView g,
         typename VEC::Q qr;
         VEC::load_q(Q + (size_t)qi * g.dim, qr, lane);
         uint32_t ep = (uint32_t)ep0;
+        const uint32_t tie0 = ctr.n_tie;
         for (uint32_t lc = lmax; lc >= 1; --lc) {  // core.rs:870-874
-            search_level_lean<VEC, 1, BB, DB, WIDE>(g, Wbuf, vis, qr, ep, 1, lc, ctr, lane, &g.hdr->ctr_search[3]);
+            search_level_lean<VEC, 1, BB, DB, WIDE, false, TIES>(g, Wbuf, vis, qr, ep, 1, lc, ctr, lane, &g.hdr->ctr_search[3]);
             ep = key_id(Wbuf[0]);                  // core.rs:872
             lds_order();
         }
-        const uint32_t nW = search_level_lean<VEC, R, BB, DB, WIDE>(g, Wbuf, vis, qr, ep, ef, 0, ctr, lane, &g.hdr->ctr_search[3]); // core.rs:876
+        const uint32_t nW = search_level_lean<VEC, R, BB, DB, WIDE, false, TIES>(g, Wbuf, vis, qr, ep, ef, 0, ctr, lane, &g.hdr->ctr_search[3]); // core.rs:876
         // core.rs:878-890: nearest first, min(k, |W|) results; sim = -dist (metrics.rs:75)
         const uint32_t nres = nW < k ? nW : k;
+        if constexpr (TIES) {
+            // equal distances among the k + 1 nearest: which of them is returned, and in which order, is the heap's business
+            for (uint32_t i0 = 0; i0 < nres && i0 + 1u < nW; i0 += 64u) {
+                const uint32_t i = i0 + (uint32_t)lane;
+                const bool in = i < nres && i + 1u < nW;
+                ctr.n_tie += (uint32_t)__popcll(__ballot(in && (uint32_t)(Wbuf[in ? i : 0u] >> 32) == (uint32_t)(Wbuf[in ? i + 1u : 0u] >> 32)));
+            }
+            if (lane == 0 && ctr.n_tie != tie0) atomicAdd(&g.hdr->ctr_tie[1], 1ull);
+        }
         for (uint32_t i = lane; i < k; i += 64) {
             const uint64_t key = i < nres ? Wbuf[i] : 0;
             out_ids[(size_t)qi * k + i] = i < nres ? key_id(key) : kEmpty;
@@ -500,6 +547,7 @@ __global__ __launch_bounds__(64, VEC::MIN_WAVES) void k_search_lean(GraphView g,
         atomicAdd(&g.hdr->ctr_search[0], (unsigned long long)ctr.n_dist);
         atomicAdd(&g.hdr->ctr_search[1], (unsigned long long)ctr.n_ids);
         atomicAdd(&g.hdr->ctr_search[2], (unsigned long long)ctr.n_expand);
+        if constexpr (TIES) atomicAdd(&g.hdr->ctr_tie[0], (unsigned long long)ctr.n_tie);
 #ifdef HNSW_PHASE_TIMERS
         for (int i = 0; i < 7; ++i) atomicAdd(&g.hdr->prof[i], ctr.ph[i]);
 #endif

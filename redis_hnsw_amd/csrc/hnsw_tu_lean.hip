@@ -4,16 +4,17 @@
 #define HNSW_SYNC_BLOCK   // search / engine unit: 64-thread workgroups handing over through LDS only (hnsw_device.hpp)
 #include "hnsw_host.hpp"
 #include "hnsw_search_lean.hpp"
+#include <type_traits>
 
 namespace hnsw_host {
 
 // no HBM spill table involved, so no region bookkeeping either
-template <class VEC, int R, int BB, int DB, bool WIDE>
+template <class VEC, int R, int BB, int DB, bool WIDE, bool TIES = false>
 static hnsw_status launch_lean_t(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t idbits, uint32_t per_cu,
                                  uint32_t *d_ids, float *d_sims, uint32_t *d_nout, hipStream_t st)
 {
     const size_t lds = LeanW<R>::kBytes + ((size_t)16 << BB);
-    auto kern = k_search_lean<VEC, R, BB, DB, WIDE>;
+    auto kern = k_search_lean<VEC, R, BB, DB, WIDE, TIES>;
     static size_t lds_set[16] = {0};
     hnsw_status ss = raise_lds_attr(h, kern, lds, lds_set);
     if (ss != HNSW_OK) return ss;
@@ -38,6 +39,18 @@ hnsw_status launch_lean_v(hnsw_index *h, int R, uint32_t bb, uint32_t db, const 
                           hipStream_t st, bool *done)
 {
     *done = true;
+    // the tie census (tuning "tie_census", hnsw_get_tie_counters): f32 rows, the shapes the headline configurations use
+    if constexpr (std::is_same<VEC, VecF32<4>>::value) {
+        if (h->tie_census) {
+#define TIE_CASE(RR, BBB, DDB)                                                                                  \
+    if (R == RR && bb == BBB && db == DDB)                                                                      \
+        return launch_lean_t<VEC, RR, BBB, DDB, WIDE, true>(h, dQ, B, k, idbits, per_cu, d_ids, d_sims, d_nout, st);
+            TIE_CASE(1, 10, 3) TIE_CASE(1, 11, 3) TIE_CASE(4, 10, 3) TIE_CASE(4, 11, 3) TIE_CASE(1, 9, 3) TIE_CASE(4, 9, 3)
+#undef TIE_CASE
+            *done = false;                               // (another shape: the general kernel answers, nothing is counted)
+            return fail(h, HNSW_ERR_INVALID, "tie_census: this index shape has no census kernel (ef_construction <= 256, ids < 2^24)");
+        }
+    }
 #define LEAN_CASE(RR, BBB, DDB)                                                                                  \
     if (R == RR && bb == BBB && db == DDB)                                                                      \
         return launch_lean_t<VEC, RR, BBB, DDB, WIDE>(h, dQ, B, k, idbits, per_cu, d_ids, d_sims, d_nout, st);

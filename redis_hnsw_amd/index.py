@@ -371,6 +371,14 @@ class Index:
     def reset_counters(self):
         self._check(self._lib.hnsw_reset_counters(self._h))
 
+    def tie_counters(self):
+        """decisions that compared equal distances of two different nodes since the last reset_counters() -- where the
+        reference's heap order could have chosen differently (hnsw_get_tie_counters): dict(search_events, queries_with_tie,
+        insert_events, plans_with_tie); search counts need set_tuning("tie_census", 1)"""
+        out = (C.c_uint64 * 4)()
+        self._check(self._lib.hnsw_get_tie_counters(self._h, out))
+        return dict(search_events=int(out[0]), queries_with_tie=int(out[1]), insert_events=int(out[2]), plans_with_tie=int(out[3]))
+
     def set_tuning(self, key, value):
         self._check(self._lib.hnsw_set_tuning(self._h, key.encode(), int(value)))
 

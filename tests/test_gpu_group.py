@@ -43,7 +43,20 @@ def _members_equal_oracle(g, o):
         assert g.member_info(i).node_count == o.live_count
 
 
-def test_sharded_search_and_replayed_writes_match_the_oracle(eng, grp, oracle_mod):
+def _member_devices():
+    """[(devices of the members besides the primary on device 0, id)]: all on the one device (this tier's box), and --
+    the moment more than one GPU is visible -- one member per OTHER device: peer copies, per-device streams and
+    hipDeviceEnablePeerAccess then run for the first time"""
+    import torch
+    nd = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    cases = [pytest.param([0, 0], id="one-device")]
+    cases.append(pytest.param(list(range(1, nd)), id="one-member-per-gpu",
+                              marks=pytest.mark.skipif(nd < 2, reason="needs at least two visible GPUs")))
+    return cases
+
+
+@pytest.mark.parametrize("devices", _member_devices())
+def test_sharded_search_and_replayed_writes_match_the_oracle(eng, grp, oracle_mod, devices):
     n, dim, m, ef, k = 2500, 128, 16, 200, 10
     V = make_data(n + 400, dim, seed=31)
     o, lv = build_oracle(oracle_mod, V[:n], m, ef)
@@ -51,8 +64,8 @@ def test_sharded_search_and_replayed_writes_match_the_oracle(eng, grp, oracle_mo
     graph["vectors"] = V[:n]
     p = eng.Index("grp", dim, m, ef)
     p.import_graph(graph)
-    g = grp.Group(p, [0, 0])                                        # three members on the one device
-    assert len(g) == 3
+    g = grp.Group(p, devices)                                       # the primary + one member per listed device
+    assert len(g) == 1 + len(devices)
     _members_equal_oracle(g, o)
     Q = make_data(701, dim, seed=32)                                # 701 = 233 + 234 + 234: ragged shards
     want = o.search_batch(Q, k, threads=8)

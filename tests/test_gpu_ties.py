@@ -1,0 +1,129 @@
+"""The tie census (hnsw_get_tie_counters): the engine counts every decision that compared equal
+distances of two different nodes -- the only places where its (distance, id) order and the reference's sim-only order
+on std's BinaryHeap (core.rs:292-300, :635, :657, :733) can part.  The oracle counts the reference's own decisions one
+neighbour at a time (hnsw_oracle_tie_census, hnsw_oracle_last_add_ties); the engine merges a whole adjacency row at once
+and counts a SUPERSET: whenever the oracle sees a tie in a query / an insert, so must the engine, and on tie-free data
+both see none."""
+import numpy as np
+import pytest
+
+from tests.util import graphs_equal, make_data
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from redis_hnsw_amd import index as idxmod
+    return idxmod
+
+
+def _binary(n, dim, seed):
+    """vectors of {0, 1}^dim: squared distances are small integers, equal everywhere"""
+    return np.random.default_rng(seed).integers(0, 2, size=(n, dim)).astype(np.float32)
+
+
+@pytest.mark.parametrize("ef", [40, 200])
+def test_search_census_sees_every_tie_the_oracle_sees(eng, oracle_mod, ef):
+    n, dim, m, k = 3000, 128, 16, 10
+    V = np.unique(_binary(n, dim, 5), axis=0)
+    n = len(V)
+    lv = oracle_mod.draw_levels(n, m, 9)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch(V, lv)
+    g = o.export()
+    gi = eng.Index("ties", dim, m, ef)
+    gi.import_graph(g)
+    gi.set_tuning("tie_census", 1)
+    Q = _binary(96, dim, 6)
+    seen = extra_flagged = 0
+    for q in Q:
+        cen = o.tie_census(q[None, :], k)
+        gi.reset_counters()
+        ids, sims, n_out = gi.search_batch(q[None, :], k)
+        oids, osims = o.search(q, k)
+        assert np.array_equal(ids[0, :len(oids)], oids)                    # same answers as ever (the census kernel is the kernel)
+        t = gi.tie_counters()
+        want = cen["stop_test_ties"] + cen["accept_test_ties"] + cen["queries_with_answer_tie"]
+        if want:
+            seen += 1
+            assert t["search_events"] >= 1 and t["queries_with_tie"] == 1, (cen, t)
+        if not want and t["search_events"]:
+            extra_flagged += 1                                              # the superset's price: counted here, no decision there
+    assert seen >= 48                                                       # the data does tie
+    # a batch: the per-query flags add up
+    gi.reset_counters()
+    gi.search_batch(Q, k)
+    cen = o.tie_census(Q, k)
+    t = gi.tie_counters()
+    assert t["queries_with_tie"] >= cen["queries_with_any_tie"] and t["queries_with_tie"] == seen + extra_flagged
+    gi.close()
+    o.close()
+
+
+def test_no_ties_on_uniform_data_and_no_count_without_the_tuning(eng, oracle_mod):
+    n, dim, m, ef, k = 6000, 128, 16, 200, 10
+    V = make_data(n, dim, seed=51)
+    lv = oracle_mod.draw_levels(n, m, 3)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    cen_build = o.add_batch_census(V, lv)
+    gi = eng.Index("noties", dim, m, ef)
+    gi.add_batch(V, levels=lv, mode="exact")                               # the windowed reference-order build
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    t = gi.tie_counters()
+    if cen_build[0] == 0:                                                   # (f32 similarities of 6 k uniform vectors: no decision tie)
+        assert t["insert_events"] == 0 and t["plans_with_tie"] == 0, t
+    else:
+        assert t["insert_events"] >= 1
+    Q = make_data(512, dim, seed=52)
+    gi.reset_counters()
+    gi.search_batch(Q, k)
+    assert gi.tie_counters()["search_events"] == 0                          # not counted: the tuning is off
+    gi.set_tuning("tie_census", 1)
+    ids, sims, n_out = gi.search_batch(Q, k)
+    oids, osims, on, _ = o.search_batch(Q, k)
+    assert np.array_equal(ids, oids) and np.array_equal(sims.view(np.uint32), osims.view(np.uint32))
+    cen = o.tie_census(Q, k)
+    t = gi.tie_counters()
+    # a superset, but a tight one: a whole row is merged at once, so an arrival next to an equal key can be counted where
+    # the reference, walking the row id by id, never compared the two
+    # (e.g. an equal pair across W's end is counted when it forms; the reference compares the two only if the outer one
+    # is popped while the inner one is still W's last).  A few per cent of the queries at most on uniform data.
+    assert cen["queries_with_any_tie"] <= t["queries_with_tie"] <= cen["queries_with_any_tie"] + len(Q) // 32, (cen, t)
+    gi.close()
+    o.close()
+
+
+def test_insert_census_sees_every_tie_the_oracle_sees(eng, oracle_mod):
+    """single hnsw_add calls (the form the Redis command issues) on tie-heavy data: whenever the oracle's insert met a
+    decision tie -- stop test, accept test or a select_neighbors cut, in the plan or in the shrink loop -- the engine's
+    counters moved too; the graphs stay identical (both use the (distance, id) order)."""
+    n0, extra, dim, m, ef = 1200, 160, 128, 8, 48
+    V = np.unique(_binary(n0 + extra + 64, dim, 15), axis=0)[:n0 + extra]
+    lv = oracle_mod.draw_levels(len(V), m, 4)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch(V[:n0], lv[:n0])
+    gi = eng.Index("insties", dim, m, ef)
+    gi.add_batch(V[:n0], levels=lv[:n0], mode="exact")
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    assert gi.tie_counters()["insert_events"] > 0                           # the windowed build met ties as well
+    import ctypes as C
+    lib = oracle_mod.lib()
+    seen = 0
+    for i in range(n0, n0 + extra):
+        o.add(V[i], int(lv[i]))
+        one = np.zeros(3, dtype=np.uint64)
+        lib.hnsw_oracle_last_add_ties(o._h, one.ctypes.data_as(C.POINTER(C.c_uint64)))
+        gi.reset_counters()
+        gi.add_node("n%d" % i, V[i], level=int(lv[i]))
+        t = gi.tie_counters()
+        if int(one.sum()):
+            seen += 1
+            assert t["insert_events"] >= 1, (i, one, t)
+    assert seen >= extra // 4
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    gi.close()
+    o.close()
