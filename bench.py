@@ -41,7 +41,11 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec -- the roofline's denominator
 HBM_MEASURED_GBS = 6300.0  # same guide: what a streaming copy sustains from DRAM on this part
 GATHER_PROFILE = os.path.join(ROOT, "profiles", "r5_gather_bw.txt")   # scripts/microbench/gather_bw.hip on the GPU box
-FIXTURES = {(1_000_000, 128, 16, 200): os.path.join(ROOT, "data", "c2_ref_graph_1m.npz")}
+FIXTURES = {(1_000_000, 128, 16, 200): os.path.join(ROOT, "data", "c2_ref_graph_1m.npz"),
+            # BASELINE config 3's shape as reference-order graphs: 100 k built by the CPU oracle; 300 k built on the GPU by the windowed
+            # reference-order build (scripts/build_c3_ref_graph_gpu.py: 604 s), its 100 k prefix checked row for row against the former
+            (100_000, 768, 32, 400): os.path.join(ROOT, "data", "c3_ref_graph_100k.npz"),
+            (300_000, 768, 32, 400): os.path.join(ROOT, "data", "c3_ref_graph_300k.npz")}
 FIXTURE_50K = os.path.join(ROOT, "data", "c2_ref_graph_50k.npz")
 # the reference's own work counters of the C2 build at several prefix sizes (tests/fixtures/make_ref_counters.py)
 REF_INSERT_COUNTERS = os.path.join(ROOT, "data", "c2_ref_insert_counters.json")
@@ -50,6 +54,7 @@ WORKLOADS = {
     "c1": dict(nodes=10_000, dim=128, m=5, ef=200, k=10, batch=1),
     "c2": dict(nodes=1_000_000, dim=128, m=16, ef=200, k=10, batch=1024),
     "c3": dict(nodes=1_000_000, dim=768, m=32, ef=400, k=100, batch=4096),
+    "c3ref": dict(nodes=300_000, dim=768, m=32, ef=400, k=100, batch=4096),     # C3's launch shape on a REFERENCE-ORDER graph (fixture)
     "c4": dict(nodes=10_000_000, dim=128, m=16, ef=200, k=10, batch=1024),
     "c5": dict(nodes=1_000_000, dim=128, m=16, ef=200, k=10, batch=1024, graph="exact"),
 }
@@ -411,6 +416,9 @@ class Bench:
             # reads the fixture itself instead)
             if s.rank == 0 or not s.replicate:
                 s.graph, s.oracle_build_s = load_graph_fixture(s.fixture, s.V)
+                if "built_by" in np.load(s.fixture).files:
+                    s.graph_desc = ("reference-order (serial core.rs:489-599 order; fixture built on the GPU by hnsw_add_batch mode 0, its first "
+                                    "100 k nodes checked row for row against the CPU oracle's serial build; imported with hnsw_import)")
                 tb = time.time()
                 s.index.import_graph(s.graph)
                 s.torch.cuda.synchronize()
@@ -676,6 +684,26 @@ class Bench:
         s.index.set_tuning("launch_concurrency", s.args.launch_concurrency)
         s.n_dist_q, s.n_ids_q, s.n_exp_q = sx.n_dist / (nb_exact * s.B), sx.n_ids / (nb_exact * s.B), sx.n_expand / (nb_exact * s.B)
         s.redo = s.sc.n_dist / (s.args.steps * s.B) / s.n_dist_q - 1.0 if s.args.steps else 0.0
+        # ---- the ENGINE's own tie census of the same batches (hnsw_get_tie_counters): decisions that compared equal distances
+        # of two different nodes, counted by the census form of the search kernel -- a superset of the reference's own
+        # decisions (the oracle's census of the same queries is cpu_baseline.tie_census); untimed, separate pass
+        s.engine_ties = None
+        try:
+            s.index.set_tuning("tie_census", 1)
+            s.index.reset_counters()
+            for b in range(nb_exact):
+                s.search_now(s.myQ[b * s.B:(b + 1) * s.B], s.B)
+            tz = s.index.tie_counters()
+            s.engine_ties = dict(queries=nb_exact * s.B, queries_with_tie=tz["queries_with_tie"], events=tz["search_events"],
+                                 note="k of N queries met a decision that compared equal distances of two different nodes (stop test "
+                                      "core.rs:635, accept test :657, or equal distances among the k + 1 nearest): only those can be "
+                                      "answered differently by the reference's binary; counted by the kernel itself, a superset of the "
+                                      "oracle's per-decision census")
+        except Exception as e:                                            # a shape without a census kernel
+            s.engine_ties = dict(queries=0, note="not counted: %s" % e)
+        finally:
+            s.index.set_tuning("tie_census", 0)
+            s.index.reset_counters()
 
         # ---- recall@k against brute force (rank 0's batches) ------------------------------
         s.recall = None
@@ -837,7 +865,12 @@ class Bench:
                 if not identical:
                     raise SystemExit("gpu_exact_build: the GPU's reference-order graph differs from the oracle's fixture")
             rc = ref_insert_counters(NE)
+            tze = ie.tie_counters()
             s.exact_build = dict(nodes=NE, build_seconds=round(te, 2), inserts_per_s=round(NE / te, 1), identical=identical,
+                               ties=dict(plans_with_tie=tze["plans_with_tie"], events=tze["insert_events"], inserts=NE,
+                                         note="plans (of %d inserts; a re-planned node counts again) whose search or select_neighbors compared "
+                                              "equal distances of two different nodes, plus such cuts in the shrink loop: where the "
+                                              "reference's binary may link differently (hnsw_get_tie_counters)" % NE),
                                checked_against=why,
                                roofline=None if rc is None else insert_roofline(
                                    rc[0], rc[1], NE, te, s.dim, "the oracle's serial build of the same %d-node prefix (data/c2_ref_insert_counters.json)" % NE),
@@ -1201,10 +1234,12 @@ class Bench:
                 gb["vectors"] = s.V
                 ix.import_graph(gb)
                 s.torch.cuda.synchronize()
+                ix.reset_counters()
                 tg = time.time()
                 ix.add_batch(newV, levels=newL, mode="exact")
                 s.torch.cuda.synchronize()
                 tg = time.time() - tg
+                tzs = ix.tie_counters()
                 c0_ = o.insert_counters()
                 c0_ = (c0_.n_dist, c0_.n_ids)
                 tc_ = time.time()
@@ -1221,10 +1256,11 @@ class Bench:
                 s.exact_at_scale = dict(workload="HNSW.NODE.ADD x %d in the reference's order on the %d-node reference-order index (hnsw_add_batch mode 0)" % (NS, s.N),
                                         build_seconds=round(tg, 3), inserts_per_s=round(NS / tg, 1), cpu_oracle_inserts_per_s=round(NS / tc_, 1),
                                         identical=True, checked_against="every adjacency row of every layer == the oracle after the same inserts",
+                                        ties=dict(plans_with_tie=tzs["plans_with_tie"], events=tzs["insert_events"], inserts=NS),
                                         roofline=insert_roofline(c1_.n_dist - c0_[0], c1_.n_ids - c0_[1], NS, tg, s.dim,
                                                                  "the oracle making the same %d inserts on the same graph" % NS),
                                         note="the rate of the reference-order build where BASELINE config 5 ends; the whole build from an "
-                                             "empty index: profiles/r5_c5_exact_build_1m.json (123.6 s = 8 090 inserts/s, identical)")
+                                             "empty index: profiles/r5_c5_exact_build_1m.json (123.6 s = 8 090 inserts/s, identical); round 6: profiles/r6_c5_exact_build_1m.json")
                 ix.close()
                 s.log("reference-order inserts at 1 M nodes: %.0f inserts/s (CPU oracle %.0f), graphs identical" % (NS / tg, NS / tc_))
             o.close()
@@ -1261,7 +1297,8 @@ class Bench:
         """the one JSON line"""
         s = self
         known = {(1_000_000, 128, 16, 200, 10, 1024): "C2", (1_000_000, 768, 32, 400, 100, 4096): "C3",
-                 (10_000_000, 128, 16, 200, 10, 1024): "C4", (10_000, 128, 5, 200, 10, 1): "C1"}
+                 (10_000_000, 128, 16, 200, 10, 1024): "C4", (10_000, 128, 5, 200, 10, 1): "C1",
+                 (300_000, 768, 32, 400, 100, 4096): "C3's shape on a 300 k reference-order graph"}
         cfg_name = known.get((s.N, s.dim, s.M, s.ef, s.k, s.B), "custom")
         if cfg_name == "C2" and s.args.graph == "exact":
             cfg_name = "C5"                                  # the same index, BUILT on the GPU in the reference's order first
@@ -1283,6 +1320,7 @@ class Bench:
             "gather_verified": s.gather_ok,
             "rccl_world": s.world if (s.world > 1 and s.backend == "nccl") else None,
             "collective_backend": s.backend if s.world > 1 else None,
+            "tie_census_engine": getattr(s, "engine_ties", None),
             "per_rank": s.per_rank, "index_replication": s.replication, "topk_exchange": s.gather_cmp, "first_contact": s.first_contact_rows,
             "recall_at_%d" % s.k: None if s.recall is None else round(s.recall, 4),
             "build_seconds": None if s.t_build is None else round(s.t_build, 2),

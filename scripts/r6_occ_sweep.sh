@@ -1,2 +1,5 @@
+cd /tmp && export TMPDIR=/tmp
 cd /root/repo
-timeout 1200 python -m pytest tests/test_gpu_ties.py -x -q 2>&1 | tail -15
+rm -rf /tmp/prof_occ
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_occ -o p -- python scripts/occ_probe.py 12000 768 32 400 64 0 2>&1 | grep -v "amdgpu.ids\|simple_timer\|generateRocpd" | tail -6
+python scripts/summarize_rocprof.py stats /tmp/prof_occ/p_results.db | head -14
