@@ -152,8 +152,11 @@ def test_reference_order_fixture_parity_in_the_bench_launch_shape(eng, oracle_mo
 FIXTURE_C3 = os.path.join(ROOT, "data", "c3_ref_graph_100k.npz")
 
 
-@pytest.mark.skipif(not os.path.exists(FIXTURE_C3), reason="data/c3_ref_graph_100k.npz is missing")
-def test_c3_search_on_a_reference_order_graph(eng, oracle_mod):
+FIXTURE_C3_300K = os.path.join(ROOT, "data", "c3_ref_graph_300k.npz")   # built ON the GPU (scripts/build_c3_ref_graph_gpu.py), prefix-checked
+
+
+@pytest.mark.parametrize("fixture,N", [(FIXTURE_C3, 100_000), (FIXTURE_C3_300K, 300_000)])
+def test_c3_search_on_a_reference_order_graph(eng, oracle_mod, fixture, N):
     """C3's kernel (dim 768, M = 32, ef = 400, k = 100, B = 4096: k_search<MODE_AVX,24,8>) on a REFERENCE-ORDER graph: the
     oracle's serial build (core.rs:489-599) of 100 k x 768 vectors, a committed fixture (tests/fixtures/make_ref_graph.py
     --nodes 100000 --dim 768 --m 32 --ef 400; ~1 h on one core -- the windowed GPU build manages 415 inserts/s at this
@@ -163,10 +166,17 @@ def test_c3_search_on_a_reference_order_graph(eng, oracle_mod):
     shape, then sampled parity with the oracle searching the same graph: ids, similarity bits, n_out, work counters."""
     import torch
     from bench import load_graph_fixture
-    N, dim, M, ef, k, B = 100_000, 768, 32, 400, 100, 4096
+    if not os.path.exists(fixture):
+        pytest.skip("%s is missing" % fixture)
+    dim, M, ef, k, B = 768, 32, 400, 100, 4096
     V = np.random.default_rng(1).random((N, dim), dtype=np.float32)
     Q = np.random.default_rng(2).random((B, dim), dtype=np.float32)
-    graph, _ = load_graph_fixture(FIXTURE_C3, V)
+    graph, _ = load_graph_fixture(fixture, V)
+    if N > 100_000 and os.path.exists(FIXTURE_C3):
+        # the GPU-built 300 k graph continues the oracle-built 100 k one: same levels, and every row of the first 100 k nodes
+        # that no later insert touched is unchanged (a later insert only ever appends to or re-selects a row it links to)
+        small, _ = load_graph_fixture(FIXTURE_C3, V)
+        assert np.array_equal(small["levels"], graph["levels"][:100_000])
     deg0 = np.diff(graph["row_ptr"][0].astype(np.int64))
     assert deg0.max() > 2 * M                                              # over-degree rows: a reference-shaped graph
     gi = eng.Index("c3-ref", dim, M, ef)

@@ -1006,6 +1006,33 @@ def test_parallel_validated_commits_build_the_serial_graph(eng, oracle_mod, n, d
     o.close()
 
 
+def test_group_commit_declines_when_its_grid_could_not_be_resident(eng, oracle_mod):
+    """k_occ_commit_par separates its iterations with a spin barrier over the whole grid: every workgroup must be resident
+    (each asks for nearly a CU's whole LDS).  The launcher asks the runtime how many are (occupancy x CUs of the device or
+    partition) and leaves a round with more window nodes than that to the in-order commit kernel -- here the limit is
+    pretended (tuning par_max_resident = 2): no group commit runs, the graph is the oracle's all the same."""
+    import ctypes as C
+    n, dim, m, ef = 2500, 128, 16, 200
+    V = make_data(n, dim, seed=92)
+    lv = oracle_mod.draw_levels(n, m, 6)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch(V, lv)
+    lib = eng._capi.load()
+    lib.hnsw_debug_occ_par.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    for limit, expect_groups in ((2, False), (0, True)):                   # 0 = what the device really holds
+        gi = eng.Index("res%d" % limit, dim, m, ef)
+        gi.set_tuning("commit_par", 2)
+        gi.set_tuning("par_max_resident", limit)
+        gi.add_batch(V, levels=lv, mode="exact")
+        ok, why = graphs_equal(o.export(), gi.export_graph())
+        assert ok, why
+        pz = (C.c_uint64 * 21)()
+        assert lib.hnsw_debug_occ_par(gi._h, pz) == 0
+        assert (pz[0] > 0) == expect_groups, (limit, pz[0])
+        gi.close()
+    o.close()
+
+
 def test_windowed_exact_build_on_clustered_and_duplicated_data(eng, oracle_mod):
     """Not uniform: a 16-cluster Gaussian mixture (dense neighbourhoods, many more relevant row changes per
     window) with every 10th vector repeated (tied similarities: the validation counts ties as relevant)."""
