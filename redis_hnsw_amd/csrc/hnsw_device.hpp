@@ -574,10 +574,8 @@ template <int R>
 __device__ __forceinline__ uint32_t merge_sorted(uint64_t *W, uint32_t nW, uint32_t cap, uint64_t nk,
                                                  bool take, int lane, uint32_t *ties = nullptr)
 {
-    // ties: += 1 when, after this merge, the list's last key and the nearest key the merge pushed OUT of it have equal
-    // distances (a select_neighbors cut between equal similarities, core.rs:733 / :741-754: which of the two stays is the
-    // heap's choice in the reference).  Together with the callers' count of arrivals REJECTED at an equal distance this
-    // sees every tie across the final cut (the pair (cap-1, cap) of the union is checked at every eviction).
+    // ties (tie census of a select_neighbors cut, core.rs:733 / :741-754): ties[1] keeps the nearest distance among the keys
+    // pushed out of the list; the callers add the arrivals they reject and compare with the final last key (merge_S)
     const uint64_t tmask = __ballot(take);
     if (tmask == 0) return nW;
     uint64_t w[R];
@@ -617,14 +615,17 @@ __device__ __forceinline__ uint32_t merge_sorted(uint64_t *W, uint32_t nW, uint3
     const uint32_t total = nW + (uint32_t)__popcll(tmask);
     dev_sync();
     if (ties && total > cap) {
-        const uint32_t bd = (uint32_t)(W[cap - 1] >> 32);                 // the list's last distance now
-        bool eq = take && mypos == cap && (uint32_t)(nk >> 32) == bd;     // the key that landed right behind it
+        // ties[1] = min(ties[1], distances of the keys this merge pushed out): the caller compares it with the list's last
+        // distance when the selection is complete (a cut between equal distances)
+        uint32_t dmin = take && mypos >= cap ? (uint32_t)(nk >> 32) : 0xFFFFFFFFu;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint32_t i = r * 64 + lane;
-            eq |= i < nW && i + up[r] == cap && (uint32_t)(w[r] >> 32) == bd;
+            if (i < nW && i + up[r] >= cap) dmin = min(dmin, (uint32_t)(w[r] >> 32));
         }
-        *ties += __ballot(eq) ? 1u : 0u;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, o, 64));
+        ties[1] = min(ties[1], dmin);
     }
     return total < cap ? total : cap;
 }
@@ -706,6 +707,9 @@ __host__ __device__ inline uint32_t occ_meta(uint32_t lc, uint32_t kind, uint32_
 struct WorkCtr {
     uint32_t n_dist, n_ids, n_expand;
     uint32_t n_tie;          // tie census (DevHeader::ctr_tie): counted by the routines instantiated with TIES
+    uint32_t tie_emin;       // ... its running minimum (&n_tie + 1: the routines take one pointer): the nearest distance among the keys that
+                             // fell out of the list being kept but are still candidates (search_level), or among everything outside the
+                             // selection (select_neighbors); all ones = none
     OccRead *log;            // nullptr: no read log
     uint32_t log_n, log_cap; // entries written / capacity (log_n keeps counting past the capacity)
 #ifdef HNSW_PHASE_TIMERS

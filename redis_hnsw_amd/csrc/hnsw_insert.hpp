@@ -31,13 +31,19 @@ constexpr uint32_t kMaxLayers = 32;       // levels 0..31
 // untouched.  Result in m.S[0..n), sorted; returns n.
 // ---------------------------------------------------------------------------
 // S holds up to kSelMax keys (m_max0 = 2M): one register slice per 64; the four-slice form serves M > 64 only
-// ties (tie census, DevHeader::ctr_tie): += the select_neighbors cuts that fell between equal distances (core.rs:733,
-// :741-754) -- an arrival rejected at the list's own last distance, or (merge_sorted) pushed out next to an equal one
+// ties (tie census, DevHeader::ctr_tie): ties[1] = the nearest distance outside the selection so far (rejected arrivals
+// here, evicted keys in merge_sorted); select_topm compares it with the last selected key at the end: equal = the cut of
+// core.rs:733 / :741-754 fell between equal similarities, which of the two is selected is the heap's choice there
 __device__ __forceinline__ uint32_t merge_S(uint64_t *S, uint32_t nS, uint32_t mcap, uint64_t key, bool have, uint64_t worst, int lane,
                                             uint32_t *ties)
 {
     const bool take = have && key < worst;
-    if (ties) *ties += __ballot(have && !take && (uint32_t)(key >> 32) == (uint32_t)(worst >> 32)) ? 1u : 0u;
+    if (ties && __ballot(have && !take)) {                  // the nearest rejected arrival joins "everything outside the selection"
+        uint32_t dmin = have && !take ? (uint32_t)(key >> 32) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, o, 64));
+        ties[1] = min(ties[1], dmin);
+    }
     if (mcap > 128) return merge_sorted<4>(S, nS, mcap, key, take, lane, ties);
     return mcap > 64 ? merge_sorted<2>(S, nS, mcap, key, take, lane, ties) : merge_sorted<1>(S, nS, mcap, key, take, lane, ties);
 }
@@ -51,8 +57,11 @@ __device__ __forceinline__ uint32_t merge_S(uint64_t *S, uint32_t nS, uint32_t m
 template <int MODE, int T, class GV>
 __device__ __forceinline__ uint32_t select_topm(const GV &g, const WaveMem &m, Visited &vis, const QReg<T> &qr,
                                 const uint64_t *cand, uint32_t ncand, uint32_t qid, uint32_t mcap,
-                                uint32_t lc, WorkCtr &ctr, int lane, bool &fail, uint32_t ignored = kEmpty)
+                                uint32_t lc, WorkCtr &ctr, int lane, bool &fail, uint32_t ignored = kEmpty, bool final_cut = true)
 {
+    // final_cut (tie census): this call selects from the WHOLE pool, so its last key against the nearest key outside is the
+    // reference's cut; a team's share (team_select) leaves ctr.tie_emin to the wave that merges the shares
+    ctr.tie_emin = 0xFFFFFFFFu;                             // tie census: nothing outside the selection yet
     visited_clear(vis, lane);                               // core.rs:692
     for (uint32_t base = 0; base < ncand; base += 64) {     // core.rs:693-696
         if (!visited_reserve(vis, lane, nullptr)) { fail = true; return 0; }
@@ -78,9 +87,11 @@ __device__ __forceinline__ uint32_t select_topm(const GV &g, const WaveMem &m, V
         if (nS > mcap) nS = mcap;
     }
     wave_sync();
-    // tie census: the candidate list itself is cut between equal distances (cand is sorted; `ignored` aside)
-    if (ncand > mcap && nS == mcap && (uint32_t)(cand[mcap] >> 32) == (uint32_t)(m.S[mcap - 1] >> 32) && key_id(cand[mcap]) != ignored)
-        ctr.n_tie += 1u;
+    // tie census: the candidates beyond the first mcap are outside the selection (cand is sorted: the nearest of them)
+    if (ncand > mcap && nS == mcap) {
+        const uint32_t first_out = key_id(cand[mcap]) != ignored ? mcap : mcap + 1u;
+        if (first_out < ncand) ctr.tie_emin = (uint32_t)(cand[first_out] >> 32);
+    }
 
     const uint32_t stride = lc ? g.strideU : g.stride0;
     if constexpr (MODE == MODE_AVX) {
@@ -192,6 +203,7 @@ __device__ __forceinline__ uint32_t select_topm(const GV &g, const WaveMem &m, V
         }
         drain(1);
         wave_sync();
+        if (final_cut && nS == mcap && nS && ctr.tie_emin == (uint32_t)(m.S[mcap - 1] >> 32)) ctr.n_tie += 1u;   // tie census
         return nS;
     }
     // software prefetch: the next candidate's row is requested before the
@@ -234,6 +246,7 @@ __device__ __forceinline__ uint32_t select_topm(const GV &g, const WaveMem &m, V
         }
     }
     wave_sync();
+    if (final_cut && nS == mcap && nS && ctr.tie_emin == (uint32_t)(m.S[mcap - 1] >> 32)) ctr.n_tie += 1u;       // tie census
     return nS;
 }
 

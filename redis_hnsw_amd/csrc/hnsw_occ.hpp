@@ -625,14 +625,14 @@ __device__ __forceinline__ void team_helper(const GV &g, volatile TeamTask *task
         if (n) {
             QReg<T> qe;
             load_query<MODE, T>(g.vec + (size_t)e * g.dim, g.dim, qe, m.qlds, lane);
-            nS = select_topm<MODE, T>(g, m, vis, qe, m.W, n, e, mmax, lc, c, lane, fail, ignored);
-        }
+            nS = select_topm<MODE, T>(g, m, vis, qe, m.W, n, e, mmax, lc, c, lane, fail, ignored, false);
+        } else c.tie_emin = 0xFFFFFFFFu;
         if (lane == 0) {
             task->nS[wave] = nS;
             task->fail[wave] = fail ? 1u : 0u;
             task->n_dist[wave] = c.n_dist;
             task->n_ids[wave] = c.n_ids;
-            task->n_tie[wave] = c.n_tie;
+            task->n_tie[wave] = c.tie_emin;                  // tie census: the nearest distance outside this share's selection
         }
         team_bar();                                         // the results are there
     }
@@ -652,14 +652,15 @@ __device__ __forceinline__ uint32_t team_select(const GV &g, const WaveMem &m, V
     fence_own_writes();                                     // the rows this wave has rewritten, before the helpers read them
     team_bar();
     const uint32_t n0 = team_share(W0sub, m.W, nE, 0u, nw, lane);
-    uint32_t nS = n0 ? select_topm<MODE, T>(g, m, vis, qe, W0sub, n0, e, mmax, lc, ctr, lane, fail, ignored) : 0u;
+    if (!n0) ctr.tie_emin = 0xFFFFFFFFu;
+    uint32_t nS = n0 ? select_topm<MODE, T>(g, m, vis, qe, W0sub, n0, e, mmax, lc, ctr, lane, fail, ignored, false) : 0u;
     team_bar();
     for (uint32_t w = 1; w < nw; ++w) {
         const uint32_t nSw = __builtin_amdgcn_readfirstlane(task->nS[w]);
         fail |= __builtin_amdgcn_readfirstlane(task->fail[w]) != 0u;
         ctr.n_dist += __builtin_amdgcn_readfirstlane(task->n_dist[w]);
         ctr.n_ids += __builtin_amdgcn_readfirstlane(task->n_ids[w]);
-        ctr.n_tie += __builtin_amdgcn_readfirstlane(task->n_tie[w]);
+        ctr.tie_emin = min(ctr.tie_emin, (uint32_t)__builtin_amdgcn_readfirstlane(task->n_tie[w]));
         const uint64_t *Sw = reinterpret_cast<const uint64_t *>(hmem0 + (size_t)(w - 1) * tc.hbytes + (size_t)kTeamCand * 8 + 64 * 4 + 64 * 4);
         for (uint32_t base = 0; base < nSw; base += 64) {
             const bool have = base + (uint32_t)lane < nSw;
@@ -677,6 +678,8 @@ __device__ __forceinline__ uint32_t team_select(const GV &g, const WaveMem &m, V
             nS = merge_S(m.S, nS, mmax, key, have && !dup, worst, lane, &ctr.n_tie);
         }
     }
+    // tie census: the cut of the whole pool (core.rs:733 / :741-754) against the nearest key left outside by any share
+    if (nS == mmax && nS && ctr.tie_emin == (uint32_t)(m.S[mmax - 1] >> 32)) ctr.n_tie += 1u;
     return nS;
 }
 

@@ -159,7 +159,7 @@ template <int R, bool WIDE, bool TIES = false>
 __device__ __forceinline__ bool duo_keep(const GraphView &g, uint64_t *Wbuf, DuoBox *box, uint32_t ef, DuoSeq &seq, int lane,
                                          WorkCtr &ctr)
 {
-    uint32_t ties = 0;                                 // tie census of this search (merge_apply_lean, tie_stop_test)
+    uint32_t ties[2] = {0u, 0xFFFFFFFFu};              // tie census of this search (merge_apply_lean, tie_stop_test): count, nearest evicted candidate
     PH_T0();
     DuoBoxLds vb = duo_lds(box);
     uint32_t lc = 0, stride = g.stride0;
@@ -195,16 +195,17 @@ __device__ __forceinline__ bool duo_keep(const GraphView &g, uint64_t *Wbuf, Duo
                 for (int r = 0; r < R; ++r) w[r] += ((uint32_t)w[r] == nlo) ? 1ull : 0ull;
                 kk += (take && (uint32_t)kk == nlo) ? 1ull : 0ull;
             }
-            nW = merge_regs_lean<R, TIES>(w, Wbuf, nW, ef, kk, take, lane, worst, &ties);      // core.rs:659-664
+            nW = merge_regs_lean<R, TIES>(w, Wbuf, nW, ef, kk, take, lane, worst, ties);      // core.rs:659-664
             // the candidate the walker expands next, against W's last key with everything merged (core.rs:635)
-            if constexpr (TIES) { if (nk != ~0ull && !(fl & DUO_INIT)) tie_stop_test<R>(Wbuf, nW, nk, &ties); }
+            if constexpr (TIES) { if (nk != ~0ull && !(fl & DUO_INIT)) tie_stop_test<R>(Wbuf, nW, nk, ties); }
         }
         if (fl & DUO_FIN) {
 #pragma unroll
             for (int r = 0; r < R; ++r) Wbuf[r * 64 + lane] = w[r];
             lds_order();
             if (lane == 0) vb->nW = nW + (warm == 0x9E3779B9u && lane == 64 ? 1u : 0u);   // (keeps the prefetches alive)
-            if (lane == 0) vb->ties = ties;
+            if constexpr (TIES) { if (nW == ef && ties[1] == (uint32_t)(worst >> 32)) ties[0] += 1u; }   // the last pop (core.rs:635)
+            if (lane == 0) vb->ties = ties[0];
             PH_MARK(ctr, 6);
             duo_reply(box, seq, lane);
             return true;

@@ -230,7 +230,8 @@ struct LeanW {
 // at a time (core.rs:657, e.sim == f.sim with W full) compares an ARRIVING key with the key that is W's last at that
 // moment; that key can only have moved outwards by the end of the row, so after the merge the two are neighbours in the
 // stretch from W's last slot outwards (or the arrival was rejected against the row's first threshold: counted by the
-// caller).  Counted: arrivals with an equal neighbour there, and an equal pair across W's end.
+// caller).  Counted here: arrivals with an equal neighbour there; tracked (ties[1]): the nearest key pushed out of W that
+// is still a candidate, for the stop test of the search's last pop (core.rs:635).
 template <int R, bool TIES = false>
 __device__ __forceinline__ uint32_t merge_apply_lean(uint64_t (&w)[R], uint64_t *Wbuf, uint32_t nW, uint32_t cap, uint64_t nk,
                                                      bool take, const uint32_t (&up)[R], uint32_t mypos, uint32_t n_new,
@@ -245,9 +246,18 @@ __device__ __forceinline__ uint32_t merge_apply_lean(uint64_t (&w)[R], uint64_t 
     lds_order();                    // one wave owns Wbuf; the LDS serves it in issue order
     if constexpr (TIES) {
         if (all >= cap) {
-            // (i) W's new last key and the nearest key left outside: which of two equal ones stays is the heap's choice, and
-            // the one outside may still be a candidate (core.rs:635)
-            if (all > cap && (uint32_t)(Wbuf[cap - 1u] >> 32) == (uint32_t)(Wbuf[cap] >> 32)) *ties += 1u;
+            // (i) keys pushed out of W that are still candidates (unexpanded): the reference pops the nearest of them when
+            // every member of W has been expanded and stops there -- unless its similarity EQUALS W's last (core.rs:635),
+            // which the caller checks at the end against ties[1], the nearest such distance
+            if (all > cap) {
+                const bool in = (uint32_t)lane < all - cap;
+                const uint64_t ek = Wbuf[in ? cap + (uint32_t)lane : cap];
+                const uint64_t um = __ballot(in && !(ek & 1ull));
+                if (um) {
+                    const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ek >> 32), __ffsll((unsigned long long)um) - 1);
+                    ties[1] = min(ties[1], d);                          // (the stretch is sorted: the first unexpanded one is the nearest)
+                }
+            }
             // (ii) an arriving key next to an equal one at or beyond W's last slot: the accept test it met (or set up for a
             // later arrival of the row) compared equal distances
             bool ev = false;
@@ -307,6 +317,7 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
     const int grp = lane / LPV, sub = lane % LPV;
     const uint32_t stride = lc ? g.strideU : g.stride0;          // <= 64 (WIDE: <= 128): a row is one (two) wave load(s)
 
+    if constexpr (TIES) ctr.tie_emin = 0xFFFFFFFFu;
     tagset_clear<BB, DB>(vis, lane);                                  // core.rs:614
     (void)tagset_visit<BB, DB>(vis, lane == 0, ep);                   // core.rs:617
     vis.count = 1;
@@ -485,6 +496,8 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
         word2 = word2_next;
     }
     nW = merge_regs_lean<R, TIES>(w, Wbuf, nW, ef, pkey, ptake, lane, worst, &ctr.n_tie);
+    // tie census, the last pop (core.rs:631-635): the nearest candidate left is one that fell out of W; equal to W's last = a tie
+    if constexpr (TIES) { if (nW == ef && ctr.tie_emin == (uint32_t)(worst >> 32)) ctr.n_tie += 1u; }
 #pragma unroll
     for (int r = 0; r < R; ++r) Wbuf[r * 64 + lane] = w[r];
     lds_order();
