@@ -13,10 +13,10 @@ import numpy as np  # noqa: E402
 from bench import FIXTURES, draw_levels, load_graph_fixture  # noqa: E402
 from redis_hnsw_amd import Index, _capi  # noqa: E402
 
-N, dim, M, ef = 1_000_000, 128, 16, 200
+N, dim, M, ef = int(os.environ.get("BASE_N", "1000000")), 128, 16, 200
 NS = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-V = np.random.default_rng(1).random((N, dim), dtype=np.float32)
-g, _ = load_graph_fixture(FIXTURES[(N, dim, M, ef)], V)
+V = np.random.default_rng(1).random((1_000_000, dim), dtype=np.float32)[:N]
+g, _ = load_graph_fixture(FIXTURES[(N, dim, M, ef)] if N == 1_000_000 else os.path.join(ROOT, "data", "c2_ref_graph_%dk.npz" % (N // 1000)), V)
 newV = np.random.default_rng(21).random((NS, dim), dtype=np.float32)
 newL = draw_levels(NS, M, 23)
 lib = _capi.load()
@@ -36,7 +36,7 @@ for tun in os.environ.get("TUNINGS", os.environ.get("TUNING", "")).split(";"):
     lib.hnsw_debug_occ(ix._h, out)
     lib.hnsw_debug_occ_par(ix._h, pz)
     n = NS - 256
-    print("[%s] %d inserts at 1 M: %.3f s = %.0f inserts/s; rounds %d (%.2f commits/round, %.1f us/round), stale plans %d, recomputed shrinks %.1f%%" % (
+    print(("[%s] %d inserts at " + str(N) + " nodes: %.3f s = %.0f inserts/s; rounds %d (%.2f commits/round, %.1f us/round), stale plans %d, recomputed shrinks %.1f%%") % (
         tun, n, dt, n / dt, out[5], out[0] / max(out[5], 1), 1e6 * dt / max(out[5], 1), out[3], 100.0 * out[2] / max(out[1] + out[2], 1)))
     if pz[0]:
         it = max(pz[5 + 6], 1)
