@@ -875,7 +875,7 @@ class Bench:
                                roofline=None if rc is None else insert_roofline(
                                    rc[0], rc[1], NE, te, s.dim, "the oracle's serial build of the same %d-node prefix (data/c2_ref_insert_counters.json)" % NE),
                                note="hnsw_add_batch mode 0 on the first 50 k nodes (the rate grows with the index; the whole 1 M "
-                                    "build: profiles/r3_c5_exact_build_1m.json)")
+                                    "build: profiles/r6_c5_exact_build_1m.json)")
             # HNSW.NODE.ADD as the Redis command issues it (src/lib.rs:356: one add_node per call): single hnsw_add
             # calls on that index, timed, then CHECKED against the oracle making the same inserts on the same graph
             if identical:
@@ -1260,7 +1260,7 @@ class Bench:
                                         roofline=insert_roofline(c1_.n_dist - c0_[0], c1_.n_ids - c0_[1], NS, tg, s.dim,
                                                                  "the oracle making the same %d inserts on the same graph" % NS),
                                         note="the rate of the reference-order build where BASELINE config 5 ends; the whole build from an "
-                                             "empty index: profiles/r5_c5_exact_build_1m.json (123.6 s = 8 090 inserts/s, identical); round 6: profiles/r6_c5_exact_build_1m.json")
+                                             "empty index: profiles/r6_c5_exact_build_1m.json (113.7 s = 8 796 inserts/s, identical)")
                 ix.close()
                 s.log("reference-order inserts at 1 M nodes: %.0f inserts/s (CPU oracle %.0f), graphs identical" % (NS / tg, NS / tc_))
             o.close()
