@@ -73,6 +73,12 @@ extern "C" {
     pub fn hnsw_serialize_size(h: *mut hnsw_index, bytes: *mut u64) -> c_int;
     pub fn hnsw_serialize(h: *mut hnsw_index, buf: *mut c_void, cap: u64, written: *mut u64) -> c_int;
     pub fn hnsw_deserialize(buf: *const c_void, bytes: u64, seed: u64, device: c_int, out: *mut *mut hnsw_index) -> c_int;
+    // the tie census: decisions that compared equal similarities of two different nodes (core.rs:292-300 orders SimPair by
+    // sim alone and leaves ties to BinaryHeap; the engine breaks them by id).  out4[2] / [3] after an add_node: zero = the
+    // links are what this crate's own insert() would have made
+    pub fn hnsw_get_tie_counters(h: *mut hnsw_index, out4: *mut u64) -> c_int;
+    pub fn hnsw_reset_counters(h: *mut hnsw_index) -> c_int;
+    pub fn hnsw_set_tuning(h: *mut hnsw_index, key: *const c_char, value: i64) -> c_int;
     // more than one GPU behind one Redis process: searches shard over the members, writes are replayed on each
     pub fn hnsw_group_create(primary: *mut hnsw_index, devices: *const c_int, n_devices: u32, seed: u64,
                              out: *mut *mut hnsw_group) -> c_int;
