@@ -278,7 +278,9 @@ hnsw_status hnsw_reset_counters(hnsw_index *h);
  * test (core.rs:635), the accept test with W full (:657), a select_neighbors cut (:733, :741-754), or equal distances
  * among the k + 1 nearest of an answer.  The kernels count every such comparison they make -- a superset of the
  * reference's own (a whole adjacency row is merged at once where the reference walks it id by id), never fewer:
- *   out[0] events in searches      (only while tuning "tie_census" = 1: the census form of the dim-128 search kernel)
+ *   out[0] events in searches      (only while tuning "tie_census" = 1: the census form of the dim-128 search kernel,
+ *          f32 rows, ef_construction <= 256; if a search of the period ran on another kernel while the tuning was on,
+ *          out[0] = out[1] = UINT64_MAX: unknown)
  *   out[1] queries with at least one
  *   out[2] events in inserts / deletes: the plans' search_level + select_neighbors, the speculative and the recomputed
  *          select_neighbors of the shrink loop (always counted by the dim-128 plan kernels and by every select)

@@ -504,6 +504,7 @@ hnsw_status launch_search(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k
     h->last_search_lean = false;
     if ((s = try_launch_lean(h, dQ, B, k, d_ids, d_sims, d_nout, st, &done)) != HNSW_OK) return s;
     if (done) { h->last_search_lean = true; return HNSW_OK; }
+    if (h->tie_census) h->tie_uncounted = true;           // the general kernel has no census form
     const int R = pick_R(h->efc);
     if (h->fmt == FMT_BF16) s = launch_search_fmt<FMT_BF16>(h, R, dQ, B, k, d_ids, d_sims, d_nout, st);   // any dim % 32 == 0, any M / ef
     else if (h->fmt == FMT_FP8) s = launch_search_fmt<FMT_FP8>(h, R, dQ, B, k, d_ids, d_sims, d_nout, st);
@@ -723,6 +724,7 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
     if (!std::strcmp(key, "occ_stage_ahead")) { h->occ_stage_ahead = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), kOccMaxW); return HNSW_OK; }
     if (!std::strcmp(key, "occ_depth_x10")) { h->occ_depth_x10 = (uint32_t)std::max<int64_t>(value, 0); return HNSW_OK; }
     if (!std::strcmp(key, "occ_front_max")) { h->occ_front_max = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 2), kOccMaxW); return HNSW_OK; }
+    if (!std::strcmp(key, "occ_slack_base")) { h->occ_slack_base = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 64); return HNSW_OK; }
     if (!std::strcmp(key, "occ_slack_extra")) { h->occ_slack_extra = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 64); return HNSW_OK; }
     if (!std::strcmp(key, "occ_log_cap")) { h->occ_log_cap = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), kOccMaxReads); return HNSW_OK; }
     if (!std::strcmp(key, "occ_min_batch")) { h->occ_min_batch = (uint32_t)std::max<int64_t>(value, 1); return HNSW_OK; }
@@ -1023,6 +1025,7 @@ hnsw_status hnsw_reset_counters(hnsw_index *h)
     HIP_TRY(h, hipDeviceSynchronize());
     static_assert(offsetof(DevHeader, ctr_tie) == offsetof(DevHeader, ctr_search) + sizeof(unsigned long long) * 16, "counters are contiguous");
     HIP_TRY(h, hipMemset((char *)h->d_hdr + offsetof(DevHeader, ctr_search), 0, sizeof(unsigned long long) * 20));
+    h->tie_uncounted = false;
     return HNSW_OK;
 }
 
@@ -1033,6 +1036,7 @@ hnsw_status hnsw_get_tie_counters(hnsw_index *h, uint64_t *out)
     DevHeader hd;
     HIP_TRY(h, hipMemcpy(&hd, h->d_hdr, sizeof hd, hipMemcpyDeviceToHost));
     for (int i = 0; i < 4; ++i) out[i] = hd.ctr_tie[i];
+    if (h->tie_uncounted) out[0] = out[1] = ~0ull;        // a search of this period ran on a kernel without a census form: unknown
     return HNSW_OK;
 }
 

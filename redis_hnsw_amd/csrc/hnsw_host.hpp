@@ -120,6 +120,8 @@ struct hnsw_index {
     uint32_t occ_min_batch = 64;    // batches smaller than this take the serial path
     uint32_t occ_log_cap = hnsw::kOccMaxReads;   // tests: a tiny read log sends every node of the window to the serial kernels
     uint32_t occ_slack_extra = 0;   // tests: demand this much more free room per row (exercises the restride stop)
+    uint32_t occ_slack_base = 0;    // measurements only: free room per row an insert is assumed to need instead of m + 2 (its worst case); a
+                                    // row that does overflow is reported (ST_ROW_OVERFLOW), never silent
     uint32_t occ_ahead_x10 = 15;    // tuning: FRONT of the group commit (nodes dry-run side by side) = this/10 x running yield + 3, at most occ_front_max
     uint32_t occ_front_max = 64;
     uint32_t occ_depth_x10 = 0;     // tuning: DEPTH of the planned window = this/10 x running yield + 6 (>= the front, <= occ_window); 0 = the front
@@ -145,6 +147,7 @@ struct hnsw_index {
     bool bf16 = false;               // fmt == FMT_BF16 (the specialised dim-128 kernel has a bf16 form)
     bool select_shortcut = true;     // select_neighbors after search_level = the head of W (hnsw_insert.hpp); 0 = the full extension
     bool plan_lean = true;           // dim-128 insert plans (single adds, the windowed exact build) search with the specialised routine (hnsw_plan_lean.hpp)
+    bool tie_uncounted = false;      // a search ran without a census kernel while tie_census was on (since the last hnsw_reset_counters)
     bool tie_census = false;         // tuning: searches run the census form of the specialised kernel (hnsw_get_tie_counters; f32 rows, one wave per query)
     bool lean = true;                // dim-128 searches use the specialised kernel (hnsw_search_lean.hpp) when its preconditions hold
     bool duo = true;                 // ... in its two-wave form (hnsw_search_duo.hpp) when at most duo_max queries are in flight
@@ -173,6 +176,10 @@ struct hnsw_index {
 namespace hnsw_host {
 
 using namespace hnsw;
+
+// free words per row a commit demands before it starts: one insert raises any row by at most m + 1 per layer (connect: +1;
+// each of its m shrinks may append itself to the same third party, core.rs:794)
+inline uint32_t occ_slack(const hnsw_index *h) { return (h->occ_slack_base ? h->occ_slack_base : h->m + 2) + h->occ_slack_extra; }
 
 // Every C-ABI entry runs on its index's device and leaves the calling thread's current HIP device as it found it
 // (a Redis module shares its threads with whatever else the process does with HIP).

@@ -164,8 +164,10 @@ template <int MODE, int T>
 __device__ __forceinline__ void occ_check_range(const GraphView &g, const WaveMem &m, const OccScratch &sc, const OccBufs &ob,
                                                 const OccRead *reads, const OccShr *shr, uint32_t q, uint32_t from,
                                                 uint32_t to, int lane, bool shrinks_only = false, uint32_t own_base = kEmpty,
-                                                const OccDelta *src = nullptr, uint32_t from0 = kEmpty)
+                                                const OccDelta *src = nullptr, uint32_t from0 = kEmpty, uint64_t skip = 0)
 {
+    // skip: speculative records (bit = sub-operation) whose verdict nobody will ask for any more -- the commit has passed
+    // their neighbour: their hits are not collected, their distances not evaluated
     // from0 != kEmpty: the plan read layer 0 later than the upper layers (OccSlot): layer-0 deltas before journal index
     // from0 were already in the graph when it did
     // src: the deltas come from this linear buffer (another node's dry run, hnsw_occ_par.hpp) instead of the journal ring
@@ -193,6 +195,7 @@ __device__ __forceinline__ void occ_check_range(const GraphView &g, const WaveMe
                     const uint32_t rm = sc.rmeta[i];
                     const uint32_t kind = (rm >> 5) & 3u, sub = (rm >> 7) & 63u;
                     const bool full = (rm >> 13) & 1u;
+                    if (kind != OCC_SEARCH && kind != OCC_SELECT && ((skip >> sub) & 1ull)) continue;
                     if (kind == OCC_SHRINK_ROW) {
                         if (d.z == q && add) continue;                   // this node's own connect
                         if (!sc.flags[2 + sub]) atomicAdd(&ob.ctl->n_rowstale, 1ull);
@@ -768,6 +771,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit(GraphView g, Oc
         }
         jr.own = sc.own;                                     // this node's deltas are mirrored in LDS from here on
         jr.own_base = jr.n;
+        uint64_t done_rec = 0;                               // speculative records already consumed by this commit
         const uint32_t lmax = g.hdr->max_layer;
         const uint32_t l = g.levels[id];
         const uint32_t top = sl->top;
@@ -813,9 +817,10 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit(GraphView g, Oc
                     if (mb) k = 63 - __builtin_clzll((unsigned long long)mb);
                 }
                 if (k >= 0 && checked != jr.n) {
-                    occ_check_range<MODE, T>(g, m, sc, ob, reads, shr, id, checked, jr.n, lane, true, jr.own_base);
+                    occ_check_range<MODE, T>(g, m, sc, ob, reads, shr, id, checked, jr.n, lane, true, jr.own_base, nullptr, kEmpty, done_rec);
                     checked = jr.n;
                 }
+                if (k >= 0) done_rec |= 1ull << k;                       // (its verdict is taken below; later deltas need not look at it)
                 OCC_T(3);
                 for (uint32_t i = lane; i < cnt; i += 64) m.aux[i] = erow[1 + i];
                 wave_sync();

@@ -314,6 +314,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g
                     jr.own_base = 0;
                     jr.cap = kParMaxDelta;
                     uint32_t checked = 0;                    // own deltas already checked against the records
+                    uint64_t done_rec = 0;                   // speculative records this dry run has already consumed
                     uint32_t nsub = n_shr;                   // the next recomputation's sub-operation
                     bool fail = false, overflow = false;
                     uint32_t nt = 0;
@@ -361,9 +362,10 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g
                                 if (mb) k = 63 - __builtin_clzll((unsigned long long)mb);
                             }
                             if (k >= 0 && checked != jr.n) {
-                                occ_check_range<MODE, T>(g, m, sc, ob, reads, shr, id, checked, jr.n, lane, true, 0u, mydelta);
+                                occ_check_range<MODE, T>(g, m, sc, ob, reads, shr, id, checked, jr.n, lane, true, 0u, mydelta, kEmpty, done_rec);
                                 checked = jr.n;
                             }
+                            if (k >= 0) done_rec |= 1ull << k;       // (its verdict is taken below; later deltas need not look at it)
                             DRY_T(2);
                             for (uint32_t i = lane; i < cnt; i += 64) m.aux[i] = erow[1 + i];
                             wave_sync_full();

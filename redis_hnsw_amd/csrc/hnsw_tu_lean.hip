@@ -47,10 +47,9 @@ hnsw_status launch_lean_v(hnsw_index *h, int R, uint32_t bb, uint32_t db, const 
         return launch_lean_t<VEC, RR, BBB, DDB, WIDE, true>(h, dQ, B, k, idbits, per_cu, d_ids, d_sims, d_nout, st);
             TIE_CASE(1, 10, 3) TIE_CASE(1, 11, 3) TIE_CASE(4, 10, 3) TIE_CASE(4, 11, 3) TIE_CASE(1, 9, 3) TIE_CASE(4, 9, 3)
 #undef TIE_CASE
-            *done = false;                               // (another shape: the general kernel answers, nothing is counted)
-            return fail(h, HNSW_ERR_INVALID, "tie_census: this index shape has no census kernel (ef_construction <= 256, ids < 2^24)");
+            h->tie_uncounted = true;                     // (another shape: the plain kernel answers, hnsw_get_tie_counters says "unknown")
         }
-    }
+    } else if (h->tie_census) h->tie_uncounted = true;
 #define LEAN_CASE(RR, BBB, DDB)                                                                                  \
     if (R == RR && bb == BBB && db == DDB)                                                                      \
         return launch_lean_t<VEC, RR, BBB, DDB, WIDE>(h, dQ, B, k, idbits, per_cu, d_ids, d_sims, d_nout, st);

@@ -56,7 +56,7 @@ static hnsw_status occ_round_t(hnsw_index *h, const InsertCfg &c, const OccBufs 
     }
     if (!team)
         hipLaunchKernelGGL(kc, dim3(1), dim3(64), lds_commit, h->stream, gv, ob, end_node, h->m, c.lnb, c.lcap, h->d_spill_one,
-                           h->spill_one_gnb, h->d_plan, h->m + 2 + h->occ_slack_extra, h->occ_want_touched ? h->d_touched : nullptr,
+                           h->spill_one_gnb, h->d_plan, occ_slack(h), h->occ_want_touched ? h->d_touched : nullptr,
                            h->occ_want_touched ? h->touched_cap : 0u, 0u, TeamCfg{}, (uint32_t *)nullptr, h->occ_chained ? 1u : 0u);
     HIP_TRY(h, hipGetLastError());
     return HNSW_OK;

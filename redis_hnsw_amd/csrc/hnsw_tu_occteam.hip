@@ -59,7 +59,7 @@ static hnsw_status commit_team_t(hnsw_index *h, const InsertCfg &c, const OccBuf
         }
     }
     hipLaunchKernelGGL(kc, dim3(1), dim3(64 * (1 + kTeamHelpers)), lds, h->stream, view_tag(h, c.tagcfg), ob, end_node, h->m, c.lnb, c.lcap,
-                       h->d_spill_one, h->spill_one_gnb, h->d_plan, h->m + 2 + h->occ_slack_extra,
+                       h->d_spill_one, h->spill_one_gnb, h->d_plan, occ_slack(h),
                        h->occ_want_touched ? h->d_touched : nullptr, h->occ_want_touched ? h->touched_cap : 0u, (uint32_t)c.lds, tc, h->d_spill,
                        h->occ_chained ? 1u : 0u);
     HIP_TRY(h, hipGetLastError());

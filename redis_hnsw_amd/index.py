@@ -377,7 +377,9 @@ class Index:
         insert_events, plans_with_tie); search counts need set_tuning("tie_census", 1)"""
         out = (C.c_uint64 * 4)()
         self._check(self._lib.hnsw_get_tie_counters(self._h, out))
-        return dict(search_events=int(out[0]), queries_with_tie=int(out[1]), insert_events=int(out[2]), plans_with_tie=int(out[3]))
+        unknown = int(out[0]) == 2 ** 64 - 1                  # a search ran on a kernel without a census form
+        return dict(search_events=None if unknown else int(out[0]), queries_with_tie=None if unknown else int(out[1]),
+                    insert_events=int(out[2]), plans_with_tie=int(out[3]))
 
     def set_tuning(self, key, value):
         self._check(self._lib.hnsw_set_tuning(self._h, key.encode(), int(value)))

@@ -30,7 +30,8 @@ while time.time() - t0 < budget:
     tun = []
     for key, vals in (("occ_window", [8, 32, 64]), ("occ_ahead_x10", [10, 15, 40]), ("select_shortcut", [0, 1]),
                       ("occ_log_cap", [500, 3072]), ("plan_lean", [0, 1]), ("commit_par", [0, 2, 2]), ("plan_split", [0, 1]),
-                      ("occ_chain", [1, 8]), ("commit_team", [0, 1])):
+                      ("occ_chain", [1, 8]), ("commit_team", [0, 1]), ("occ_stage_ahead", [0, 8, 32]), ("occ_depth_x10", [0, 30]),
+                      ("occ_front_max", [3, 16]), ("par_max_resident", [3, 0])):
         if rng.random() < 0.3:
             tun.append((key, int(rng.choice(vals))))
     case = dict(seed=seed, kind=kind, dim=dim, m=m, ef=ef, n=n, tun=tun)

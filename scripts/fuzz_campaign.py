@@ -31,7 +31,9 @@ while time.time() - t0 < budget:
                           ("occ_min_batch", [2, 64]), ("occ_ahead_x10", [10, 30]), ("waves_per_cu", [1, 4, 8]),
                           ("tag_table", [0, 1]), ("pipe_chunk", [64, 256, 1024]), ("grid_stride", [0, 1]),
                           ("force_restride", [16, 48]), ("plan_lean", [0, 1]), ("single_window", [0, 1]),
-                          ("duo", [0, 1]), ("plan_duo", [0, 1]), ("commit_team", [0, 1]), ("commit_par", [0, 2, 2]), ("plan_split", [0, 1]), ("occ_chain", [1, 4, 8])):
+                          ("duo", [0, 1]), ("plan_duo", [0, 1]), ("commit_team", [0, 1]), ("commit_par", [0, 2, 2]), ("plan_split", [0, 1]), ("occ_chain", [1, 4, 8]),
+                          ("occ_stage_ahead", [0, 8, 32]), ("occ_depth_x10", [0, 30]), ("occ_front_max", [3, 16]), ("par_max_resident", [3, 0]),
+                          ("tie_census", [0, 1])):
             if rng.random() < 0.4:
                 tun.append((key, int(rng.choice(vals))))
     case = case + (tuple(tun),)

@@ -1,2 +1,3 @@
 cd /root/repo
-BASE_N=50000 TUNINGS=";occ_ahead_x10=30;occ_ahead_x10=50;plan_split=0;occ_stage_ahead=0;commit_par=0;commit_par=0,occ_ahead_x10=40;select_shortcut=0" python scripts/occ_at_scale.py 6144 2>&1 | grep -v "amdgpu.ids\|rounds ended\|   groups"
+TUNINGS=";occ_slack_base=3;" python scripts/occ_at_scale.py 12288 2>&1 | grep -v "amdgpu.ids\|rounds ended"
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_ties.py -k "parallel_validated or windowed or exact or ties or census or unknown" -x -q 2>&1 | tail -5

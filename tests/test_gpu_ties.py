@@ -127,3 +127,27 @@ def test_insert_census_sees_every_tie_the_oracle_sees(eng, oracle_mod):
     assert ok, why
     gi.close()
     o.close()
+
+
+def test_a_search_without_a_census_kernel_reads_as_unknown(eng, oracle_mod):
+    """tie_census = 1 on a shape the census form of the kernel does not serve (dim 64: the general kernel): the searches are
+    answered as ever, and the search half of the counters says UNKNOWN rather than zero; the insert half still counts."""
+    n, dim, m, ef = 800, 64, 8, 40
+    V = make_data(n, dim, seed=61)
+    lv = oracle_mod.draw_levels(n, m, 2)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch(V, lv)
+    gi = eng.Index("unk", dim, m, ef)
+    gi.add_batch(V, levels=lv, mode="exact")
+    gi.set_tuning("tie_census", 1)
+    gi.reset_counters()
+    Q = make_data(32, dim, seed=62)
+    ids, sims, n_out = gi.search_batch(Q, 5)
+    oids, osims, on, _ = o.search_batch(Q, 5)
+    assert np.array_equal(ids, oids) and np.array_equal(sims.view(np.uint32), osims.view(np.uint32))
+    t = gi.tie_counters()
+    assert t["search_events"] is None and t["queries_with_tie"] is None and t["insert_events"] == 0
+    gi.reset_counters()                                                     # a new period: nothing ran, nothing is unknown
+    assert gi.tie_counters()["search_events"] == 0
+    gi.close()
+    o.close()
