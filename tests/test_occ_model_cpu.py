@@ -45,6 +45,25 @@ def test_parallel_validated_commits_reproduce_the_serial_graph(tmp_path):
     assert r.returncode != 0 and "graphs IDENTICAL" not in r.stdout
 
 
+def test_look_ahead_plans_made_during_the_commits_are_sound_under_the_hot_row_rule(tmp_path):
+    """AHEAD (round 6, DESIGN.md 4.2g / docs/history.md): the nodes that enter the window next round are planned WHILE this
+    round's commits are applied -- modelled by planning them against the graph as it stands after the round's first group --
+    with the journal position at the START of the commits as their snapshot, and every delta journalled during those
+    commits that sits on a row such a plan read voids the read outright (the row may have been seen before, after, or
+    torn).  The graphs must stay the serial oracle's; the model also says what the rule costs (most look-ahead plans are
+    voided on small indexes), which is why the overlap was not built for the GPU."""
+    exe = str(tmp_path / "occ_model")
+    src = os.path.join(ROOT, "tests", "experiments", "occ_model.c")
+    subprocess.check_call(["gcc", "-O2", "-mavx2", "-mfma", "-ffp-contract=off", "-w", "-o", exe, src, "-lm", "-lpthread"])
+    env = dict(os.environ, PAR="1", AHEAD="1.3")
+    for args in (["1500", "200", "16", "32", "6", "40"], ["3000", "400", "24", "16", "8", "32"]):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "graphs IDENTICAL" in r.stdout
+        m = re.search(r"look-ahead plans \(made during the commits\): ([0-9]+), of which voided by a hot delta on a row they read: link plan ([0-9]+)", r.stdout)
+        assert m and int(m.group(1)) > 0 and int(m.group(2)) > 0
+
+
 def test_select_after_search_is_the_head_of_W(tmp_path):
     """tests/experiments/select_head.c: the reference's insert() with the full select_neighbors never returns
     anything but the m nearest of W (what the engine's plan kernels use instead of the extension)."""
