@@ -257,7 +257,11 @@ hnsw_status hnsw_deserialize(const void *buf, uint64_t bytes, uint64_t seed, int
  *             kernel, see hnsw_get_tie_counters), "grid_stride", "query_in_lds", "time_launches",
  *             "lds_buckets" / "lds_hash_bits" / "tag_table" / "tag_bb" / "idbits" / "grid" (tests)
  *   build     "occ_window" (slots of the exact parallel insert, 0 = serial), "occ_min_batch",
- *             "occ_ahead_x10", "select_shortcut" (1: select_neighbors after search_level is the head
+ *             "occ_ahead_x10" / "occ_front_max" (nodes the group commit dry-runs side by side), "occ_depth_x10" (how far
+ *             ahead of them nodes are planned; 0 = the same), "occ_stage_ahead" (nodes beyond the window whose layers
+ *             above 0 are planned ahead), "commit_par" / "commit_par_min_x10" / "par_max_resident" (commits in validated
+ *             parallel groups; the last one pretends a smaller device, tests), "plan_split" / "plan_split_x10",
+ *             "occ_chain" (rounds enqueued per host synchronisation), "select_shortcut" (1: select_neighbors after search_level is the head
  *             of W, see csrc/hnsw_insert.hpp), "plan_lean" (1: dim-128 insert plans -- single hnsw_add
  *             calls and the windowed exact build -- search with the specialised routine of the search
  *             kernel, csrc/hnsw_plan_lean.hpp; same graph either way), "single_window" (1: a single hnsw_add
