@@ -214,6 +214,7 @@ typedef struct {
      * different nodes -- the only places where the reference's sim-only order (core.rs:292-300) and this
      * file's (sim, id) order can part */
     uint64_t tie_stop, tie_accept, tie_select;
+    uint64_t tie_order;   /* equal similarities where only an ORDER is decided: inside a selection (link / shrink / append order), W's two nearest (entry point) */
 } scratch;
 
 struct hnsw_oracle {                                   /* core.rs:303-319  */
@@ -381,6 +382,8 @@ static simpair nearest_of_W(const scratch *s)
 {
     simpair best = s->W.a[0];
     for (uint32_t i = 1; i < s->W.n; i++) if (nearer(s->W.a[i], best)) best = s->W.a[i];
+    /* census: two nearest members with equal similarities -- which one is the next layer's entry point is the heap's choice */
+    for (uint32_t i = 0; i < s->W.n; i++) if (s->W.a[i].sim == best.sim && s->W.a[i].id != best.id) { ((scratch *)s)->tie_order++; break; }
     return best;
 }
 
@@ -435,6 +438,12 @@ static void select_neighbors(hnsw_oracle *o, scratch *s, uint32_t query,
         if (p.id == query || (ignored >= 0 && p.id == (uint32_t)ignored)) continue;
         heap_push(r, p);
     }
+    /* census: equal similarities INSIDE the selection: connect_neighbors (:765-772), the shrink loop (:540-541) and
+     * update_node_connections (:790-796) pop it nearest first, so which of two equal ones is linked / shrunk / appended first
+     * -- the stored order of rows -- is the heap's choice */
+    for (uint32_t i = 0; i < r->n; i++)
+        for (uint32_t j = i + 1; j < r->n; j++)
+            if (r->a[i].sim == r->a[j].sim) { s->tie_order++; i = r->n; break; }
     if (r->n == m && m) {                               /* census: equal similarities across the cut (:733 / :741) */
         float worst = r->a[0].sim;
         for (uint32_t i = 1; i < r->n; i++) if (r->a[i].sim < worst) worst = r->a[i].sim;
@@ -644,7 +653,7 @@ int64_t hnsw_oracle_add(hnsw_oracle *o, const float *v, int32_t level,
     uint32_t id = o->node_count;
     ensure_cap(o);                                      /* before touch_reset sizes its stamps */
     touch_reset(o);
-    o->sc.tie_stop = o->sc.tie_accept = o->sc.tie_select = 0;   /* census of this insert (hnsw_oracle_last_add_ties) */
+    o->sc.tie_stop = o->sc.tie_accept = o->sc.tie_select = o->sc.tie_order = 0;   /* census of this insert (hnsw_oracle_last_add_ties) */
     insert(o, v, l);
     if (touched) {
         uint32_t n = o->n_touch < touched_cap ? o->n_touch : touched_cap;
@@ -715,7 +724,7 @@ void hnsw_oracle_tie_census(const hnsw_oracle *o, const float *Q, uint32_t B, ui
     float *sims = (float *)malloc(((size_t)k + 1) * 4);
     for (uint32_t b = 0; b < B; b++) {
         hnsw_oracle_counters ct = { 0, 0, 0 };
-        s->tie_stop = s->tie_accept = 0;
+        s->tie_stop = s->tie_accept = s->tie_order = 0;
         uint32_t n = search_knn_internal(o, s, Q + (size_t)b * o->dim, k + 1, o->ef_construction, ids, sims, &ct);
         int rt = 0;
         for (uint32_t i = 1; i < n; i++) rt |= sims[i] == sims[i - 1];
@@ -723,7 +732,7 @@ void hnsw_oracle_tie_census(const hnsw_oracle *o, const float *Q, uint32_t B, ui
         out[1] += s->tie_stop; out[2] += s->tie_accept;
         out[3] += (s->tie_stop + s->tie_accept) != 0;
         out[4] += rt != 0;
-        out[5] += (s->tie_stop + s->tie_accept) != 0 || rt;
+        out[5] += (s->tie_stop + s->tie_accept + s->tie_order) != 0 || rt;   /* (tie_order: two nearest of an upper layer equal: the entry point) */
     }
     free(ids); free(sims);
 }
@@ -882,6 +891,12 @@ static void select_neighbors_std(hnsw_oracle *o, scratch *s, rscratch *z, uint32
         if (p.id == query || (ignored >= 0 && p.id == (uint32_t)ignored)) continue;
         rh_push(r, p);
     }
+    /* census: equal similarities INSIDE the selection: connect_neighbors (:765-772), the shrink loop (:540-541) and
+     * update_node_connections (:790-796) pop it nearest first, so which of two equal ones is linked / shrunk / appended first
+     * -- the stored order of rows -- is the heap's choice */
+    for (uint32_t i = 0; i < r->n; i++)
+        for (uint32_t j = i + 1; j < r->n; j++)
+            if (r->a[i].sim == r->a[j].sim) { s->tie_order++; i = r->n; break; }
     if (r->n == m && m) {                                   /* census: equal similarities across the cut */
         float worst = r->a[0].sim;
         for (uint32_t i = 1; i < r->n; i++) if (r->a[i].sim < worst) worst = r->a[i].sim;
@@ -965,6 +980,7 @@ static void insert_std(hnsw_oracle *o, const float *data, uint32_t l)
     while (lc > l) {                                        /* :512 */
         search_level_std_ct(o, s, qv, ep, 1, lc, &z.C, &z.W, &z.res, ct);   /* :513 */
         ep = z.res.a[0].id;                                 /* :514 w.pop(): the root */
+        for (uint32_t i = 1; i < z.res.n; i++) if (z.res.a[i].sim == z.res.a[0].sim) { s->tie_order++; break; }
         if (lc == 0) break;
         lc--;
     }
@@ -996,12 +1012,13 @@ static void insert_std(hnsw_oracle *o, const float *data, uint32_t l)
             }
         }
         ep = z.res.a[0].id;                                 /* :576 w.peek() */
+        for (uint32_t i = 1; i < z.res.n; i++) if (z.res.a[i].sim == z.res.a[0].sim) { s->tie_order++; break; }
     }
     if (l > l_max) { o->max_layer = l; o->enterpoint = query; }   /* :587-593 */
     rscratch_free(&z);
 }
-/* core.rs:383-412 in the Rust binary's tie order; ties[3] (may be NULL) += decisions of THIS insert that met equal
- * similarities of two different nodes: [0] the stop test :635, [1] the accept test :657 with W full, [2] a select cut :733 */
+/* core.rs:383-412 in the Rust binary's tie order; ties[4] (may be NULL) += decisions of THIS insert that met equal
+ * similarities of two different nodes: [0] the stop test :635, [1] the accept test :657 with W full, [2] a select cut :733, [3] order-only ties (inside a selection, W's two nearest) */
 int64_t hnsw_oracle_add_std_heap(hnsw_oracle *o, const float *v, int32_t level, uint64_t *ties)
 {
     if (o->node_count - o->n_dead == 0) {                   /* :393-405 */
@@ -1013,9 +1030,9 @@ int64_t hnsw_oracle_add_std_heap(hnsw_oracle *o, const float *v, int32_t level, 
     uint32_t id = o->node_count;
     ensure_cap(o);
     touch_reset(o);
-    o->sc.tie_stop = o->sc.tie_accept = o->sc.tie_select = 0;
+    o->sc.tie_stop = o->sc.tie_accept = o->sc.tie_select = o->sc.tie_order = 0;
     insert_std(o, v, l);
-    if (ties) { ties[0] += o->sc.tie_stop; ties[1] += o->sc.tie_accept; ties[2] += o->sc.tie_select; }
+    if (ties) { ties[0] += o->sc.tie_stop; ties[1] += o->sc.tie_accept; ties[2] += o->sc.tie_select; ties[3] += o->sc.tie_order; }
     return id;
 }
 
@@ -1192,9 +1209,9 @@ int hnsw_oracle_delete(hnsw_oracle *o, uint32_t id, uint32_t *touched, uint32_t 
     return 0;
 }
 
-void hnsw_oracle_last_add_ties(const hnsw_oracle *o, uint64_t out[3])
+void hnsw_oracle_last_add_ties(const hnsw_oracle *o, uint64_t out[4])
 {
-    out[0] = o->sc.tie_stop; out[1] = o->sc.tie_accept; out[2] = o->sc.tie_select;
+    out[0] = o->sc.tie_stop; out[1] = o->sc.tie_accept; out[2] = o->sc.tie_select; out[3] = o->sc.tie_order;
 }
 
 uint32_t hnsw_oracle_live_count(const hnsw_oracle *o) { return o->node_count - o->n_dead; }

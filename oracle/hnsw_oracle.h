@@ -103,10 +103,14 @@ uint32_t hnsw_oracle_search_std_heap(const hnsw_oracle *o, const float *q, uint3
 /* HNSW.NODE.ADD in the Rust binary's own tie order (core.rs:489-599 on std's BinaryHeap restated, sim-only comparisons
  * at :635, :657, :733): what the reference's binary links once a decision meets equal similarities.  ties (may be NULL)
  * accumulates the decisions of this insert that met a tie: [0] stop test, [1] accept test with W full, [2] a
- * select_neighbors cut.  Same levels / first-node rules as hnsw_oracle_add; no touched list.                          */
+ * select_neighbors cut, [3] equal similarities where only an ORDER is decided -- inside a selection (which of two equal
+ * neighbours is linked / shrunk / appended first: the stored order of rows) or W's two nearest (the next layer's entry
+ * point).  An insert with all four at zero links the same rows in the same order under ANY heap (tests/test_golden_cpu.py:
+ * a build that takes the total-order insert for those and this one for the rest IS this build).  ties has 4 entries.
+ * Same levels / first-node rules as hnsw_oracle_add; no touched list.                                                */
 int64_t hnsw_oracle_add_std_heap(hnsw_oracle *o, const float *v, int32_t level, uint64_t *ties);
-/* Tie census of the LAST hnsw_oracle_add (the total-order build): the same three counts for that insert.             */
-void hnsw_oracle_last_add_ties(const hnsw_oracle *o, uint64_t out[3]);
+/* Tie census of the LAST hnsw_oracle_add (the total-order build): the same four counts for that insert.              */
+void hnsw_oracle_last_add_ties(const hnsw_oracle *o, uint64_t out[4]);
 
 /* core.rs:414-475 + 824-863 (HNSW.NODE.DEL).  Ids are never reused; node_count() keeps counting
  * allocated ids, live_count() is the reference's node_count.  The new enterpoint, which the

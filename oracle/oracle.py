@@ -171,19 +171,19 @@ class OracleIndex:
 
     def add_batch_std_heap(self, V, levels=None):
         """HNSW.NODE.ADD x N in the Rust binary's own tie order (sim-only comparisons on std's BinaryHeap, restated):
-        -> (stop-test ties, accept-test ties, select-cut ties) met by the build's decisions"""
+        -> (stop-test ties, accept-test ties, select-cut ties, order ties) met by the build"""
         V = _f32(V)
-        ties = np.zeros(3, dtype=np.uint64)
+        ties = np.zeros(4, dtype=np.uint64)
         for i in range(V.shape[0]):
             lib().hnsw_oracle_add_std_heap(self._h, _fp(V[i]), -1 if levels is None else int(levels[i]), _u64p(ties))
         return tuple(int(x) for x in ties)
 
     def add_batch_census(self, V, levels=None):
         """add_batch (the (sim, id) total order) with the tie census of every insert: -> (inserts that met a decision
-        tie, stop-test ties, accept-test ties, select-cut ties)"""
+        tie of any kind, stop-test ties, accept-test ties, select-cut ties, order ties)"""
         V = _f32(V)
-        tot = np.zeros(3, dtype=np.uint64)
-        one = np.zeros(3, dtype=np.uint64)
+        tot = np.zeros(4, dtype=np.uint64)
+        one = np.zeros(4, dtype=np.uint64)
         n_ins = 0
         for i in range(V.shape[0]):
             first = self.live_count == 0

@@ -630,6 +630,15 @@ __device__ __forceinline__ uint32_t merge_sorted(uint64_t *W, uint32_t nW, uint3
     return total < cap ? total : cap;
 }
 
+// tie census: do two neighbouring keys of the sorted list L[0..n) have equal distances?  (Keys that the reference pops
+// "nearest first" from a heap ordered by similarity alone: which of two equal ones comes first is the heap's choice.)
+__device__ __forceinline__ bool any_adjacent_equal(const uint64_t *L, uint32_t n, int lane)
+{
+    bool eq = false;
+    for (uint32_t i = lane; i + 1 < n; i += 64) eq |= (uint32_t)(L[i] >> 32) == (uint32_t)(L[i + 1] >> 32);
+    return __ballot(eq) != 0;
+}
+
 // index of the nearest entry not yet expanded (core.rs:631 pop of C), or -1.
 template <int R>
 __device__ __forceinline__ int find_unexpanded(const uint64_t *W, uint32_t nW, int lane)

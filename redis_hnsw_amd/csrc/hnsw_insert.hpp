@@ -204,6 +204,7 @@ __device__ __forceinline__ uint32_t select_topm(const GV &g, const WaveMem &m, V
         drain(1);
         wave_sync();
         if (final_cut && nS == mcap && nS && ctr.tie_emin == (uint32_t)(m.S[mcap - 1] >> 32)) ctr.n_tie += 1u;   // tie census
+        if (final_cut && any_adjacent_equal(m.S, nS, lane)) ctr.n_tie += 1u;     // ... and equal distances INSIDE the selection (link / shrink order)
         return nS;
     }
     // software prefetch: the next candidate's row is requested before the
@@ -247,6 +248,7 @@ __device__ __forceinline__ uint32_t select_topm(const GV &g, const WaveMem &m, V
     }
     wave_sync();
     if (final_cut && nS == mcap && nS && ctr.tie_emin == (uint32_t)(m.S[mcap - 1] >> 32)) ctr.n_tie += 1u;       // tie census
+    if (final_cut && any_adjacent_equal(m.S, nS, lane)) ctr.n_tie += 1u;         // ... and equal distances INSIDE the selection (link / shrink order)
     return nS;
 }
 
@@ -270,8 +272,10 @@ __device__ __forceinline__ uint32_t select_head_of_W(const WaveMem &m, uint32_t 
 {
     const uint32_t nS = nW < mcap ? nW : mcap;
     for (uint32_t i = lane; i < nS; i += 64) m.S[i] = m.W[i] & ~1ull;
-    // tie census: the cut falls between equal distances (core.rs:733: which of the two is linked is the heap's choice)
+    // tie census: the cut falls between equal distances (core.rs:733: which of the two is linked is the heap's choice), or
+    // two selected neighbours have equal distances (core.rs:765-772, :540-541: which is linked / shrunk first)
     if (ties && nW > mcap && mcap && (uint32_t)(m.W[mcap - 1] >> 32) == (uint32_t)(m.W[mcap] >> 32)) *ties += 1u;
+    if (ties && any_adjacent_equal(m.W, nS, lane)) *ties += 1u;
     wave_sync();
     return nS;
 }

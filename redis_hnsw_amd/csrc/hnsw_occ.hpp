@@ -683,6 +683,7 @@ __device__ __forceinline__ uint32_t team_select(const GV &g, const WaveMem &m, V
     }
     // tie census: the cut of the whole pool (core.rs:733 / :741-754) against the nearest key left outside by any share
     if (nS == mmax && nS && ctr.tie_emin == (uint32_t)(m.S[mmax - 1] >> 32)) ctr.n_tie += 1u;
+    if (any_adjacent_equal(m.S, nS, lane)) ctr.n_tie += 1u;                      // equal distances inside the selection
     return nS;
 }
 

@@ -205,6 +205,7 @@ __device__ __forceinline__ bool duo_keep(const GraphView &g, uint64_t *Wbuf, Duo
             lds_order();
             if (lane == 0) vb->nW = nW + (warm == 0x9E3779B9u && lane == 64 ? 1u : 0u);   // (keeps the prefetches alive)
             if constexpr (TIES) { if (nW == ef && ties[1] == (uint32_t)(worst >> 32)) ties[0] += 1u; }   // the last pop (core.rs:635)
+            if constexpr (TIES) { if (nW >= 2u && (uint32_t)(Wbuf[0] >> 32) == (uint32_t)(Wbuf[1] >> 32)) ties[0] += 1u; }   // the entry point of the next layer
             if (lane == 0) vb->ties = ties[0];
             PH_MARK(ctr, 6);
             duo_reply(box, seq, lane);

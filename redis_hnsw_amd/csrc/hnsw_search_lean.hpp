@@ -501,6 +501,9 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
 #pragma unroll
     for (int r = 0; r < R; ++r) Wbuf[r * 64 + lane] = w[r];
     lds_order();
+    // tie census: W's two nearest members at equal distances -- which one is the next layer's entry point (core.rs:514,
+    // :576, :872) is the heap's choice
+    if constexpr (TIES) { if (nW >= 2u && (uint32_t)(Wbuf[0] >> 32) == (uint32_t)(Wbuf[1] >> 32)) ctr.n_tie += 1u; }
     (void)ckey;
     if constexpr (LOG) occ_finalize_search_log(ctr, log_start, lc, nW == ef ? Wbuf[ef - 1] : ~0ull, lane);
     else (void)log_start;

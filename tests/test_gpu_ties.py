@@ -44,7 +44,7 @@ def test_search_census_sees_every_tie_the_oracle_sees(eng, oracle_mod, ef):
         oids, osims = o.search(q, k)
         assert np.array_equal(ids[0, :len(oids)], oids)                    # same answers as ever (the census kernel is the kernel)
         t = gi.tie_counters()
-        want = cen["stop_test_ties"] + cen["accept_test_ties"] + cen["queries_with_answer_tie"]
+        want = cen["queries_with_any_tie"]
         if want:
             seen += 1
             assert t["search_events"] >= 1 and t["queries_with_tie"] == 1, (cen, t)
@@ -114,7 +114,7 @@ def test_insert_census_sees_every_tie_the_oracle_sees(eng, oracle_mod):
     seen = 0
     for i in range(n0, n0 + extra):
         o.add(V[i], int(lv[i]))
-        one = np.zeros(3, dtype=np.uint64)
+        one = np.zeros(4, dtype=np.uint64)
         lib.hnsw_oracle_last_add_ties(o._h, one.ctypes.data_as(C.POINTER(C.c_uint64)))
         gi.reset_counters()
         gi.add_node("n%d" % i, V[i], level=int(lv[i]))
