@@ -28,6 +28,7 @@ UNITS = [
     ("hnsw_tu_occpar.hip", [0, 1, 2, 3], ["hnsw_occ_par.hpp"]),
     ("hnsw_tu_planlean.hip", [0, 1], ["hnsw_plan_lean.hpp", "hnsw_search_lean.hpp", "hnsw_search_duo.hpp"]),
     ("hnsw_tu_planduo.hip", [0, 1], ["hnsw_plan_lean.hpp", "hnsw_search_lean.hpp", "hnsw_search_duo.hpp"]),
+    ("hnsw_tu_std.hip", [None], ["hnsw_std_heap.hpp"]),   # the reference binary's tie order on one lane (tuning tie_mode)
     ("hnsw_group.hip", [None], []),                   # one process, several GPUs: host code above the C ABI
 ]
 SOURCES = [u[0] for u in UNITS]

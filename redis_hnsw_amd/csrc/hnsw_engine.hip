@@ -730,6 +730,7 @@ hnsw_status hnsw_set_tuning(hnsw_index *h, const char *key, int64_t value)
     if (!std::strcmp(key, "occ_min_batch")) { h->occ_min_batch = (uint32_t)std::max<int64_t>(value, 1); return HNSW_OK; }
     if (!std::strcmp(key, "lean")) { h->lean = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "tie_census")) { h->tie_census = value != 0; return HNSW_OK; }
+    if (!std::strcmp(key, "tie_mode")) { h->tie_mode = value < 0 ? 0 : (value > 2 ? 2 : (int)value); if (h->tie_mode == 1) h->tie_census = true; return HNSW_OK; }
     if (!std::strcmp(key, "duo")) { h->duo = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "plan_duo")) { h->plan_duo = value != 0; return HNSW_OK; }
     if (!std::strcmp(key, "occ_chain")) { h->occ_chain = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 16); return HNSW_OK; }
@@ -817,7 +818,7 @@ hnsw_status hnsw_add_batch(hnsw_index *h, const float *V, uint32_t n, uint32_t d
     if (h->wide_m) mode = 0;                                 // M > 64: the reference's order through the serial kernels
     // exact inserts: all of them (mode 0) or the seed prefix of the fast build.  Large exact batches go
     // through the optimistic window (same graph, planned in parallel, committed in order: hnsw_occ.hpp).
-    if (mode == 0 && h->occ_window >= 2 && n >= h->occ_min_batch) {
+    if (mode == 0 && h->occ_window >= 2 && n >= h->occ_min_batch && h->tie_mode != 2) {
         while (done < n && h->n - h->n_dead < 2) {           // the first nodes: serial (no graph to plan against)
             if ((s = add_exact(h, V + (size_t)done * dim, nullptr, levels ? levels[done] : -1, nullptr, false, nullptr)) != HNSW_OK)
                 return s;

@@ -147,6 +147,12 @@ struct hnsw_index {
     bool bf16 = false;               // fmt == FMT_BF16 (the specialised dim-128 kernel has a bf16 form)
     bool select_shortcut = true;     // select_neighbors after search_level = the head of W (hnsw_insert.hpp); 0 = the full extension
     bool plan_lean = true;           // dim-128 insert plans (single adds, the windowed exact build) search with the specialised routine (hnsw_plan_lean.hpp)
+    // tuning "tie_mode": 0 off; 1 an insert / a query the tie census flags is redone in the reference binary's own tie order
+    // (hnsw_std_heap.hpp: one lane, std's BinaryHeap restated); 2 EVERY insert and query runs there (tests: the port itself)
+    int tie_mode = 0;
+    void *d_std_stamp = nullptr, *d_std_heaps = nullptr, *d_std_ctx = nullptr, *d_std_misc = nullptr;
+    uint32_t std_cap = 0, std_hcap = 0;
+    struct { void *stamp, *epoch, *heaps; uint32_t hcap; void *status; } std_ctx0 = {};   // (layout of hnsw::StdScratch: checked where it is used)
     bool tie_uncounted = false;      // a search ran without a census kernel while tie_census was on (since the last hnsw_reset_counters)
     bool tie_census = false;         // tuning: searches run the census form of the specialised kernel (hnsw_get_tie_counters; f32 rows, one wave per query)
     bool lean = true;                // dim-128 searches use the specialised kernel (hnsw_search_lean.hpp) when its preconditions hold
@@ -314,6 +320,11 @@ hnsw_status launch_occ_plan_duo_v(hnsw_index *h, const InsertCfg &c, const OccBu
 uint32_t plan_lean_idbits(const hnsw_index *h, const InsertCfg &c);
 size_t plan_lean_lds(int R);
 hnsw_status launch_occ_plan_lean(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t head, uint32_t count, bool *done);
+// hnsw_tu_std.hip: the reference binary's own tie order on one lane (tuning "tie_mode")
+hnsw_status launch_insert_std(hnsw_index *h, uint32_t id, bool want_touched);
+hnsw_status launch_search_std(hnsw_index *h, const float *dQ, const uint32_t *d_which, uint32_t n, uint32_t k, uint32_t *d_ids, float *d_sims,
+                              uint32_t *d_nout, hipStream_t st);
+hnsw_status std_status(hnsw_index *h, uint32_t *out);
 // hnsw_tu_occ.hip
 template <int MODE, int T>
 hnsw_status occ_round_r(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t head, uint32_t count, uint32_t end_node);

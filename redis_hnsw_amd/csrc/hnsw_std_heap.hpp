@@ -1,0 +1,366 @@
+// hnsw_std_heap.hpp -- HNSW.NODE.ADD and HNSW.SEARCH in the REFERENCE BINARY's own tie order (tuning "tie_mode").
+//
+// The reference orders SimPair by similarity alone (core.rs:292-300) and keeps C, W and every selection in
+// std::collections::BinaryHeap: which of two EQUAL similarities pops, is evicted or is linked first is decided by that
+// heap's sift procedures.  The engine's kernels use the total order (distance, id) instead -- a whole adjacency row merged
+// at once needs one -- and count every place where the two can part (hnsw_get_tie_counters; proven sufficient on the CPU:
+// tests/test_golden_cpu.py).  With tie_mode on, an insert / a query the census flags is REDONE here, on one lane, as the
+// reference executes it: insert() / search_level() / select_neighbors() / connect_neighbors() / update_node_connections()
+// of core.rs:489-822 statement by statement on a restatement of std's heap (push = sift_up; pop = swap the last element
+// into the root, sift_down_to_bottom towards the greater child -- the right one when equal -- then sift_up; clone /
+// into_vec / into_iter = the array as it is).  Slow by construction (one lane, heaps in HBM: ~10-50 ms per insert) and
+// rare (1-2.5 % of the inserts on uniform f32 data); the result is what the Rust binary links, row for row
+// (tests/test_gpu_ties.py against the transcription's "rust"-mode golden).
+#pragma once
+#include "hnsw_insert.hpp"
+
+namespace hnsw {
+
+struct StdPair { float sim; uint32_t id; };
+struct StdHeap { StdPair *a; uint32_t n, cap; int reverse; };        // reverse: BinaryHeap<Reverse<SimPair>> (pops the smallest sim)
+
+// scratch of one std-order operation (HBM): visited stamps + ten heaps of `hcap` entries
+struct StdScratch {
+    uint32_t *stamp;          // [node capacity]: epoch stamps (HashSet v, core.rs:614, 692)
+    uint32_t *epoch;          // [1]
+    StdPair *heaps;           // [10][hcap]
+    uint32_t hcap;
+    uint32_t *status;         // [1]: 1 = a heap overflowed (nothing can be trusted: the host reports it)
+};
+
+__device__ __forceinline__ bool std_le(const StdHeap &h, float x, float y) { return h.reverse ? y <= x : x <= y; }
+__device__ inline uint32_t std_sift_up(StdHeap &h, uint32_t start, uint32_t pos)
+{
+    const StdPair e = h.a[pos];
+    while (pos > start) {
+        const uint32_t parent = (pos - 1) / 2;
+        if (std_le(h, e.sim, h.a[parent].sim)) break;                 // hole.element() <= hole.get(parent)
+        h.a[pos] = h.a[parent];
+        pos = parent;
+    }
+    h.a[pos] = e;
+    return pos;
+}
+__device__ inline void std_push(StdHeap &h, StdPair x, uint32_t *status)
+{
+    if (h.n >= h.cap) { *status = 1u; return; }
+    h.a[h.n++] = x;
+    std_sift_up(h, 0, h.n - 1);
+}
+__device__ inline StdPair std_pop(StdHeap &h)
+{
+    StdPair item = h.a[--h.n];
+    if (h.n) {
+        const StdPair t = h.a[0]; h.a[0] = item; item = t;
+        const uint32_t end = h.n;
+        uint32_t pos = 0, child = 1;
+        const StdPair e = h.a[0];
+        while (end >= 2 && child <= end - 2) {                        // sift_down_to_bottom
+            if (std_le(h, h.a[child].sim, h.a[child + 1].sim)) child++;
+            h.a[pos] = h.a[child];
+            pos = child;
+            child = 2 * pos + 1;
+        }
+        if (child == end - 1) { h.a[pos] = h.a[child]; pos = child; }
+        h.a[pos] = e;
+        std_sift_up(h, 0, pos);
+    }
+    return item;
+}
+__device__ inline void std_clone(StdHeap &dst, const StdHeap &src, uint32_t *status)
+{
+    if (src.n > dst.cap) { *status = 1u; dst.n = 0; return; }
+    for (uint32_t i = 0; i < src.n; ++i) dst.a[i] = src.a[i];
+    dst.n = src.n; dst.reverse = src.reverse;
+}
+
+// metrics.rs:14-84 on one lane, bit for bit: the AVX2 order (4 accumulators x 8 lanes, one FMA per 32-block, then
+// (e1+e2)+(e3+e4), low128+high128, (s0+s1)+(s2+s3)) iff dim % 32 == 0, else the scalar left fold
+__device__ inline float std_sim(const float *a, const float *b, uint32_t dim)
+{
+    if (dim % 32u == 0u) {
+        float e[4][8];
+        for (int acc = 0; acc < 4; ++acc)
+            for (int j = 0; j < 8; ++j) e[acc][j] = 0.f;
+        for (uint32_t i = 0; i + 32 <= dim; i += 32)
+            for (int acc = 0; acc < 4; ++acc)
+                for (int j = 0; j < 8; ++j) {
+                    const float d = __fsub_rn(a[i + 8 * acc + j], b[i + 8 * acc + j]);
+                    e[acc][j] = __fmaf_rn(d, d, e[acc][j]);
+                }
+        float v[8], s[4];
+        for (int j = 0; j < 8; ++j) v[j] = __fadd_rn(__fadd_rn(e[0][j], e[1][j]), __fadd_rn(e[2][j], e[3][j]));
+        for (int j = 0; j < 4; ++j) s[j] = __fadd_rn(v[j], v[j + 4]);
+        return -__fadd_rn(__fadd_rn(s[0], s[1]), __fadd_rn(s[2], s[3]));
+    }
+    float acc = 0.f;
+    for (uint32_t i = 0; i < dim; ++i) {
+        const float d = __fsub_rn(a[i], b[i]);
+        acc = __fadd_rn(acc, __fmul_rn(d, d));
+    }
+    return -acc;
+}
+
+struct StdCtx {
+    GraphView g;
+    StdScratch sc;
+    StdHeap C, W, res, w, wd, ccopy, nbrs, econn, enew, t;
+    uint32_t epoch;
+    unsigned long long n_dist, n_ids, n_expand;
+    uint32_t *touched, touched_cap, nt;
+};
+__device__ inline void std_ctx_init(StdCtx &x, const GraphView &g, const StdScratch &sc)
+{
+    x.g = g; x.sc = sc;
+    StdHeap *hs[10] = {&x.C, &x.W, &x.res, &x.w, &x.wd, &x.ccopy, &x.nbrs, &x.econn, &x.enew, &x.t};
+    for (int i = 0; i < 10; ++i) { hs[i]->a = sc.heaps + (size_t)i * sc.hcap; hs[i]->n = 0; hs[i]->cap = sc.hcap; hs[i]->reverse = 0; }
+    x.epoch = *sc.epoch;
+    x.n_dist = x.n_ids = x.n_expand = 0;
+    x.touched = nullptr; x.touched_cap = 0; x.nt = 0;
+}
+__device__ inline void std_visited_reset(StdCtx &x, uint32_t n)
+{
+    if (++x.epoch == 0u) { for (uint32_t i = 0; i < n; ++i) x.sc.stamp[i] = 0u; x.epoch = 1u; }
+}
+__device__ inline bool std_test_and_set(StdCtx &x, uint32_t id)
+{
+    if (x.sc.stamp[id] == x.epoch) return true;
+    x.sc.stamp[id] = x.epoch;
+    return false;
+}
+__device__ inline const float *std_vec(const StdCtx &x, uint32_t id) { return x.g.vec + (size_t)id * x.g.dim; }
+// rows above a node's top level behave as empty (push_levels, core.rs:127-135, 642)
+__device__ inline const uint32_t *std_row(const StdCtx &x, uint32_t id, uint32_t lc, uint32_t &cnt)
+{
+    if (lc > x.g.levels[id]) { cnt = 0; return nullptr; }
+    const uint32_t *r = row_ptr(x.g, id, lc);
+    const uint32_t stride = lc ? x.g.strideU : x.g.stride0;
+    cnt = r[0] > stride - 1 ? stride - 1 : r[0];
+    return r + 1;
+}
+__device__ inline void std_touch(StdCtx &x, uint32_t id)
+{
+    if (x.touched && x.nt < x.touched_cap) x.touched[x.nt] = id;
+    x.nt += 1;
+}
+// core.rs:137-143 add_neighbor: push iff not already present
+__device__ inline void std_add_neighbor(StdCtx &x, uint32_t id, uint32_t lc, uint32_t nb)
+{
+    uint32_t *r = row_ptr(x.g, id, lc);
+    const uint32_t stride = lc ? x.g.strideU : x.g.stride0;
+    const uint32_t cnt = r[0];
+    for (uint32_t i = 0; i < cnt; ++i) if (r[1 + i] == nb) return;
+    if (cnt + 1 > stride - 1) { atomicOr(&x.g.hdr->status, ST_ROW_OVERFLOW); return; }
+    r[1 + cnt] = nb; r[0] = cnt + 1;
+    atomicMax(lc ? &x.g.hdr->max_degU : &x.g.hdr->max_deg0, cnt + 1);
+}
+// core.rs:145-152 rm_neighbor: position().unwrap() then Vec::remove
+__device__ inline void std_rm_neighbor(StdCtx &x, uint32_t id, uint32_t lc, uint32_t nb)
+{
+    uint32_t *r = row_ptr(x.g, id, lc);
+    const uint32_t cnt = r[0];
+    for (uint32_t i = 0; i < cnt; ++i)
+        if (r[1 + i] == nb) {
+            for (uint32_t j = i; j + 1 < cnt; ++j) r[1 + j] = r[2 + j];
+            r[0] = cnt - 1;
+            return;
+        }
+    atomicOr(&x.g.hdr->status, ST_ASYMMETRIC);                         // the reference panics here (core.rs:150)
+}
+
+// core.rs:607-675; leaves the result heap (:670-674) in x.res
+__device__ inline void std_search_level(StdCtx &x, const float *query, uint32_t ep, uint32_t ef, uint32_t level)
+{
+    std_visited_reset(x, x.g.hdr->node_count);
+    std_test_and_set(x, ep);
+    const StdPair qpair = {std_sim(query, std_vec(x, ep), x.g.dim), ep};
+    x.n_dist += 1;
+    x.C.n = x.W.n = x.res.n = 0; x.C.reverse = 0; x.W.reverse = 1; x.res.reverse = 0;
+    std_push(x.C, qpair, x.sc.status); std_push(x.W, qpair, x.sc.status);
+    while (x.C.n) {
+        const StdPair c = std_pop(x.C);
+        StdPair f = x.W.a[0];
+        if (c.sim < f.sim) break;                                     // :635
+        x.n_expand += 1;
+        uint32_t cnt;
+        const uint32_t *nb = std_row(x, c.id, level, cnt);
+        for (uint32_t i = 0; i < cnt; ++i) {                          // :646 stored order
+            const uint32_t e = nb[i];
+            x.n_ids += 1;
+            if (std_test_and_set(x, e)) continue;
+            f = x.W.a[0];
+            const StdPair e2 = {std_sim(query, std_vec(x, e), x.g.dim), e};
+            x.n_dist += 1;
+            if (e2.sim > f.sim || x.W.n < ef) {                       // :657
+                std_push(x.C, e2, x.sc.status); std_push(x.W, e2, x.sc.status);
+                if (x.W.n > ef) std_pop(x.W);
+            }
+        }
+        if (*x.sc.status) return;
+    }
+    for (uint32_t i = 0; i < x.W.n; ++i) std_push(x.res, x.W.a[i], x.sc.status);   // :670-674: into_iter order, pushed one by one
+}
+
+// core.rs:677-757 (extend_candidates = keep_pruned_connections = true at every call site); result in r
+__device__ inline void std_select_neighbors(StdCtx &x, uint32_t query, const StdHeap &c, uint32_t m, uint32_t lc, uint32_t ignored, StdHeap &r)
+{
+    r.n = 0; r.reverse = 0;
+    std_clone(x.w, c, x.sc.status);                                   // :685
+    x.wd.n = 0; x.wd.reverse = 0;
+    std_visited_reset(x, x.g.hdr->node_count);                        // :692
+    for (uint32_t i = 0; i < c.n; ++i) std_test_and_set(x, c.a[i].id);   // :690-696 (a set)
+    std_clone(x.ccopy, c, x.sc.status);                               // :698
+    const float *qv = std_vec(x, query);
+    while (x.ccopy.n) {
+        const StdPair e = std_pop(x.ccopy);
+        uint32_t cnt;
+        const uint32_t *nb = std_row(x, e.id, lc, cnt);
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const uint32_t en = nb[i];
+            x.n_ids += 1;
+            if (en == query || en == ignored) continue;              // :704-708
+            if (x.sc.stamp[en] != x.epoch) {                          // :710
+                const StdPair p = {std_sim(qv, std_vec(x, en), x.g.dim), en};
+                x.n_dist += 1;
+                std_push(x.w, p, x.sc.status);                        // :717
+                x.sc.stamp[en] = x.epoch;                             // :718
+            }
+        }
+        if (*x.sc.status) return;
+    }
+    while (x.w.n && r.n < m) {                                        // :724-738
+        const StdPair e = std_pop(x.w);
+        if (e.id == query || e.id == ignored) continue;
+        if (r.n == 0 || e.sim > r.a[0].sim) std_push(r, e, x.sc.status);   // :733
+        else std_push(x.wd, e, x.sc.status);
+    }
+    while (x.wd.n && r.n < m) {                                       // :741-754
+        const StdPair p = std_pop(x.wd);
+        if (p.id == query || p.id == ignored) continue;
+        std_push(r, p, x.sc.status);
+    }
+}
+
+// core.rs:776-822
+__device__ inline void std_update_node_connections(StdCtx &x, uint32_t node, const StdHeap &new_neighbors, const StdHeap &old_neighbors, uint32_t level,
+                                                   uint32_t ignored)
+{
+    std_clone(x.t, new_neighbors, x.sc.status);                      // :784
+    // :785 into_vec: the old heap's array as it is -- kept in x.wd's storage (free here)
+    StdPair *rm = x.wd.a;
+    uint32_t n_rm = old_neighbors.n;
+    if (n_rm > x.wd.cap) { *x.sc.status = 1u; return; }
+    for (uint32_t i = 0; i < n_rm; ++i) rm[i] = old_neighbors.a[i];
+    std_touch(x, node);                                               // :787
+    while (x.t.n) {                                                   // :790
+        const StdPair np = std_pop(x.t);
+        std_add_neighbor(x, node, level, np.id);                      // :793
+        std_add_neighbor(x, np.id, level, node);                      // :794-795
+        std_touch(x, np.id);                                          // :796
+        for (uint32_t i = 0; i < n_rm; ++i)                           // :799-801
+            if (rm[i].id == np.id) { for (uint32_t j = i; j + 1 < n_rm; ++j) rm[j] = rm[j + 1]; n_rm--; break; }
+    }
+    while (n_rm) {                                                    // :805
+        const StdPair rp = rm[--n_rm];
+        std_rm_neighbor(x, node, level, rp.id);                       // :808
+        if (rp.id == ignored) continue;                               // :810-813
+        std_rm_neighbor(x, rp.id, level, node);                       // :815
+        std_touch(x, rp.id);                                          // :816
+    }
+}
+
+// core.rs:489-599 for node `query` (vector, level and empty rows already in place); one lane
+__device__ inline void std_insert(StdCtx &x, uint32_t query, uint32_t mlinks, uint32_t ef)
+{
+    const uint32_t l = x.g.levels[query];
+    const uint32_t l_max = x.g.hdr->max_layer;                        // :496
+    const float *qv = std_vec(x, query);
+    uint32_t ep = (uint32_t)x.g.hdr->enterpoint;                      // :508
+    uint32_t lc = l_max;
+    while (lc > l) {                                                  // :511-520
+        std_search_level(x, qv, ep, 1, lc);
+        if (*x.sc.status) return;
+        ep = x.res.a[0].id;                                           // :514 w.pop(): the root
+        if (lc == 0) break;
+        lc--;
+    }
+    const uint32_t top = l_max < l ? l_max : l;
+    for (uint32_t lcc = top + 1; lcc-- > 0;) {                        // :523
+        std_search_level(x, qv, ep, ef, lcc);                         // :524
+        if (*x.sc.status) return;
+        std_select_neighbors(x, query, x.res, mlinks, lcc, kEmpty, x.nbrs);   // :525-531
+        if (*x.sc.status) return;
+        std_clone(x.t, x.nbrs, x.sc.status);                          // :532 connect_neighbors (:759-774)
+        while (x.t.n) { const StdPair n = std_pop(x.t); std_add_neighbor(x, query, lcc, n.id); std_add_neighbor(x, n.id, lcc, query); }
+        for (uint32_t i = 0; i < x.nbrs.n; ++i) std_touch(x, x.nbrs.a[i].id);   // :535-537
+        const uint32_t ep_next = x.res.a[0].id;                       // :576 w.peek() (res is not touched below)
+        while (x.nbrs.n) {                                            // :540
+            const StdPair e = std_pop(x.nbrs);
+            x.econn.n = 0; x.econn.reverse = 0;                       // :544-558
+            uint32_t cnt;
+            const uint32_t *er = std_row(x, e.id, lcc, cnt);
+            const float *ev = std_vec(x, e.id);
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const StdPair p = {std_sim(ev, std_vec(x, er[i]), x.g.dim), er[i]};   // :550
+                x.n_dist += 1; x.n_ids += 1;
+                std_push(x.econn, p, x.sc.status);
+            }
+            const uint32_t m_max = lcc == 0 ? 2 * mlinks : mlinks;    // :560
+            if (x.econn.n > m_max) {                                  // :561
+                std_select_neighbors(x, e.id, x.econn, m_max, lcc, kEmpty, x.enew);   // :568
+                if (*x.sc.status) return;
+                std_update_node_connections(x, e.id, x.enew, x.econn, lcc, kEmpty);  // :569
+            }
+            if (*x.sc.status) return;
+        }
+        ep = ep_next;
+    }
+    if (l > l_max) { x.g.hdr->max_layer = l; x.g.hdr->enterpoint = (int32_t)query; }   // :587-593
+    x.g.hdr->node_count = query + 1;
+}
+
+// HNSW.NODE.ADD in the reference binary's tie order: one lane of one wavefront
+__global__ void k_insert_std_heap(GraphView g, StdScratch sc, uint32_t id, uint32_t mlinks, uint32_t ef, uint32_t *touched, uint32_t touched_cap)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    StdCtx x;
+    std_ctx_init(x, g, sc);
+    x.touched = touched; x.touched_cap = touched_cap;
+    std_insert(x, id, mlinks, ef);
+    *sc.epoch = x.epoch;
+    if (touched) g.hdr->n_touched = x.nt;
+    atomicAdd(&g.hdr->ctr_insert[0], x.n_dist);
+    atomicAdd(&g.hdr->ctr_insert[1], x.n_ids);
+    atomicAdd(&g.hdr->ctr_insert[2], x.n_expand);
+}
+
+// HNSW.SEARCH (core.rs:477-486, 865-892) in the reference binary's tie order for the queries listed in `which`: one lane
+// per query, each with a scratch of its own
+__global__ void k_search_std_heap(GraphView g, const StdScratch *scs, const float *Q, const uint32_t *which, uint32_t n_which, uint32_t k, uint32_t ef,
+                                  uint32_t *out_ids, float *out_sims, uint32_t *out_n)
+{
+    if (threadIdx.x != 0 || blockIdx.x >= n_which) return;
+    const uint32_t qi = which[blockIdx.x];
+    StdCtx x;
+    std_ctx_init(x, g, scs[blockIdx.x]);
+    const float *q = Q + (size_t)qi * g.dim;
+    uint32_t ep = (uint32_t)g.hdr->enterpoint, lc = g.hdr->max_layer;
+    while (lc > 0) {                                                  // :869-874
+        std_search_level(x, q, ep, 1, lc);
+        ep = x.res.a[0].id;                                           // :872 peek
+        lc--;
+    }
+    std_search_level(x, q, ep, ef, 0);                                // :876
+    uint32_t n = 0;
+    while (n < k && x.res.n) {                                        // :878-890
+        const StdPair p = std_pop(x.res);
+        out_ids[(size_t)qi * k + n] = p.id;
+        out_sims[(size_t)qi * k + n] = p.sim;
+        n++;
+    }
+    for (uint32_t i = n; i < k; ++i) { out_ids[(size_t)qi * k + i] = kEmpty; out_sims[(size_t)qi * k + i] = -__builtin_inff(); }
+    out_n[qi] = n;
+    *x.sc.epoch = x.epoch;
+}
+
+} // namespace hnsw

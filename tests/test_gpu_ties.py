@@ -151,3 +151,31 @@ def test_a_search_without_a_census_kernel_reads_as_unknown(eng, oracle_mod):
     assert gi.tie_counters()["search_events"] == 0
     gi.close()
     o.close()
+
+
+@pytest.mark.parametrize("kind,n,dim,m,ef", [("binary", 1200, 128, 8, 48), ("binary", 700, 32, 5, 16), ("lattice", 900, 20, 6, 24),
+                                             ("uniform", 800, 128, 16, 64)])
+def test_the_std_heap_kernel_builds_what_the_std_heap_oracle_builds(eng, oracle_mod, kind, n, dim, m, ef):
+    """tie_mode = 2: EVERY insert runs on the one-lane kernel that restates the reference's insert() on std's BinaryHeap
+    (hnsw_std_heap.hpp) -- against hnsw_oracle_add_std_heap, which is pinned to the transcription's "rust"-mode golden.  Tie-
+    heavy data (binary / lattice vectors: equal similarities at every turn, both metric orders), so the heap's sift order
+    decides nearly every insert; rows must match in stored order."""
+    rng = np.random.default_rng(77)
+    if kind == "binary":
+        V = np.unique(rng.integers(0, 2, size=(n + 200, dim)).astype(np.float32), axis=0)[:n]
+        rng.shuffle(V)
+    elif kind == "lattice":
+        V = rng.integers(0, 3, size=(n, dim)).astype(np.float32)            # duplicates included
+    else:
+        V = make_data(n, dim, seed=78)
+    n = len(V)
+    lv = oracle_mod.draw_levels(n, m, 8)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch_std_heap(V, lv)
+    gi = eng.Index("std", dim, m, ef)
+    gi.set_tuning("tie_mode", 2)
+    gi.add_batch(V, levels=lv, mode="exact")
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    gi.close()
+    o.close()
