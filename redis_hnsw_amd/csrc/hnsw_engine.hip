@@ -1087,6 +1087,14 @@ hnsw_status hnsw_debug_occ_par2(hnsw_index *h, uint64_t *out4)
     return HNSW_OK;
 }
 
+// inserts of windowed builds that tie_mode 1 handed to the std-order kernel since the handle was created (development aid)
+hnsw_status hnsw_debug_tie_redone(hnsw_index *h, uint64_t *out)
+{
+    if (!h || !out) return HNSW_ERR_INVALID;
+    *out = h->tie_redone;
+    return HNSW_OK;
+}
+
 // recomputed shrinks of the last windowed build by cause (development aid; not in the public header)
 hnsw_status hnsw_debug_occ_causes(hnsw_index *h, uint64_t *out8)
 {

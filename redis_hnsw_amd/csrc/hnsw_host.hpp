@@ -150,6 +150,7 @@ struct hnsw_index {
     // tuning "tie_mode": 0 off; 1 an insert / a query the tie census flags is redone in the reference binary's own tie order
     // (hnsw_std_heap.hpp: one lane, std's BinaryHeap restated); 2 EVERY insert and query runs there (tests: the port itself)
     int tie_mode = 0;
+    uint64_t tie_redone = 0;         // inserts of windowed builds handed to the std-order kernel (hnsw_debug_tie_redone)
     void *d_std_stamp = nullptr, *d_std_heaps = nullptr, *d_std_ctx = nullptr, *d_std_misc = nullptr;
     uint32_t std_cap = 0, std_hcap = 0;
     struct { void *stamp, *epoch, *heaps; uint32_t hcap; void *status; } std_ctx0 = {};   // (layout of hnsw::StdScratch: checked where it is used)

@@ -38,6 +38,7 @@ constexpr uint32_t kOccMaxHits = 1024;      // (reader, z) pairs whose distance 
 struct OccShr {
     uint32_t lc, e, nS, bound;              // bound = distance bits of the last selected; nS = 0: not computed yet
     uint32_t log0, cnt, w_dist, w_ids;      // its read-log range starts at log0: 1 + cnt + 1 entries (row e, its members, this node); w_*: evaluations / ids scanned computing it
+    uint32_t tie, pad0, pad1, pad2;         // tie census: computing it met equal distances (a cut, or an order inside the selection)
     uint32_t S[kSelMax];                    // selected ids, nearest first (up to m_max0 = 2M)
 };
 struct OccSlot {
@@ -49,6 +50,7 @@ struct OccSlot {
     // searches.  The reads of layers >= 1 date from snapU, those of layer 0 (and the speculative records) from snap:
     // occ_check_range ignores layer-0 deltas older than snap.
     uint32_t stage, snapU, ep_l0, n_reads_u;
+    uint32_t tie, pad0, pad1, pad2;         // tie census of the stages planned so far (tie gate: OccCtl::tie_gate)
 };
 enum { OCC_WHY_ROW = 1, OCC_WHY_OPEN = 2, OCC_WHY_ADD = 4, OCC_WHY_REMOVE = 8 };   // why a speculative shrink is stale (flags[2 + sub]; the first cause met, later entries are not looked at)
 enum { OCC_STOP_NONE = 0, OCC_STOP_REPLAN = 1, OCC_STOP_RESTRIDE = 2, OCC_STOP_SERIAL = 3 };
@@ -65,6 +67,7 @@ struct OccCtl {
     unsigned long long n_groups, n_dry, n_conf_link, n_conf_rec, n_conf_row;   // groups committed, dry runs made, groups closed by: a stale link plan / a record used / a changed row
     unsigned long long n_early;             // rounds that ended right after a group: the next head was known not to be able to commit
     unsigned long long dry_prof[8];         // all workgroups' dry runs, 100 MHz ticks: hash + journal check, connect, record checks, row load + spec apply, recompute, update_connections, finish; [7] = sum over iterations of the slowest dry run
+    uint32_t tie_gate, pad_tg;              // tuning tie_mode 1: a node whose plan or commit met a tie (the census) is handed to the host untouched (OCC_STOP_SERIAL: the std-order kernel)
     uint32_t end_node, rounds;              // rounds enqueued ahead of the host (occ_round_window): where the chunk ends; commit launches that ran
     unsigned long long par_prof[8];         // k_occ_commit_par, workgroup 0, 100 MHz ticks: dry run, wait, validate, wait, apply, wait; [6] iterations, [7] launches
 };
@@ -267,7 +270,6 @@ __device__ __forceinline__ void occ_plan_finish(const GraphView &g, const OccBuf
                                                 WorkCtr &ctr, uint32_t id, uint32_t top, uint32_t mlinks, uint32_t log_cap,
                                                 uint32_t snap, uint32_t epoch, bool fail, Visited &vis, int lane, uint32_t snapU = kEmpty)
 {
-    (void)ob;
     // ---- the shrinks the connect will trigger (core.rs:560-561): listed here, computed speculatively by
     // k_occ_shrinks, one wave each ----
     uint32_t n_shr = 0;
@@ -304,6 +306,7 @@ __device__ __forceinline__ void occ_plan_finish(const GraphView &g, const OccBuf
         n_shr += (uint32_t)__popcll(nm);
     }
     if (ctr.log_n > log_cap) fail = true;           // (log_cap < kOccMaxReads only in tests: forces the serial path)
+    if (ob.ctl->tie_gate && (ctr.n_tie || (sl->node == id && sl->stage == 1u && sl->tie))) fail = true;   // the census flagged this plan: not for the window
     if (vis.glob_dirty) visited_clear(vis, lane);
     __threadfence();
     if (lane == 0) {
@@ -478,6 +481,7 @@ __global__ __launch_bounds__(64, 1) void k_occ_shrinks(GraphView g, OccBufs ob, 
     }
     if (lane == 0) { sp->w_dist = nolog.n_dist; sp->w_ids = nolog.n_ids; }
     if (lane == 0 && nolog.n_tie) atomicAdd(&g.hdr->ctr_tie[2], (unsigned long long)nolog.n_tie);   // tie census: a cut between equal distances
+    if (lane == 0) sp->tie = nolog.n_tie ? 1u : 0u;
     const uint32_t bound = (uint32_t)(m.S[nS - 1] >> 32);
     for (uint32_t i = lane; i < nS; i += 64) sp->S[i] = key_id(m.S[i]);
     // reads: row e itself, and the rows of econn's members

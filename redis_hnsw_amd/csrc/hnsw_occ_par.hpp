@@ -315,6 +315,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g
                     jr.cap = kParMaxDelta;
                     uint32_t checked = 0;                    // own deltas already checked against the records
                     uint64_t done_rec = 0;                   // speculative records this dry run has already consumed
+                    uint32_t n_tie_used = 0;
                     uint32_t nsub = n_shr;                   // the next recomputation's sub-operation
                     bool fail = false, overflow = false;
                     uint32_t nt = 0;
@@ -379,6 +380,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g
                                 n_spec += 1;
                                 w_dist += shr[k].w_dist;
                                 w_ids += shr[k].w_ids;
+                                n_tie_used += shr[k].tie;            // (tie gate: a record whose selection met a tie)
                                 live |= 1ull << k;
                                 DRY_T(3);
                             } else {
@@ -429,7 +431,10 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g
                     }
                     if (vis.glob_dirty) visited_clear(vis, lane);
                     wave_sync_full();
-                    if (fail || overflow || ov.ovctl[1] || jr.n > kParMaxDelta || n_hash + ov.ovctl[0] > kOccMaxReads) state = PAR_SERIAL;
+                    // tie gate (tuning tie_mode 1): a commit whose selections met a tie is not applied: the host redoes the insert in
+                    // the reference binary's own tie order (hnsw_std_heap.hpp)
+                    const bool tied = ob.ctl->tie_gate && (n_tie || n_tie_used);
+                    if (fail || overflow || tied || ov.ovctl[1] || jr.n > kParMaxDelta || n_hash + ov.ovctl[0] > kOccMaxReads) state = PAR_SERIAL;
                     else {
                         // the rows this dry run rewrote join what it "read": any delta of an earlier node on one of them is a conflict
                         const uint32_t meta = occ_meta(0, OCC_SHRINK_ROW, kParSubRows, true);

@@ -275,6 +275,7 @@ __global__ __launch_bounds__(DUO ? 128 : 64, 1) void k_occ_plan_lean(GraphView g
         if (lane == 0) {
             sl->node = id; sl->planned = 0u; sl->epoch = epoch; sl->fail = 0u;
             sl->snapU = snap; sl->ep_l0 = ep; sl->n_reads_u = ctr.log_n; sl->top = top;
+            sl->tie = ctr.n_tie ? 1u : 0u;
             sl->stage = 1u;
             atomicAdd(&g.hdr->ctr_insert[0], (unsigned long long)ctr.n_dist);
             atomicAdd(&g.hdr->ctr_insert[1], (unsigned long long)ctr.n_ids);

@@ -42,13 +42,16 @@ static hnsw_status occ_round_t(hnsw_index *h, const InsertCfg &c, const OccBufs 
     hipLaunchKernelGGL(ks, dim3(count * kOccInsShr), dim3(64), c.lds, h->stream, gv, ob, head, count, h->m, c.lnb, c.lcap, h->d_spill,
                        h->spill_gnb, kEmpty, kOccInsShr);
     bool team = false;
-    if (count > 1 && !h->occ_want_touched && (h->commit_par == 2 || (h->commit_par == 1 && h->occ_yield * 10.0 >= (double)h->commit_par_min_x10))) {
+    // (tie_mode 1: always -- a dry run can be thrown away when its selections meet a tie, an in-order commit cannot)
+    if (count > 1 && !h->occ_want_touched && (h->commit_par == 2 || h->tie_mode == 1 || (h->commit_par == 1 && h->occ_yield * 10.0 >= (double)h->commit_par_min_x10))) {
         // the window's commits in validated parallel groups, one workgroup per window node (hnsw_occ_par.hpp)
         HIP_TRY(h, hipGetLastError());
         // (the commit's grid is the FRONT; the plans above cover the whole depth of the window, add_exact_window)
         hnsw_status ps = occ_commit_par_r<MODE, T>(h, c, ob, h->occ_front ? std::min(h->occ_front, count) : count, end_node, &team);
         if (ps != HNSW_OK) return ps;
     }
+    if (!team && h->tie_mode == 1 && count > 1)
+        return fail(h, HNSW_ERR_INVALID, "tie_mode 1 needs the group commit kernel (ef_construction <= 1024, ids < 2^27, a device that holds the window's workgroups)");
     if (!team && h->commit_team) {
         HIP_TRY(h, hipGetLastError());
         hnsw_status ts = occ_commit_team_r<MODE, T>(h, c, ob, end_node, &team);

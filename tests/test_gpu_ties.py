@@ -179,3 +179,27 @@ def test_the_std_heap_kernel_builds_what_the_std_heap_oracle_builds(eng, oracle_
     assert ok, why
     gi.close()
     o.close()
+
+
+def test_tie_mode_builds_the_reference_binary_s_graph(eng, oracle_mod):
+    """tie_mode = 1 on SURVEY's model shape (20 k x 128 uniform f32, M = 16, ef = 200): the windowed reference-order build,
+    with every insert the census flags -- in its plan or in the dry run of its commit -- handed UNTOUCHED to the one-lane
+    kernel that restates insert() on std's BinaryHeap.  The result must be the graph the transcription built in its
+    "rust" tie mode (tests/golden/transcribed_20k_dim128.npz: 16 accept-test and 2 select-cut ties decided by the heap's
+    sift order, after which the total order's graph differs in 3.7 % of the layer-0 rows): every row of every layer, in
+    stored order.  Without tie_mode the engine builds the total order's graph (every other test)."""
+    import ctypes as C
+    from tests.golden_util import load_transcribed
+    c = load_transcribed("transcribed_20k_dim128")
+    assert c["stats"]["ties"] == "rust"
+    gi = eng.Index("tiemode", c["dim"], c["m"], c["ef"])
+    gi.set_tuning("tie_mode", 1)
+    gi.add_batch(c["V"], levels=c["levels"], mode="exact")
+    ok, why = graphs_equal(c["graph"], gi.export_graph())
+    assert ok, why
+    lib = eng._capi.load()
+    lib.hnsw_debug_tie_redone.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    red = C.c_uint64(0)
+    assert lib.hnsw_debug_tie_redone(gi._h, C.byref(red)) == 0
+    assert 18 <= red.value < c["n"] // 10, red.value                       # the flagged few, not the build
+    gi.close()
