@@ -494,8 +494,27 @@ uint32_t search_concurrency(hnsw_index *h, hipStream_t st)
     return std::min(n, 8u);
 }
 
+static hnsw_status launch_search_kernels(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t *d_ids,
+                                         float *d_sims, uint32_t *d_nout, hipStream_t st);
+
+// tuning tie_mode: after the search kernel, the queries its census flagged (1), or all of them (2, or a shape without a
+// census kernel), are answered again in the reference binary's own tie order (hnsw_std_heap.hpp); same stream, asynchronous
 hnsw_status launch_search(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t *d_ids,
                           float *d_sims, uint32_t *d_nout, hipStream_t st)
+{
+    if (!h->tie_mode) return launch_search_kernels(h, dQ, B, k, d_ids, d_sims, d_nout, st);
+    hnsw_status s = ensure_tie_flags(h, B);
+    if (s != HNSW_OK) return s;
+    const bool was = h->tie_uncounted;
+    h->tie_uncounted = false;
+    if ((s = launch_search_kernels(h, dQ, B, k, d_ids, d_sims, d_nout, st)) != HNSW_OK) return s;
+    const bool all = h->tie_mode == 2 || h->tie_uncounted;
+    h->tie_uncounted = h->tie_uncounted || was;
+    return launch_search_std(h, dQ, B, k, d_ids, d_sims, d_nout, all, st);
+}
+
+static hnsw_status launch_search_kernels(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t *d_ids,
+                                         float *d_sims, uint32_t *d_nout, hipStream_t st)
 {
     hnsw_status s = ensure_spill(h);
     if (s != HNSW_OK) return s;

@@ -150,6 +150,10 @@ struct hnsw_index {
     // tuning "tie_mode": 0 off; 1 an insert / a query the tie census flags is redone in the reference binary's own tie order
     // (hnsw_std_heap.hpp: one lane, std's BinaryHeap restated); 2 EVERY insert and query runs there (tests: the port itself)
     int tie_mode = 0;
+    uint32_t *d_tie_flags = nullptr;  // [cap] per-query flags of the census kernel, then [4] a count, then [cap] the flagged queries
+    uint32_t tie_flags_cap = 0;
+    hipEvent_t std_ev = nullptr;     // the last std-order search launch (they share scratch contexts)
+    bool std_ev_valid = false;
     uint64_t tie_redone = 0;         // inserts of windowed builds handed to the std-order kernel (hnsw_debug_tie_redone)
     void *d_std_stamp = nullptr, *d_std_heaps = nullptr, *d_std_ctx = nullptr, *d_std_misc = nullptr;
     uint32_t std_cap = 0, std_hcap = 0;
@@ -323,8 +327,9 @@ size_t plan_lean_lds(int R);
 hnsw_status launch_occ_plan_lean(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t head, uint32_t count, bool *done);
 // hnsw_tu_std.hip: the reference binary's own tie order on one lane (tuning "tie_mode")
 hnsw_status launch_insert_std(hnsw_index *h, uint32_t id, bool want_touched);
-hnsw_status launch_search_std(hnsw_index *h, const float *dQ, const uint32_t *d_which, uint32_t n, uint32_t k, uint32_t *d_ids, float *d_sims,
-                              uint32_t *d_nout, hipStream_t st);
+hnsw_status launch_search_std(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t *d_ids, float *d_sims, uint32_t *d_nout, bool all,
+                              hipStream_t st);
+hnsw_status ensure_tie_flags(hnsw_index *h, uint32_t B);
 hnsw_status std_status(hnsw_index *h, uint32_t *out);
 // hnsw_tu_occ.hip
 template <int MODE, int T>

@@ -515,8 +515,9 @@ template <class VEC, int R, int BB, int DB, bool WIDE, bool TIES = false>
 __global__ __launch_bounds__(64, VEC::MIN_WAVES) void k_search_lean(GraphView g, const float *__restrict__ Q, uint32_t B, uint32_t k,
                                                     uint32_t ef, uint32_t lcap, uint32_t idbits,
                                                     uint32_t *__restrict__ out_ids, float *__restrict__ out_sims,
-                                                    uint32_t *__restrict__ out_n)
+                                                    uint32_t *__restrict__ out_n, uint32_t *__restrict__ tie_flags = nullptr)
 {
+    // tie_flags (TIES kernels, tuning tie_mode): [B] 1 = this query met a tie (it is answered again in std's heap order)
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
     uint64_t *Wbuf = reinterpret_cast<uint64_t *>(smem);                       // [LeanW<R>::kSlots]
@@ -550,6 +551,7 @@ __global__ __launch_bounds__(64, VEC::MIN_WAVES) void k_search_lean(GraphView g,
                 ctr.n_tie += (uint32_t)__popcll(__ballot(in && (uint32_t)(Wbuf[in ? i : 0u] >> 32) == (uint32_t)(Wbuf[in ? i + 1u : 0u] >> 32)));
             }
             if (lane == 0 && ctr.n_tie != tie0) atomicAdd(&g.hdr->ctr_tie[1], 1ull);
+            if (lane == 0 && tie_flags) tie_flags[qi] = ctr.n_tie != tie0 ? 1u : 0u;
         }
         for (uint32_t i = lane; i < k; i += 64) {
             const uint64_t key = i < nres ? Wbuf[i] : 0;

@@ -334,32 +334,42 @@ __global__ void k_insert_std_heap(GraphView g, StdScratch sc, uint32_t id, uint3
     atomicAdd(&g.hdr->ctr_insert[2], x.n_expand);
 }
 
-// HNSW.SEARCH (core.rs:477-486, 865-892) in the reference binary's tie order for the queries listed in `which`: one lane
-// per query, each with a scratch of its own
-__global__ void k_search_std_heap(GraphView g, const StdScratch *scs, const float *Q, const uint32_t *which, uint32_t n_which, uint32_t k, uint32_t ef,
-                                  uint32_t *out_ids, float *out_sims, uint32_t *out_n)
+// which[0 .. *count) = the queries whose tie flag is set (all = 1: every query of the batch); any order
+__global__ void k_tie_compact(const uint32_t *flags, uint32_t B, uint32_t *which, uint32_t *count, uint32_t all)
 {
-    if (threadIdx.x != 0 || blockIdx.x >= n_which) return;
-    const uint32_t qi = which[blockIdx.x];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B && (all || flags[i])) which[atomicAdd(count, 1u)] = i;
+}
+
+// HNSW.SEARCH (core.rs:477-486, 865-892) in the reference binary's tie order for the queries which[0 .. *n_which): one lane
+// per query; block b serves entries b, b + gridDim.x, ... with scratch context b
+__global__ void k_search_std_heap(GraphView g, const StdScratch *scs, const float *Q, const uint32_t *which, const uint32_t *n_which, uint32_t k,
+                                  uint32_t ef, uint32_t *out_ids, float *out_sims, uint32_t *out_n)
+{
+    if (threadIdx.x != 0) return;
+    const uint32_t n = *n_which;
     StdCtx x;
     std_ctx_init(x, g, scs[blockIdx.x]);
-    const float *q = Q + (size_t)qi * g.dim;
-    uint32_t ep = (uint32_t)g.hdr->enterpoint, lc = g.hdr->max_layer;
-    while (lc > 0) {                                                  // :869-874
-        std_search_level(x, q, ep, 1, lc);
-        ep = x.res.a[0].id;                                           // :872 peek
-        lc--;
+    for (uint32_t w = blockIdx.x; w < n; w += gridDim.x) {
+        const uint32_t qi = which[w];
+        const float *q = Q + (size_t)qi * g.dim;
+        uint32_t ep = (uint32_t)g.hdr->enterpoint, lc = g.hdr->max_layer;
+        while (lc > 0) {                                              // :869-874
+            std_search_level(x, q, ep, 1, lc);
+            ep = x.res.a[0].id;                                       // :872 peek
+            lc--;
+        }
+        std_search_level(x, q, ep, ef, 0);                            // :876
+        uint32_t m = 0;
+        while (m < k && x.res.n) {                                    // :878-890
+            const StdPair p = std_pop(x.res);
+            out_ids[(size_t)qi * k + m] = p.id;
+            out_sims[(size_t)qi * k + m] = p.sim;
+            m++;
+        }
+        for (uint32_t i = m; i < k; ++i) { out_ids[(size_t)qi * k + i] = kEmpty; out_sims[(size_t)qi * k + i] = -__builtin_inff(); }
+        out_n[qi] = m;
     }
-    std_search_level(x, q, ep, ef, 0);                                // :876
-    uint32_t n = 0;
-    while (n < k && x.res.n) {                                        // :878-890
-        const StdPair p = std_pop(x.res);
-        out_ids[(size_t)qi * k + n] = p.id;
-        out_sims[(size_t)qi * k + n] = p.sim;
-        n++;
-    }
-    for (uint32_t i = n; i < k; ++i) { out_ids[(size_t)qi * k + i] = kEmpty; out_sims[(size_t)qi * k + i] = -__builtin_inff(); }
-    out_n[qi] = n;
     *x.sc.epoch = x.epoch;
 }
 

@@ -24,7 +24,7 @@ static hnsw_status launch_lean_t(hnsw_index *h, const float *dQ, uint32_t B, uin
     if (h->grid_override > 0) grid = std::min<uint32_t>(grid, (uint32_t)h->grid_override);
     if (h->time_launches) HIP_TRY(h, hipEventRecord(h->ev0, st));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, st, view(h), dQ, B, k, h->efc, (1u << BB) * 6u, idbits, d_ids, d_sims,
-                       d_nout);
+                       d_nout, TIES && h->tie_mode == 1 ? h->d_tie_flags : (uint32_t *)nullptr);
     HIP_TRY(h, hipGetLastError());
     if (h->time_launches) {
         HIP_TRY(h, hipEventRecord(h->ev1, st));

@@ -60,18 +60,37 @@ hnsw_status launch_insert_std(hnsw_index *h, uint32_t id, bool want_touched)
     return HNSW_OK;
 }
 
-// the queries which[0 .. n) of the device batch dQ, results written over d_ids / d_sims / d_nout; on stream st
-hnsw_status launch_search_std(hnsw_index *h, const float *dQ, const uint32_t *d_which, uint32_t n, uint32_t k, uint32_t *d_ids, float *d_sims,
-                              uint32_t *d_nout, hipStream_t st)
+// tie_mode after a search launch on `st`: the queries whose tie flag the census kernel set (all = every query: tie_mode 2, or
+// a shape without a census kernel) are answered again in the reference binary's own tie order, results written over
+// d_ids / d_sims / d_nout.  Asynchronous on `st`; launches of this kind share the scratch contexts and are chained by an event.
+hnsw_status launch_search_std(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t *d_ids, float *d_sims, uint32_t *d_nout, bool all,
+                              hipStream_t st)
 {
     hnsw_status s = ensure_std_scratch(h);
     if (s != HNSW_OK) return s;
+    if (!h->std_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->std_ev, hipEventDisableTiming));
+    if (h->std_ev_valid) HIP_TRY(h, hipStreamWaitEvent(st, h->std_ev, 0));
+    uint32_t *count = h->d_tie_flags + h->tie_flags_cap, *which = h->d_tie_flags + h->tie_flags_cap + 4;
+    HIP_TRY(h, hipMemsetAsync(count, 0, 4, st));
+    hipLaunchKernelGGL(k_tie_compact, dim3((B + 255) / 256), dim3(256), 0, st, h->d_tie_flags, B, which, count, all ? 1u : 0u);
     const StdScratch *ctx = reinterpret_cast<const StdScratch *>(h->d_std_ctx) + 1;
-    for (uint32_t done = 0; done < n; done += kStdSearchCtx) {
-        const uint32_t c = std::min(kStdSearchCtx, n - done);
-        hipLaunchKernelGGL(k_search_std_heap, dim3(c), dim3(64), 0, st, view(h), ctx, dQ, d_which + done, c, k, h->efc, d_ids, d_sims, d_nout);
-    }
+    hipLaunchKernelGGL(k_search_std_heap, dim3(kStdSearchCtx), dim3(64), 0, st, view(h), ctx, dQ, which, count, k, h->efc, d_ids, d_sims, d_nout);
     HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->std_ev, st));
+    h->std_ev_valid = true;
+    return HNSW_OK;
+}
+
+// per-query tie flags of a search launch (written by the census kernel), then the count and the list of flagged queries
+hnsw_status ensure_tie_flags(hnsw_index *h, uint32_t B)
+{
+    if (h->d_tie_flags && h->tie_flags_cap >= B) return HNSW_OK;
+    HIP_TRY(h, hipDeviceSynchronize());
+    (void)hipFree(h->d_tie_flags);
+    h->d_tie_flags = nullptr;
+    const uint32_t cap = std::max(B, 1024u);
+    HIP_TRY(h, hipMalloc((void **)&h->d_tie_flags, ((size_t)2 * cap + 4) * 4));
+    h->tie_flags_cap = cap;
     return HNSW_OK;
 }
 

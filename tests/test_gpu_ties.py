@@ -203,3 +203,52 @@ def test_tie_mode_builds_the_reference_binary_s_graph(eng, oracle_mod):
     assert lib.hnsw_debug_tie_redone(gi._h, C.byref(red)) == 0
     assert 18 <= red.value < c["n"] // 10, red.value                       # the flagged few, not the build
     gi.close()
+
+
+@pytest.mark.parametrize("kind,n,dim,m,ef,mode", [("binary", 3000, 128, 16, 40, 1), ("binary", 3000, 128, 16, 200, 1), ("binary", 3000, 128, 16, 40, 2),
+                                                  ("lattice", 1500, 64, 8, 32, 1), ("uniform", 6000, 128, 16, 200, 1)])
+def test_tie_mode_answers_queries_as_the_reference_binary_does(eng, oracle_mod, kind, n, dim, m, ef, mode):
+    """tie_mode on HNSW.SEARCH: the queries the census kernel flags (mode 1), or all of them (mode 2, and mode 1 on a shape
+    without a census kernel -- dim 64 here), are answered again by the one-lane kernel that restates search_knn / search_level
+    on std's BinaryHeap: ids in the reference's pop order and similarities bit for bit against hnsw_oracle_search_std_heap,
+    on a graph built in std order too.  On binary / lattice data nearly every query ties somewhere."""
+    rng = np.random.default_rng(91)
+    if kind == "binary":
+        V = np.unique(rng.integers(0, 2, size=(n + 200, dim)).astype(np.float32), axis=0)[:n]
+        rng.shuffle(V)
+        Q = rng.integers(0, 2, size=(160, dim)).astype(np.float32)
+    elif kind == "lattice":
+        V = rng.integers(0, 3, size=(n, dim)).astype(np.float32)
+        Q = rng.integers(0, 3, size=(160, dim)).astype(np.float32)
+    else:
+        V = make_data(n, dim, seed=92)
+        Q = make_data(512, dim, seed=93)
+    n, k = len(V), 10
+    lv = oracle_mod.draw_levels(n, m, 8)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch_std_heap(V, lv)
+    gi = eng.Index("stdq", dim, m, ef)
+    gi.import_graph(o.export())
+    gi.set_tuning("tie_mode", mode)
+    gi.reset_counters()
+    ids, sims, n_out = gi.search_batch(Q, k)
+    differs_from_total_order = 0
+    for i, q in enumerate(Q):
+        oids, osims = o.search_std_heap(q, k)
+        assert n_out[i] == len(oids)
+        assert np.array_equal(ids[i, :len(oids)], oids), (i, ids[i], oids)
+        assert np.array_equal(sims[i, :len(oids)].view(np.uint32), np.asarray(osims, dtype=np.float32).view(np.uint32))
+        tids, _ = o.search(q, k)
+        differs_from_total_order += not np.array_equal(tids, oids)
+    if kind != "uniform":
+        assert differs_from_total_order > 0                                 # the mode had something to decide
+    t = gi.tie_counters()
+    if mode == 1 and dim == 128:
+        assert t["queries_with_tie"] is not None
+        if kind == "uniform":
+            assert t["queries_with_tie"] <= len(Q) // 16                    # the flagged few, not the batch
+    # a second batch through the asynchronous device entry and the pipelined host entry gives the same answers
+    ids2, sims2, n2 = gi.search_batch(Q[:64], k)
+    assert np.array_equal(ids2, ids[:64]) and np.array_equal(n2, n_out[:64])
+    gi.close()
+    o.close()
