@@ -699,9 +699,29 @@ class Bench:
                                       "core.rs:635, accept test :657, or equal distances among the k + 1 nearest): only those can be "
                                       "answered differently by the reference's binary; counted by the kernel itself, a superset of the "
                                       "oracle's per-decision census")
+            # tuning tie_mode = 1: the flagged queries answered again in the reference binary's own heap order (one lane each,
+            # hnsw_std_heap.hpp); what that costs a batch and how many answers it changes -- untimed elsewhere, off by default
+            import time as _t
+            s.search_now(s.myQ[:s.B], s.B)
+            ids_total = s.d_ids.cpu().numpy().copy()
+            s.index.set_tuning("tie_mode", 1)
+            s.search_now(s.myQ[:s.B], s.B)                                 # (allocates the std-order scratch)
+            t0 = _t.perf_counter()
+            s.search_now(s.myQ[:s.B], s.B)
+            t_mode = _t.perf_counter() - t0
+            ids_std = s.d_ids.cpu().numpy().copy()
+            s.index.set_tuning("tie_mode", 0)
+            t0 = _t.perf_counter()
+            s.search_now(s.myQ[:s.B], s.B)
+            t_census = _t.perf_counter() - t0
+            s.engine_ties["tie_mode"] = dict(batch=s.B, ms_per_batch=round(t_mode * 1e3, 2), ms_per_batch_census_only=round(t_census * 1e3, 2),
+                                             answers_changed=int((ids_total != ids_std).any(axis=1).sum()),
+                                             note="one lone batch with tuning tie_mode = 1: the flagged queries are answered again as the "
+                                                  "Rust binary would (std BinaryHeap order, one lane per query)")
         except Exception as e:                                            # a shape without a census kernel
             s.engine_ties = dict(queries=0, note="not counted: %s" % e)
         finally:
+            s.index.set_tuning("tie_mode", 0)
             s.index.set_tuning("tie_census", 0)
             s.index.reset_counters()
 

@@ -30,6 +30,7 @@ constexpr uint32_t ST_VISITED_OVERFLOW = 1u; // spill table full
 constexpr uint32_t ST_ROW_OVERFLOW = 2u;     // adjacency row full (engine bug: host re-strides first)
 constexpr uint32_t ST_ROW_DROPPED = 4u;      // fast build dropped a reverse link
 constexpr uint32_t ST_ASYMMETRIC = 8u;       // rm of a non-neighbour (reference would panic, core.rs:150)
+constexpr uint32_t ST_STD_OVERFLOW = 16u;    // tie_mode: a heap of the std-order search kernel overflowed (answers of that call void)
 
 struct DevHeader {
     uint32_t node_count;

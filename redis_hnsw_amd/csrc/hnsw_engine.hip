@@ -572,8 +572,9 @@ hnsw_status check_dev_status(hnsw_index *h, const DevHeader &hd)
 {
     if (hd.status == 0) return HNSW_OK;
     HIP_TRY(h, hipMemsetAsync((char *)h->d_hdr + offsetof(DevHeader, status), 0, sizeof(uint32_t), h->stream));
-    char buf[160];
-    snprintf(buf, sizeof buf, "device status 0x%x:%s%s%s%s", hd.status,
+    char buf[200];
+    snprintf(buf, sizeof buf, "device status 0x%x:%s%s%s%s%s", hd.status,
+             (hd.status & ST_STD_OVERFLOW) ? " std-order search heap overflow" : "",
              (hd.status & ST_VISITED_OVERFLOW) ? " visited-set overflow" : "",
              (hd.status & ST_ROW_OVERFLOW) ? " adjacency row overflow" : "",
              (hd.status & ST_ROW_DROPPED) ? " reverse link dropped" : "",

@@ -4,11 +4,11 @@
 // std::collections::BinaryHeap: which of two EQUAL similarities pops, is evicted or is linked first is decided by that
 // heap's sift procedures.  The engine's kernels use the total order (distance, id) instead -- a whole adjacency row merged
 // at once needs one -- and count every place where the two can part (hnsw_get_tie_counters; proven sufficient on the CPU:
-// tests/test_golden_cpu.py).  With tie_mode on, an insert / a query the census flags is REDONE here, on one lane, as the
+// tests/test_golden_cpu.py).  With tie_mode on, an insert / a query the census flags is REDONE here, one step at a time, as the
 // reference executes it: insert() / search_level() / select_neighbors() / connect_neighbors() / update_node_connections()
 // of core.rs:489-822 statement by statement on a restatement of std's heap (push = sift_up; pop = swap the last element
 // into the root, sift_down_to_bottom towards the greater child -- the right one when equal -- then sift_up; clone /
-// into_vec / into_iter = the array as it is).  Slow by construction (one lane, heaps in HBM: ~10-50 ms per insert) and
+// into_vec / into_iter = the array as it is).  Slow by construction (one wavefront whose lanes share only the distance, heaps in HBM) and
 // rare (1-2.5 % of the inserts on uniform f32 data); the result is what the Rust binary links, row for row
 // (tests/test_gpu_ties.py against the transcription's "rust"-mode golden).
 #pragma once
@@ -74,31 +74,40 @@ __device__ inline void std_clone(StdHeap &dst, const StdHeap &src, uint32_t *sta
     dst.n = src.n; dst.reverse = src.reverse;
 }
 
-// metrics.rs:14-84 on one lane, bit for bit: the AVX2 order (4 accumulators x 8 lanes, one FMA per 32-block, then
-// (e1+e2)+(e3+e4), low128+high128, (s0+s1)+(s2+s3)) iff dim % 32 == 0, else the scalar left fold
+// All 64 lanes of the wavefront run the operation in lockstep with the same values (nothing but std_sim depends on the lane:
+// every load, store and branch is uniform, a store writes the same word 64 times over); std_sim is the one place where the
+// lanes share work.  metrics.rs:14-84 bit for bit: the AVX2 order iff dim % 32 == 0 -- lane s < 32 is accumulator s / 8, SIMD
+// lane s % 8 (one FMA per 32-block), then (e1+e2)+(e3+e4), low128+high128, (s0+s1)+(s2+s3) as butterfly steps (additions
+// commute, so every lane ends with the same bits) -- else the scalar left fold: squares side by side, the additions one by one.
 __device__ inline float std_sim(const float *a, const float *b, uint32_t dim)
 {
+    const uint32_t lane = threadIdx.x & 63u;
+    float r;
     if (dim % 32u == 0u) {
-        float e[4][8];
-        for (int acc = 0; acc < 4; ++acc)
-            for (int j = 0; j < 8; ++j) e[acc][j] = 0.f;
-        for (uint32_t i = 0; i + 32 <= dim; i += 32)
-            for (int acc = 0; acc < 4; ++acc)
-                for (int j = 0; j < 8; ++j) {
-                    const float d = __fsub_rn(a[i + 8 * acc + j], b[i + 8 * acc + j]);
-                    e[acc][j] = __fmaf_rn(d, d, e[acc][j]);
-                }
-        float v[8], s[4];
-        for (int j = 0; j < 8; ++j) v[j] = __fadd_rn(__fadd_rn(e[0][j], e[1][j]), __fadd_rn(e[2][j], e[3][j]));
-        for (int j = 0; j < 4; ++j) s[j] = __fadd_rn(v[j], v[j + 4]);
-        return -__fadd_rn(__fadd_rn(s[0], s[1]), __fadd_rn(s[2], s[3]));
+        const uint32_t s = lane & 31u;
+        float e = 0.f;
+        for (uint32_t i = 0; i < dim; i += 32) {
+            const float d = __fsub_rn(a[i + s], b[i + s]);
+            e = __fmaf_rn(d, d, e);
+        }
+        e = __fadd_rn(e, __shfl_xor(e, 8));
+        e = __fadd_rn(e, __shfl_xor(e, 16));
+        e = __fadd_rn(e, __shfl_xor(e, 4));
+        e = __fadd_rn(e, __shfl_xor(e, 1));
+        e = __fadd_rn(e, __shfl_xor(e, 2));
+        r = -e;
+    } else {
+        float acc = 0.f;
+        for (uint32_t base = 0; base < dim; base += 64) {
+            const uint32_t i = base + lane;
+            float sq = 0.f;
+            if (i < dim) { const float d = __fsub_rn(a[i], b[i]); sq = __fmul_rn(d, d); }
+            const uint32_t cnt = dim - base < 64u ? dim - base : 64u;
+            for (uint32_t j = 0; j < cnt; ++j) acc = __fadd_rn(acc, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sq), (int)j)));
+        }
+        r = -acc;
     }
-    float acc = 0.f;
-    for (uint32_t i = 0; i < dim; ++i) {
-        const float d = __fsub_rn(a[i], b[i]);
-        acc = __fadd_rn(acc, __fmul_rn(d, d));
-    }
-    return -acc;
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(r)));
 }
 
 struct StdCtx {
@@ -152,7 +161,7 @@ __device__ inline void std_add_neighbor(StdCtx &x, uint32_t id, uint32_t lc, uin
     for (uint32_t i = 0; i < cnt; ++i) if (r[1 + i] == nb) return;
     if (cnt + 1 > stride - 1) { atomicOr(&x.g.hdr->status, ST_ROW_OVERFLOW); return; }
     r[1 + cnt] = nb; r[0] = cnt + 1;
-    atomicMax(lc ? &x.g.hdr->max_degU : &x.g.hdr->max_deg0, cnt + 1);
+    if ((threadIdx.x & 63u) == 0u) atomicMax(lc ? &x.g.hdr->max_degU : &x.g.hdr->max_deg0, cnt + 1);
 }
 // core.rs:145-152 rm_neighbor: position().unwrap() then Vec::remove
 __device__ inline void std_rm_neighbor(StdCtx &x, uint32_t id, uint32_t lc, uint32_t nb)
@@ -269,7 +278,7 @@ __device__ inline void std_update_node_connections(StdCtx &x, uint32_t node, con
     }
 }
 
-// core.rs:489-599 for node `query` (vector, level and empty rows already in place); one lane
+// core.rs:489-599 for node `query` (vector, level and empty rows already in place)
 __device__ inline void std_insert(StdCtx &x, uint32_t query, uint32_t mlinks, uint32_t ef)
 {
     const uint32_t l = x.g.levels[query];
@@ -319,16 +328,18 @@ __device__ inline void std_insert(StdCtx &x, uint32_t query, uint32_t mlinks, ui
     x.g.hdr->node_count = query + 1;
 }
 
-// HNSW.NODE.ADD in the reference binary's tie order: one lane of one wavefront
-__global__ void k_insert_std_heap(GraphView g, StdScratch sc, uint32_t id, uint32_t mlinks, uint32_t ef, uint32_t *touched, uint32_t touched_cap)
+// HNSW.NODE.ADD in the reference binary's tie order: one wavefront, its lanes in lockstep (see std_sim)
+__global__ __launch_bounds__(64) void k_insert_std_heap(GraphView g, StdScratch sc, uint32_t id, uint32_t mlinks, uint32_t ef, uint32_t *touched,
+                                                        uint32_t touched_cap)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0) return;
     StdCtx x;
     std_ctx_init(x, g, sc);
     x.touched = touched; x.touched_cap = touched_cap;
     std_insert(x, id, mlinks, ef);
     *sc.epoch = x.epoch;
     if (touched) g.hdr->n_touched = x.nt;
+    if (threadIdx.x != 0) return;
     atomicAdd(&g.hdr->ctr_insert[0], x.n_dist);
     atomicAdd(&g.hdr->ctr_insert[1], x.n_ids);
     atomicAdd(&g.hdr->ctr_insert[2], x.n_expand);
@@ -341,12 +352,11 @@ __global__ void k_tie_compact(const uint32_t *flags, uint32_t B, uint32_t *which
     if (i < B && (all || flags[i])) which[atomicAdd(count, 1u)] = i;
 }
 
-// HNSW.SEARCH (core.rs:477-486, 865-892) in the reference binary's tie order for the queries which[0 .. *n_which): one lane
-// per query; block b serves entries b, b + gridDim.x, ... with scratch context b
-__global__ void k_search_std_heap(GraphView g, const StdScratch *scs, const float *Q, const uint32_t *which, const uint32_t *n_which, uint32_t k,
+// HNSW.SEARCH (core.rs:477-486, 865-892) in the reference binary's tie order for the queries which[0 .. *n_which): one
+// wavefront per query (lanes in lockstep, see std_sim); block b serves entries b, b + gridDim.x, ... with scratch context b
+__global__ __launch_bounds__(64) void k_search_std_heap(GraphView g, const StdScratch *scs, const float *Q, const uint32_t *which, const uint32_t *n_which, uint32_t k,
                                   uint32_t ef, uint32_t *out_ids, float *out_sims, uint32_t *out_n)
 {
-    if (threadIdx.x != 0) return;
     const uint32_t n = *n_which;
     StdCtx x;
     std_ctx_init(x, g, scs[blockIdx.x]);
@@ -371,6 +381,7 @@ __global__ void k_search_std_heap(GraphView g, const StdScratch *scs, const floa
         out_n[qi] = m;
     }
     *x.sc.epoch = x.epoch;
+    if (*x.sc.status) atomicOr(&g.hdr->status, ST_STD_OVERFLOW);     // (the insert's launcher reads the word itself: std_status)
 }
 
 } // namespace hnsw

@@ -1,4 +1,4 @@
-// hnsw_tu_std.hip -- HNSW.NODE.ADD / HNSW.SEARCH in the reference binary's own tie order (hnsw_std_heap.hpp: one lane,
+// hnsw_tu_std.hip -- HNSW.NODE.ADD / HNSW.SEARCH in the reference binary's own tie order (hnsw_std_heap.hpp: one wavefront per operation,
 // std::collections::BinaryHeap restated), and their launchers.  Used by tuning "tie_mode" for the operations the tie
 // census flags.
 #define HNSW_SYNC_WAVE_FULL
@@ -11,7 +11,7 @@ namespace hnsw_host {
 static_assert(sizeof(hnsw_index::std_ctx0) == sizeof(StdScratch), "hnsw_index::std_ctx0 mirrors hnsw::StdScratch");
 
 // scratch contexts: [0] the insert's (heaps as large as the index), [1 ..] the searches' (smaller heaps)
-constexpr uint32_t kStdSearchCtx = 8;
+constexpr uint32_t kStdSearchCtx = 32;    // queries answered side by side (one wavefront each; 4 B x capacity of stamps per context)
 
 hnsw_status ensure_std_scratch(hnsw_index *h)
 {
@@ -72,6 +72,7 @@ hnsw_status launch_search_std(hnsw_index *h, const float *dQ, uint32_t B, uint32
     if (h->std_ev_valid) HIP_TRY(h, hipStreamWaitEvent(st, h->std_ev, 0));
     uint32_t *count = h->d_tie_flags + h->tie_flags_cap, *which = h->d_tie_flags + h->tie_flags_cap + 4;
     HIP_TRY(h, hipMemsetAsync(count, 0, 4, st));
+    HIP_TRY(h, hipMemsetAsync(reinterpret_cast<uint32_t *>(h->d_std_misc) + 1 + kStdSearchCtx, 0, 4, st));    // (an insert reads its own at once)
     hipLaunchKernelGGL(k_tie_compact, dim3((B + 255) / 256), dim3(256), 0, st, h->d_tie_flags, B, which, count, all ? 1u : 0u);
     const StdScratch *ctx = reinterpret_cast<const StdScratch *>(h->d_std_ctx) + 1;
     hipLaunchKernelGGL(k_search_std_heap, dim3(kStdSearchCtx), dim3(64), 0, st, view(h), ctx, dQ, which, count, k, h->efc, d_ids, d_sims, d_nout);
