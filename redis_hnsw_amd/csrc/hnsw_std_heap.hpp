@@ -17,7 +17,22 @@
 namespace hnsw {
 
 struct StdPair { float sim; uint32_t id; };
-struct StdHeap { StdPair *a; uint32_t n, cap; int reverse; };        // reverse: BinaryHeap<Reverse<SimPair>> (pops the smallest sim)
+// entries [0, lcap) -- the levels every sift passes through -- live in LDS (at g_std_lds + lo), the rest in HBM
+struct StdHeap { StdPair *a; uint32_t lo, n, cap, lcap; int reverse; };   // reverse: BinaryHeap<Reverse<SimPair>> (pops the smallest sim)
+
+// LDS entries of the ten heaps (C, W, res, w, wd, ccopy, nbrs, econn, enew, t): 6 912 x 8 B = 54 KB
+constexpr uint32_t kStdLdsTotal = 2048 + 512 + 512 + 2048 + 512 + 512 + 64 + 128 + 64 + 512;
+__shared__ StdPair g_std_lds[kStdLdsTotal];
+__device__ __forceinline__ StdPair std_get(const StdHeap &h, uint32_t i)
+{
+    if (i < h.lcap) return g_std_lds[h.lo + i];
+    return h.a[i];
+}
+__device__ __forceinline__ void std_set(const StdHeap &h, uint32_t i, StdPair v)
+{
+    if (i < h.lcap) g_std_lds[h.lo + i] = v;
+    else h.a[i] = v;
+}
 
 // scratch of one std-order operation (HBM): visited stamps + ten heaps of `hcap` entries
 struct StdScratch {
@@ -29,48 +44,48 @@ struct StdScratch {
 };
 
 __device__ __forceinline__ bool std_le(const StdHeap &h, float x, float y) { return h.reverse ? y <= x : x <= y; }
-__device__ inline uint32_t std_sift_up(StdHeap &h, uint32_t start, uint32_t pos)
+__device__ __forceinline__ uint32_t std_sift_up(StdHeap &h, uint32_t start, uint32_t pos)
 {
-    const StdPair e = h.a[pos];
+    const StdPair e = std_get(h, pos);
     while (pos > start) {
         const uint32_t parent = (pos - 1) / 2;
-        if (std_le(h, e.sim, h.a[parent].sim)) break;                 // hole.element() <= hole.get(parent)
-        h.a[pos] = h.a[parent];
+        if (std_le(h, e.sim, std_get(h, parent).sim)) break;                 // hole.element() <= hole.get(parent)
+        std_set(h, pos, std_get(h, parent));
         pos = parent;
     }
-    h.a[pos] = e;
+    std_set(h, pos, e);
     return pos;
 }
-__device__ inline void std_push(StdHeap &h, StdPair x, uint32_t *status)
+__device__ __forceinline__ void std_push(StdHeap &h, StdPair x, uint32_t *status)
 {
     if (h.n >= h.cap) { *status = 1u; return; }
-    h.a[h.n++] = x;
+    std_set(h, h.n++, x);
     std_sift_up(h, 0, h.n - 1);
 }
-__device__ inline StdPair std_pop(StdHeap &h)
+__device__ __forceinline__ StdPair std_pop(StdHeap &h)
 {
-    StdPair item = h.a[--h.n];
+    StdPair item = std_get(h, --h.n);
     if (h.n) {
-        const StdPair t = h.a[0]; h.a[0] = item; item = t;
+        const StdPair t = std_get(h, 0); std_set(h, 0, item); item = t;
         const uint32_t end = h.n;
         uint32_t pos = 0, child = 1;
-        const StdPair e = h.a[0];
+        const StdPair e = std_get(h, 0);
         while (end >= 2 && child <= end - 2) {                        // sift_down_to_bottom
-            if (std_le(h, h.a[child].sim, h.a[child + 1].sim)) child++;
-            h.a[pos] = h.a[child];
+            if (std_le(h, std_get(h, child).sim, std_get(h, child + 1).sim)) child++;
+            std_set(h, pos, std_get(h, child));
             pos = child;
             child = 2 * pos + 1;
         }
-        if (child == end - 1) { h.a[pos] = h.a[child]; pos = child; }
-        h.a[pos] = e;
+        if (child == end - 1) { std_set(h, pos, std_get(h, child)); pos = child; }
+        std_set(h, pos, e);
         std_sift_up(h, 0, pos);
     }
     return item;
 }
-__device__ inline void std_clone(StdHeap &dst, const StdHeap &src, uint32_t *status)
+__device__ __forceinline__ void std_clone(StdHeap &dst, const StdHeap &src, uint32_t *status)
 {
     if (src.n > dst.cap) { *status = 1u; dst.n = 0; return; }
-    for (uint32_t i = 0; i < src.n; ++i) dst.a[i] = src.a[i];
+    for (uint32_t i = 0; i < src.n; ++i) std_set(dst, i, std_get(src, i));
     dst.n = src.n; dst.reverse = src.reverse;
 }
 
@@ -79,7 +94,7 @@ __device__ inline void std_clone(StdHeap &dst, const StdHeap &src, uint32_t *sta
 // lanes share work.  metrics.rs:14-84 bit for bit: the AVX2 order iff dim % 32 == 0 -- lane s < 32 is accumulator s / 8, SIMD
 // lane s % 8 (one FMA per 32-block), then (e1+e2)+(e3+e4), low128+high128, (s0+s1)+(s2+s3) as butterfly steps (additions
 // commute, so every lane ends with the same bits) -- else the scalar left fold: squares side by side, the additions one by one.
-__device__ inline float std_sim(const float *a, const float *b, uint32_t dim)
+__device__ __forceinline__ float std_sim(const float *a, const float *b, uint32_t dim)
 {
     const uint32_t lane = threadIdx.x & 63u;
     float r;
@@ -116,30 +131,81 @@ struct StdCtx {
     StdHeap C, W, res, w, wd, ccopy, nbrs, econn, enew, t;
     uint32_t epoch;
     unsigned long long n_dist, n_ids, n_expand;
+    uint32_t ovf;                 // a heap overflowed (written to sc.status when the operation ends)
     uint32_t *touched, touched_cap, nt;
 };
-__device__ inline void std_ctx_init(StdCtx &x, const GraphView &g, const StdScratch &sc)
+__device__ __forceinline__ void std_ctx_init(StdCtx &x, const GraphView &g, const StdScratch &sc)
 {
     x.g = g; x.sc = sc;
-    StdHeap *hs[10] = {&x.C, &x.W, &x.res, &x.w, &x.wd, &x.ccopy, &x.nbrs, &x.econn, &x.enew, &x.t};
-    for (int i = 0; i < 10; ++i) { hs[i]->a = sc.heaps + (size_t)i * sc.hcap; hs[i]->n = 0; hs[i]->cap = sc.hcap; hs[i]->reverse = 0; }
+    // (each heap named: an array of pointers to them would pin the whole context in scratch memory)
+    uint32_t off = 0, slot = 0;
+    auto init = [&](StdHeap &h, uint32_t lcap) {
+        h.a = sc.heaps + (size_t)slot * sc.hcap; h.n = 0; h.cap = sc.hcap; h.reverse = 0;
+        h.lo = off; h.lcap = lcap; off += lcap; slot += 1;
+    };
+    init(x.C, 2048); init(x.W, 512); init(x.res, 512); init(x.w, 2048); init(x.wd, 512);
+    init(x.ccopy, 512); init(x.nbrs, 64); init(x.econn, 128); init(x.enew, 64); init(x.t, 512);
     x.epoch = *sc.epoch;
     x.n_dist = x.n_ids = x.n_expand = 0;
+    x.ovf = 0;
     x.touched = nullptr; x.touched_cap = 0; x.nt = 0;
 }
-__device__ inline void std_visited_reset(StdCtx &x, uint32_t n)
+__device__ __forceinline__ void std_visited_reset(StdCtx &x, uint32_t n)
 {
     if (++x.epoch == 0u) { for (uint32_t i = 0; i < n; ++i) x.sc.stamp[i] = 0u; x.epoch = 1u; }
 }
-__device__ inline bool std_test_and_set(StdCtx &x, uint32_t id)
+__device__ __forceinline__ bool std_test_and_set(StdCtx &x, uint32_t id)
 {
     if (x.sc.stamp[id] == x.epoch) return true;
     x.sc.stamp[id] = x.epoch;
     return false;
 }
-__device__ inline const float *std_vec(const StdCtx &x, uint32_t id) { return x.g.vec + (size_t)id * x.g.dim; }
+__device__ __forceinline__ const float *std_vec(const StdCtx &x, uint32_t id) { return x.g.vec + (size_t)id * x.g.dim; }
+// Similarities of one adjacency-row chunk against vector a: lane i holds the id of entry i, `mask` says which entries are
+// wanted, lane i returns entry i's similarity.  The values are those of std_sim; computing them ahead of the heap decisions
+// changes nothing (a similarity does not depend on the heaps) and takes the row's loads off the dependent chain: two entries
+// per pass in the AVX order (one per half of the wavefront; the butterfly steps stay inside a half).
+__device__ __forceinline__ float std_sims_row(const StdCtx &x, const float *a, uint32_t myid, uint64_t mask)
+{
+    const uint32_t lane = threadIdx.x & 63u, dim = x.g.dim;
+    float mine = 0.f;
+    if (dim % 32u == 0u) {
+        const uint32_t s = lane & 31u, half = lane >> 5;
+        while (mask) {
+            const uint32_t b0 = (uint32_t)__ffsll((unsigned long long)mask) - 1u;
+            mask &= mask - 1;
+            uint32_t b1 = b0;
+            if (mask) { b1 = (uint32_t)__ffsll((unsigned long long)mask) - 1u; mask &= mask - 1; }
+            const uint32_t id0 = (uint32_t)__builtin_amdgcn_readlane((int)myid, (int)b0), id1 = (uint32_t)__builtin_amdgcn_readlane((int)myid, (int)b1);
+            const float *b = x.g.vec + (size_t)(half ? id1 : id0) * dim;
+            float e = 0.f;
+            for (uint32_t i = 0; i < dim; i += 32) {
+                const float d = __fsub_rn(a[i + s], b[i + s]);
+                e = __fmaf_rn(d, d, e);
+            }
+            e = __fadd_rn(e, __shfl_xor(e, 8));
+            e = __fadd_rn(e, __shfl_xor(e, 16));
+            e = __fadd_rn(e, __shfl_xor(e, 4));
+            e = __fadd_rn(e, __shfl_xor(e, 1));
+            e = __fadd_rn(e, __shfl_xor(e, 2));
+            const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), 0));
+            const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), 32));
+            if (lane == b0) mine = -r0;
+            if (lane == b1) mine = -r1;
+        }
+    } else {
+        while (mask) {
+            const uint32_t b0 = (uint32_t)__ffsll((unsigned long long)mask) - 1u;
+            mask &= mask - 1;
+            const uint32_t id0 = (uint32_t)__builtin_amdgcn_readlane((int)myid, (int)b0);
+            const float r = std_sim(a, x.g.vec + (size_t)id0 * dim, dim);
+            if (lane == b0) mine = r;
+        }
+    }
+    return mine;
+}
 // rows above a node's top level behave as empty (push_levels, core.rs:127-135, 642)
-__device__ inline const uint32_t *std_row(const StdCtx &x, uint32_t id, uint32_t lc, uint32_t &cnt)
+__device__ __forceinline__ const uint32_t *std_row(const StdCtx &x, uint32_t id, uint32_t lc, uint32_t &cnt)
 {
     if (lc > x.g.levels[id]) { cnt = 0; return nullptr; }
     const uint32_t *r = row_ptr(x.g, id, lc);
@@ -147,127 +213,172 @@ __device__ inline const uint32_t *std_row(const StdCtx &x, uint32_t id, uint32_t
     cnt = r[0] > stride - 1 ? stride - 1 : r[0];
     return r + 1;
 }
-__device__ inline void std_touch(StdCtx &x, uint32_t id)
+__device__ __forceinline__ void std_touch(StdCtx &x, uint32_t id)
 {
     if (x.touched && x.nt < x.touched_cap) x.touched[x.nt] = id;
     x.nt += 1;
 }
+// Row scans below: the lanes compare a chunk of the row at once (one load latency instead of one per entry); a shift moves
+// a chunk per step, every lane's load before any lane's store (one instruction each, in order).
+// position of the first entry of r[1 .. 1 + cnt) equal to nb, or kEmpty
+__device__ __forceinline__ uint32_t std_row_find(const uint32_t *r, uint32_t cnt, uint32_t nb)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t base = 0; base < cnt; base += 64u) {
+        const uint64_t hit = __ballot(base + lane < cnt && r[1 + base + lane] == nb);
+        if (hit) return base + (uint32_t)__ffsll((unsigned long long)hit) - 1u;
+    }
+    return kEmpty;
+}
 // core.rs:137-143 add_neighbor: push iff not already present
-__device__ inline void std_add_neighbor(StdCtx &x, uint32_t id, uint32_t lc, uint32_t nb)
+__device__ __forceinline__ void std_add_neighbor(StdCtx &x, uint32_t id, uint32_t lc, uint32_t nb)
 {
     uint32_t *r = row_ptr(x.g, id, lc);
     const uint32_t stride = lc ? x.g.strideU : x.g.stride0;
     const uint32_t cnt = r[0];
-    for (uint32_t i = 0; i < cnt; ++i) if (r[1 + i] == nb) return;
+    if (std_row_find(r, cnt, nb) != kEmpty) return;
     if (cnt + 1 > stride - 1) { atomicOr(&x.g.hdr->status, ST_ROW_OVERFLOW); return; }
     r[1 + cnt] = nb; r[0] = cnt + 1;
     if ((threadIdx.x & 63u) == 0u) atomicMax(lc ? &x.g.hdr->max_degU : &x.g.hdr->max_deg0, cnt + 1);
 }
 // core.rs:145-152 rm_neighbor: position().unwrap() then Vec::remove
-__device__ inline void std_rm_neighbor(StdCtx &x, uint32_t id, uint32_t lc, uint32_t nb)
+__device__ __forceinline__ void std_rm_neighbor(StdCtx &x, uint32_t id, uint32_t lc, uint32_t nb)
 {
     uint32_t *r = row_ptr(x.g, id, lc);
-    const uint32_t cnt = r[0];
-    for (uint32_t i = 0; i < cnt; ++i)
-        if (r[1 + i] == nb) {
-            for (uint32_t j = i; j + 1 < cnt; ++j) r[1 + j] = r[2 + j];
-            r[0] = cnt - 1;
-            return;
-        }
-    atomicOr(&x.g.hdr->status, ST_ASYMMETRIC);                         // the reference panics here (core.rs:150)
+    const uint32_t cnt = r[0], lane = threadIdx.x & 63u;
+    const uint32_t pos = std_row_find(r, cnt, nb);
+    if (pos == kEmpty) { atomicOr(&x.g.hdr->status, ST_ASYMMETRIC); return; }    // the reference panics here (core.rs:150)
+    for (uint32_t b = pos; b + 1 < cnt; b += 64u) {
+        const uint32_t j = b + lane;
+        const bool in = j + 1 < cnt;
+        const uint32_t v = in ? r[2 + j] : 0u;
+        if (in) r[1 + j] = v;
+    }
+    r[0] = cnt - 1;
 }
 
 // core.rs:607-675; leaves the result heap (:670-674) in x.res
-__device__ inline void std_search_level(StdCtx &x, const float *query, uint32_t ep, uint32_t ef, uint32_t level)
+__device__ __forceinline__ void std_search_level(StdCtx &x, const float *query, uint32_t ep, uint32_t ef, uint32_t level)
 {
     std_visited_reset(x, x.g.hdr->node_count);
     std_test_and_set(x, ep);
     const StdPair qpair = {std_sim(query, std_vec(x, ep), x.g.dim), ep};
     x.n_dist += 1;
     x.C.n = x.W.n = x.res.n = 0; x.C.reverse = 0; x.W.reverse = 1; x.res.reverse = 0;
-    std_push(x.C, qpair, x.sc.status); std_push(x.W, qpair, x.sc.status);
+    std_push(x.C, qpair, &x.ovf); std_push(x.W, qpair, &x.ovf);
     while (x.C.n) {
         const StdPair c = std_pop(x.C);
-        StdPair f = x.W.a[0];
+        StdPair f = std_get(x.W, 0);
         if (c.sim < f.sim) break;                                     // :635
         x.n_expand += 1;
         uint32_t cnt;
         const uint32_t *nb = std_row(x, c.id, level, cnt);
-        for (uint32_t i = 0; i < cnt; ++i) {                          // :646 stored order
-            const uint32_t e = nb[i];
-            x.n_ids += 1;
-            if (std_test_and_set(x, e)) continue;
-            f = x.W.a[0];
-            const StdPair e2 = {std_sim(query, std_vec(x, e), x.g.dim), e};
-            x.n_dist += 1;
-            if (e2.sim > f.sim || x.W.n < ef) {                       // :657
-                std_push(x.C, e2, x.sc.status); std_push(x.W, e2, x.sc.status);
-                if (x.W.n > ef) std_pop(x.W);
+        const uint32_t lane = threadIdx.x & 63u;
+        for (uint32_t base = 0; base < cnt; base += 64u) {            // :646 stored order, a chunk of the row at a time
+            const uint32_t nn = cnt - base < 64u ? cnt - base : 64u;
+            const bool in = lane < nn;
+            const uint32_t myid = in ? nb[base + lane] : 0u;
+            const uint64_t unvisited = __ballot(in && x.sc.stamp[myid] != x.epoch);
+            const float mysim = std_sims_row(x, query, myid, unvisited);
+            x.n_ids += nn;
+            for (uint64_t todo = unvisited; todo; todo &= todo - 1) {
+                const uint32_t i = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
+                const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)myid, (int)i);
+                if (__ballot(in && myid == e) & ((1ull << i) - 1ull)) continue;    // the same id earlier in this row: visited by now
+                x.sc.stamp[e] = x.epoch;
+                f = std_get(x.W, 0);
+                const StdPair e2 = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(mysim), (int)i)), e};
+                x.n_dist += 1;
+                if (e2.sim > f.sim || x.W.n < ef) {                   // :657
+                    std_push(x.C, e2, &x.ovf); std_push(x.W, e2, &x.ovf);
+                    if (x.W.n > ef) std_pop(x.W);
+                }
             }
         }
-        if (*x.sc.status) return;
+        if (x.ovf) return;
     }
-    for (uint32_t i = 0; i < x.W.n; ++i) std_push(x.res, x.W.a[i], x.sc.status);   // :670-674: into_iter order, pushed one by one
+    for (uint32_t i = 0; i < x.W.n; ++i) std_push(x.res, std_get(x.W, i), &x.ovf);   // :670-674: into_iter order, pushed one by one
 }
 
 // core.rs:677-757 (extend_candidates = keep_pruned_connections = true at every call site); result in r
-__device__ inline void std_select_neighbors(StdCtx &x, uint32_t query, const StdHeap &c, uint32_t m, uint32_t lc, uint32_t ignored, StdHeap &r)
+__device__ __forceinline__ void std_select_neighbors(StdCtx &x, uint32_t query, const StdHeap &c, uint32_t m, uint32_t lc, uint32_t ignored, StdHeap &r)
 {
     r.n = 0; r.reverse = 0;
-    std_clone(x.w, c, x.sc.status);                                   // :685
+    std_clone(x.w, c, &x.ovf);                                   // :685
     x.wd.n = 0; x.wd.reverse = 0;
     std_visited_reset(x, x.g.hdr->node_count);                        // :692
-    for (uint32_t i = 0; i < c.n; ++i) std_test_and_set(x, c.a[i].id);   // :690-696 (a set)
-    std_clone(x.ccopy, c, x.sc.status);                               // :698
+    for (uint32_t i = 0; i < c.n; ++i) x.sc.stamp[std_get(c, i).id] = x.epoch;   // :690-696 (a set)
+    std_clone(x.ccopy, c, &x.ovf);                               // :698
     const float *qv = std_vec(x, query);
     while (x.ccopy.n) {
         const StdPair e = std_pop(x.ccopy);
         uint32_t cnt;
         const uint32_t *nb = std_row(x, e.id, lc, cnt);
-        for (uint32_t i = 0; i < cnt; ++i) {
-            const uint32_t en = nb[i];
-            x.n_ids += 1;
-            if (en == query || en == ignored) continue;              // :704-708
-            if (x.sc.stamp[en] != x.epoch) {                          // :710
-                const StdPair p = {std_sim(qv, std_vec(x, en), x.g.dim), en};
+        const uint32_t lane = threadIdx.x & 63u;
+        for (uint32_t base = 0; base < cnt; base += 64u) {            // stored order, a chunk of the row at a time
+            const uint32_t nn = cnt - base < 64u ? cnt - base : 64u;
+            const bool in = lane < nn;
+            const uint32_t myid = in ? nb[base + lane] : 0u;
+            const uint64_t fresh = __ballot(in && myid != query && myid != ignored && x.sc.stamp[myid] != x.epoch);   // :704-710
+            const float mysim = std_sims_row(x, qv, myid, fresh);
+            x.n_ids += nn;
+            for (uint64_t todo = fresh; todo; todo &= todo - 1) {
+                const uint32_t i = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
+                const uint32_t en = (uint32_t)__builtin_amdgcn_readlane((int)myid, (int)i);
+                if (__ballot(in && myid == en) & ((1ull << i) - 1ull)) continue;   // the same id earlier in this row: in the set by now
+                const StdPair p = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(mysim), (int)i)), en};
                 x.n_dist += 1;
-                std_push(x.w, p, x.sc.status);                        // :717
+                std_push(x.w, p, &x.ovf);                             // :717
                 x.sc.stamp[en] = x.epoch;                             // :718
             }
         }
-        if (*x.sc.status) return;
+        if (x.ovf) return;
     }
     while (x.w.n && r.n < m) {                                        // :724-738
         const StdPair e = std_pop(x.w);
         if (e.id == query || e.id == ignored) continue;
-        if (r.n == 0 || e.sim > r.a[0].sim) std_push(r, e, x.sc.status);   // :733
-        else std_push(x.wd, e, x.sc.status);
+        if (r.n == 0 || e.sim > std_get(r, 0).sim) std_push(r, e, &x.ovf);   // :733
+        else std_push(x.wd, e, &x.ovf);
     }
     while (x.wd.n && r.n < m) {                                       // :741-754
         const StdPair p = std_pop(x.wd);
         if (p.id == query || p.id == ignored) continue;
-        std_push(r, p, x.sc.status);
+        std_push(r, p, &x.ovf);
     }
 }
 
 // core.rs:776-822
-__device__ inline void std_update_node_connections(StdCtx &x, uint32_t node, const StdHeap &new_neighbors, const StdHeap &old_neighbors, uint32_t level,
+__device__ __forceinline__ void std_update_node_connections(StdCtx &x, uint32_t node, const StdHeap &new_neighbors, const StdHeap &old_neighbors, uint32_t level,
                                                    uint32_t ignored)
 {
-    std_clone(x.t, new_neighbors, x.sc.status);                      // :784
-    // :785 into_vec: the old heap's array as it is -- kept in x.wd's storage (free here)
-    StdPair *rm = x.wd.a;
+    std_clone(x.t, new_neighbors, &x.ovf);                      // :784
+    // :785 into_vec: the old heap's array as it is -- its ids kept in the LDS part of x.wd (free here)
     uint32_t n_rm = old_neighbors.n;
-    if (n_rm > x.wd.cap) { *x.sc.status = 1u; return; }
-    for (uint32_t i = 0; i < n_rm; ++i) rm[i] = old_neighbors.a[i];
+    StdPair *rm = g_std_lds + x.wd.lo;
+    if (n_rm > x.wd.lcap) { x.ovf = 1u; return; }
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t i = 0; i < n_rm; ++i) rm[i] = std_get(old_neighbors, i);
     std_touch(x, node);                                               // :787
     while (x.t.n) {                                                   // :790
         const StdPair np = std_pop(x.t);
         std_add_neighbor(x, node, level, np.id);                      // :793
         std_add_neighbor(x, np.id, level, node);                      // :794-795
         std_touch(x, np.id);                                          // :796
-        for (uint32_t i = 0; i < n_rm; ++i)                           // :799-801
-            if (rm[i].id == np.id) { for (uint32_t j = i; j + 1 < n_rm; ++j) rm[j] = rm[j + 1]; n_rm--; break; }
+        uint32_t pos = kEmpty;                                        // :799-801 position() + Vec::remove
+        for (uint32_t base = 0; base < n_rm && pos == kEmpty; base += 64u) {
+            const uint64_t hit = __ballot(base + lane < n_rm && rm[base + lane].id == np.id);
+            if (hit) pos = base + (uint32_t)__ffsll((unsigned long long)hit) - 1u;
+        }
+        if (pos != kEmpty) {
+            for (uint32_t b = pos; b + 1 < n_rm; b += 64u) {
+                const uint32_t j = b + lane;
+                const bool in = j + 1 < n_rm;
+                StdPair v = {0.f, 0u};
+                if (in) v = rm[j + 1];
+                if (in) rm[j] = v;
+            }
+            n_rm--;
+        }
     }
     while (n_rm) {                                                    // :805
         const StdPair rp = rm[--n_rm];
@@ -279,7 +390,7 @@ __device__ inline void std_update_node_connections(StdCtx &x, uint32_t node, con
 }
 
 // core.rs:489-599 for node `query` (vector, level and empty rows already in place)
-__device__ inline void std_insert(StdCtx &x, uint32_t query, uint32_t mlinks, uint32_t ef)
+__device__ __forceinline__ void std_insert(StdCtx &x, uint32_t query, uint32_t mlinks, uint32_t ef)
 {
     const uint32_t l = x.g.levels[query];
     const uint32_t l_max = x.g.hdr->max_layer;                        // :496
@@ -288,39 +399,47 @@ __device__ inline void std_insert(StdCtx &x, uint32_t query, uint32_t mlinks, ui
     uint32_t lc = l_max;
     while (lc > l) {                                                  // :511-520
         std_search_level(x, qv, ep, 1, lc);
-        if (*x.sc.status) return;
-        ep = x.res.a[0].id;                                           // :514 w.pop(): the root
+        if (x.ovf) return;
+        ep = std_get(x.res, 0).id;                                           // :514 w.pop(): the root
         if (lc == 0) break;
         lc--;
     }
     const uint32_t top = l_max < l ? l_max : l;
     for (uint32_t lcc = top + 1; lcc-- > 0;) {                        // :523
         std_search_level(x, qv, ep, ef, lcc);                         // :524
-        if (*x.sc.status) return;
+        if (x.ovf) return;
         std_select_neighbors(x, query, x.res, mlinks, lcc, kEmpty, x.nbrs);   // :525-531
-        if (*x.sc.status) return;
-        std_clone(x.t, x.nbrs, x.sc.status);                          // :532 connect_neighbors (:759-774)
+        if (x.ovf) return;
+        std_clone(x.t, x.nbrs, &x.ovf);                          // :532 connect_neighbors (:759-774)
         while (x.t.n) { const StdPair n = std_pop(x.t); std_add_neighbor(x, query, lcc, n.id); std_add_neighbor(x, n.id, lcc, query); }
-        for (uint32_t i = 0; i < x.nbrs.n; ++i) std_touch(x, x.nbrs.a[i].id);   // :535-537
-        const uint32_t ep_next = x.res.a[0].id;                       // :576 w.peek() (res is not touched below)
+        for (uint32_t i = 0; i < x.nbrs.n; ++i) std_touch(x, std_get(x.nbrs, i).id);   // :535-537
+        const uint32_t ep_next = std_get(x.res, 0).id;                       // :576 w.peek() (res is not touched below)
         while (x.nbrs.n) {                                            // :540
             const StdPair e = std_pop(x.nbrs);
             x.econn.n = 0; x.econn.reverse = 0;                       // :544-558
             uint32_t cnt;
             const uint32_t *er = std_row(x, e.id, lcc, cnt);
             const float *ev = std_vec(x, e.id);
-            for (uint32_t i = 0; i < cnt; ++i) {
-                const StdPair p = {std_sim(ev, std_vec(x, er[i]), x.g.dim), er[i]};   // :550
-                x.n_dist += 1; x.n_ids += 1;
-                std_push(x.econn, p, x.sc.status);
+            const uint32_t lane = threadIdx.x & 63u;
+            for (uint32_t base = 0; base < cnt; base += 64u) {
+                const uint32_t nn = cnt - base < 64u ? cnt - base : 64u;
+                const bool in = lane < nn;
+                const uint32_t myid = in ? er[base + lane] : 0u;
+                const float mysim = std_sims_row(x, ev, myid, __ballot(in));                 // :550
+                for (uint32_t i = 0; i < nn; ++i) {
+                    const StdPair p = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(mysim), (int)i)),
+                                       (uint32_t)__builtin_amdgcn_readlane((int)myid, (int)i)};
+                    x.n_dist += 1; x.n_ids += 1;
+                    std_push(x.econn, p, &x.ovf);
+                }
             }
             const uint32_t m_max = lcc == 0 ? 2 * mlinks : mlinks;    // :560
             if (x.econn.n > m_max) {                                  // :561
                 std_select_neighbors(x, e.id, x.econn, m_max, lcc, kEmpty, x.enew);   // :568
-                if (*x.sc.status) return;
+                if (x.ovf) return;
                 std_update_node_connections(x, e.id, x.enew, x.econn, lcc, kEmpty);  // :569
             }
-            if (*x.sc.status) return;
+            if (x.ovf) return;
         }
         ep = ep_next;
     }
@@ -338,6 +457,7 @@ __global__ __launch_bounds__(64) void k_insert_std_heap(GraphView g, StdScratch 
     x.touched = touched; x.touched_cap = touched_cap;
     std_insert(x, id, mlinks, ef);
     *sc.epoch = x.epoch;
+    if (x.ovf) *sc.status = 1u;
     if (touched) g.hdr->n_touched = x.nt;
     if (threadIdx.x != 0) return;
     atomicAdd(&g.hdr->ctr_insert[0], x.n_dist);
@@ -366,7 +486,7 @@ __global__ __launch_bounds__(64) void k_search_std_heap(GraphView g, const StdSc
         uint32_t ep = (uint32_t)g.hdr->enterpoint, lc = g.hdr->max_layer;
         while (lc > 0) {                                              // :869-874
             std_search_level(x, q, ep, 1, lc);
-            ep = x.res.a[0].id;                                       // :872 peek
+            ep = std_get(x.res, 0).id;                                       // :872 peek
             lc--;
         }
         std_search_level(x, q, ep, ef, 0);                            // :876
@@ -381,7 +501,7 @@ __global__ __launch_bounds__(64) void k_search_std_heap(GraphView g, const StdSc
         out_n[qi] = m;
     }
     *x.sc.epoch = x.epoch;
-    if (*x.sc.status) atomicOr(&g.hdr->status, ST_STD_OVERFLOW);     // (the insert's launcher reads the word itself: std_status)
+    if (x.ovf) { *scs[blockIdx.x].status = 1u; atomicOr(&g.hdr->status, ST_STD_OVERFLOW); }     // (the insert's launcher reads the word itself: std_status)
 }
 
 } // namespace hnsw
