@@ -254,7 +254,13 @@ hnsw_status hnsw_deserialize(const void *buf, uint64_t bytes, uint64_t seed, int
  *             (1: a full LDS visited table stops recording -- exact results, distance evaluations may
  *             exceed the reference's; 0: the table continues in HBM -- counters equal the reference's),
  *             "lean" (specialised dim-128 kernel on/off), "tie_census" (1: searches run the census form of that
- *             kernel, see hnsw_get_tie_counters), "grid_stride", "query_in_lds", "time_launches",
+ *             kernel, see hnsw_get_tie_counters), "tie_mode" (0: answers and links in the total order (similarity, id),
+ *             the default; 1: every insert and every query the tie census flags is redone in the REFERENCE BINARY's own
+ *             order -- core.rs:489-892 statement by statement on std::collections::BinaryHeap restated, one wavefront
+ *             per operation (csrc/hnsw_std_heap.hpp): the graph and the answers are the Rust binary's, row for row;
+ *             implies tie_census; a single hnsw_add always runs there; 2: every insert / query runs there (tests);
+ *             deletes stay in the total order; a heap overflow of that kernel is HNSW_ERR_CAPACITY),
+ *             "grid_stride", "query_in_lds", "time_launches",
  *             "lds_buckets" / "lds_hash_bits" / "tag_table" / "tag_bb" / "idbits" / "grid" (tests)
  *   build     "occ_window" (slots of the exact parallel insert, 0 = serial), "occ_min_batch",
  *             "occ_ahead_x10" / "occ_front_max" (nodes the group commit dry-runs side by side), "occ_depth_x10" (how far
