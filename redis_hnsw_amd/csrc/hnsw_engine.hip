@@ -838,7 +838,10 @@ hnsw_status hnsw_add_batch(hnsw_index *h, const float *V, uint32_t n, uint32_t d
     if (h->wide_m) mode = 0;                                 // M > 64: the reference's order through the serial kernels
     // exact inserts: all of them (mode 0) or the seed prefix of the fast build.  Large exact batches go
     // through the optimistic window (same graph, planned in parallel, committed in order: hnsw_occ.hpp).
-    if (mode == 0 && h->occ_window >= 2 && n >= h->occ_min_batch && h->tie_mode != 2) {
+    // (tie_mode 2: every insert on the std-order kernel; tie_mode 1 on a shape whose plans do not count ties -- anything but
+    // dim-128 f32 rows in the AVX order -- likewise: add_exact decides per node)
+    const bool tie_gate_shape = h->plan_lean && h->mode == MODE_AVX && h->dim == 128 && h->fmt == FMT_F32;
+    if (mode == 0 && h->occ_window >= 2 && n >= h->occ_min_batch && h->tie_mode != 2 && !(h->tie_mode == 1 && !tie_gate_shape)) {
         while (done < n && h->n - h->n_dead < 2) {           // the first nodes: serial (no graph to plan against)
             if ((s = add_exact(h, V + (size_t)done * dim, nullptr, levels ? levels[done] : -1, nullptr, false, nullptr)) != HNSW_OK)
                 return s;

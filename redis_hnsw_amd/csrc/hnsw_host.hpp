@@ -323,6 +323,7 @@ template <bool WIDE>
 hnsw_status launch_occ_plan_duo_v(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t head, uint32_t count, uint32_t idbits);
 // hnsw_engine.hip: 0 when the specialised plan cannot serve this index, else the id-hash width to launch it with
 uint32_t plan_lean_idbits(const hnsw_index *h, const InsertCfg &c);
+hnsw_status ensure_par(hnsw_index *h);
 size_t plan_lean_lds(int R);
 hnsw_status launch_occ_plan_lean(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t head, uint32_t count, bool *done);
 // hnsw_tu_std.hip: the reference binary's own tie order on one lane (tuning "tie_mode")

@@ -207,8 +207,11 @@ template <int MODE, int T, int R, int HW = 0>
 __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g, OccBufs ob, ParBufs pb, uint32_t end_node, uint32_t mlinks,
                                                        uint32_t lnb, uint32_t lcap, uint32_t *__restrict__ gspill, uint32_t gnb,
                                                        const uint32_t *__restrict__ plan, uint32_t slack, uint32_t own_lds = 0,
-                                                       TeamCfg tc = TeamCfg{}, uint32_t chained = 0)
+                                                       TeamCfg tc = TeamCfg{}, uint32_t chained = 0, uint32_t *__restrict__ touched = nullptr,
+                                                       uint32_t touched_cap = 0)
 {
+    // touched (a window of ONE node: a single hnsw_add under tuning tie_mode 1): the update_fn list of core.rs:535-537, 787-816,
+    // written by the dry run in the reference's order and published when the node is applied
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     if (chained && (ob.ctl->stop >= OCC_STOP_RESTRIDE || ob.ctl->head >= end_node)) return;   // a round enqueued ahead of the host (occ_round_window)
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g
 #define DRY_T(i) do { const unsigned long long n_ = wall_clock64(); dprof[i] += n_ - d_; d_ = n_; } while (0)
     // the dry run this workgroup holds (kept across iterations while nothing committed touches it)
     bool have = false, redo = false;
-    uint32_t cur_id = kEmpty, kept_state = PAR_NONE;
+    uint32_t cur_id = kEmpty, kept_state = PAR_NONE, kept_nt = 0;
     uint64_t live = 0;                                       // sub-operations whose reads stand for the dry run
     uint32_t n_hash = 0;                                     // entries in the LDS hash
     uint32_t n_delta = 0, promotes = 0;
@@ -342,6 +345,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g
                             else { nrow[1 + c] = id; nrow[0] = c + 1; atomicMax(maxdeg, c + 1); }
                         }
                         if (lane == 0) atomicMax(maxdeg, nsel);
+                        touch_push(touched, touched_cap, nt, myselid, touched != nullptr && (uint32_t)lane < nsel, lane);   // :535-537
                         journal_push(&jr, (uint32_t)lane < nsel, myselid, lc, id, true, lane);
                         fence_own_writes();
                         wave_sync_full();
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g
                                 }
                                 DRY_T(4);
                             }
-                            update_connections(ov, m, e, erow, cnt, nS, lc, stride, maxdeg, kEmpty, (uint32_t *)nullptr, 0u, nt, lane, &jr);
+                            update_connections(ov, m, e, erow, cnt, nS, lc, stride, maxdeg, kEmpty, touched, touched_cap, nt, lane, &jr);
                             DRY_T(5);
                         }
                     }
@@ -459,6 +463,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g
                     have = true;                             // kept until a group touches it (a void dry run, PAR_SERIAL, as well)
                     cur_id = id;
                     kept_state = state;
+                    kept_nt = nt;
                 }
             }
         }
@@ -546,6 +551,7 @@ __global__ __launch_bounds__(64 * (1 + HW), 1) void k_occ_commit_par(GraphView g
             if (stale && lane == 0) { me->pad1 = 1u; sl->planned = 0; sl->stage = 0u; }
         }
         if (state == PAR_READY && pos < p) {
+            if (touched && lane == 0) g.hdr->n_touched = kept_nt;
             // write the overlay rows back, eight at a time
             for (uint32_t base = 0; base < kParTab; base += 64) {
                 const uint32_t key = ov.ovkey[base + lane];

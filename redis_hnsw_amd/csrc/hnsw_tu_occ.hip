@@ -43,14 +43,19 @@ static hnsw_status occ_round_t(hnsw_index *h, const InsertCfg &c, const OccBufs 
                        h->spill_gnb, kEmpty, kOccInsShr);
     bool team = false;
     // (tie_mode 1: always -- a dry run can be thrown away when its selections meet a tie, an in-order commit cannot)
-    if (count > 1 && !h->occ_want_touched && (h->commit_par == 2 || h->tie_mode == 1 || (h->commit_par == 1 && h->occ_yield * 10.0 >= (double)h->commit_par_min_x10))) {
+    // (a window of one node under tie_mode 1 -- a single hnsw_add -- too: the dry run tells whether the commit meets a tie
+    // before a row is written, and writes the touched list)
+    if (!lean_plan && h->tie_mode == 1)
+        return fail(h, HNSW_ERR_INVALID, "tie_mode 1 needs the dim-128 plan kernels (their searches count the ties); use tie_mode 2");
+    const bool lone_gated = count == 1 && h->tie_mode == 1;
+    if (lone_gated || (count > 1 && !h->occ_want_touched && (h->commit_par == 2 || h->tie_mode == 1 || (h->commit_par == 1 && h->occ_yield * 10.0 >= (double)h->commit_par_min_x10)))) {
         // the window's commits in validated parallel groups, one workgroup per window node (hnsw_occ_par.hpp)
         HIP_TRY(h, hipGetLastError());
         // (the commit's grid is the FRONT; the plans above cover the whole depth of the window, add_exact_window)
         hnsw_status ps = occ_commit_par_r<MODE, T>(h, c, ob, h->occ_front ? std::min(h->occ_front, count) : count, end_node, &team);
         if (ps != HNSW_OK) return ps;
     }
-    if (!team && h->tie_mode == 1 && count > 1)
+    if (!team && h->tie_mode == 1)
         return fail(h, HNSW_ERR_INVALID, "tie_mode 1 needs the group commit kernel (ef_construction <= 1024, ids < 2^27, a device that holds the window's workgroups)");
     if (!team && h->commit_team) {
         HIP_TRY(h, hipGetLastError());

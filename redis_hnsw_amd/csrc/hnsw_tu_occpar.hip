@@ -82,7 +82,8 @@ static hnsw_status commit_par_t(hnsw_index *h, const InsertCfg &c, const OccBufs
         if (rs != HNSW_OK) return rs;
         if (count > std::min(resident, h->par_max_resident)) return HNSW_OK;      // not all workgroups would be resident: the in-order commit
         hipLaunchKernelGGL(kt, dim3(count), dim3(64 * (1 + kParHelpers)), lds_team, h->stream, view_tag(h, c.tagcfg), ob, pb, end_node, h->m, c.lnb,
-                           c.lcap, h->d_spill, h->spill_gnb, h->d_plan, occ_slack(h), (uint32_t)c.lds, tc, h->occ_chained ? 1u : 0u);
+                           c.lcap, h->d_spill, h->spill_gnb, h->d_plan, occ_slack(h), (uint32_t)c.lds, tc, h->occ_chained ? 1u : 0u,
+                           h->occ_want_touched ? h->d_touched : (uint32_t *)nullptr, h->occ_want_touched ? h->touched_cap : 0u);
         HIP_TRY(h, hipGetLastError());
         *done = true;
         return HNSW_OK;
@@ -102,7 +103,8 @@ static hnsw_status commit_par_t(hnsw_index *h, const InsertCfg &c, const OccBufs
     if (rs != HNSW_OK) return rs;
     if (count > std::min(resident, h->par_max_resident)) return HNSW_OK;          // not all workgroups would be resident: the in-order commit
     hipLaunchKernelGGL(kc, dim3(count), dim3(64), lds, h->stream, view_tag(h, c.tagcfg), ob, pb, end_node, h->m, c.lnb, c.lcap, h->d_spill,
-                       h->spill_gnb, h->d_plan, occ_slack(h), 0u, TeamCfg{}, h->occ_chained ? 1u : 0u);
+                       h->spill_gnb, h->d_plan, occ_slack(h), 0u, TeamCfg{}, h->occ_chained ? 1u : 0u,
+                       h->occ_want_touched ? h->d_touched : (uint32_t *)nullptr, h->occ_want_touched ? h->touched_cap : 0u);
     HIP_TRY(h, hipGetLastError());
     *done = true;
     return HNSW_OK;

@@ -252,3 +252,57 @@ def test_tie_mode_answers_queries_as_the_reference_binary_does(eng, oracle_mod, 
     assert np.array_equal(ids2, ids[:64]) and np.array_equal(n2, n_out[:64])
     gi.close()
     o.close()
+
+
+@pytest.mark.parametrize("kind,n", [("uniform", 2500), ("quantised", 900)])
+def test_single_adds_in_tie_mode_link_what_the_reference_binary_links(eng, oracle_mod, kind, n):
+    """tie_mode = 1, one hnsw_add per call (the HNSW.NODE.ADD command's shape): each insert runs as a one-node window whose
+    plan and whose commit -- a dry run of the group commit kernel, which writes nothing before it knows -- are gated by the
+    tie census; only a flagged insert is redone on the std-order kernel.  The graph must be the std-order oracle's row for
+    row; on uniform data nearly every insert takes the gated window, on quantised data (distances on a coarse grid) most
+    are redone.  The touched list (update_fn, core.rs:535-537, 787-816) covers every row the insert changed."""
+    import ctypes as C
+    dim, m, ef = 128, 16, 64
+    V = make_data(n, dim, seed=33)
+    if kind == "quantised":
+        V = np.unique(np.round(V * 2.0) / 2.0, axis=0)
+        np.random.default_rng(2).shuffle(V)
+    n = len(V)
+    lv = oracle_mod.draw_levels(n, m, 6)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch_std_heap(V, lv)
+    want = o.export()
+    gi = eng.Index("single-ties", dim, m, ef)
+    gi.set_tuning("tie_mode", 1)
+    before = None
+    for i in range(n):
+        sample = i >= 40 and i % 97 == 0
+        if sample:
+            before = gi.export_graph()
+        got = []
+        gi.add_node("n%d" % i, V[i], (lambda s, nid: got.append(nid)) if sample else None, level=int(lv[i]))
+        if sample:
+            after = gi.export_graph()
+            changed = set()
+            for lc in range(len(after["row_ptr"])):                        # rows are CSR over all ids, per layer
+                ra, ca = after["row_ptr"][lc].astype(np.int64), after["col"][lc]
+                if lc < len(before["row_ptr"]):
+                    rb, cb = before["row_ptr"][lc].astype(np.int64), before["col"][lc]
+                else:
+                    rb, cb = np.zeros(i + 1, dtype=np.int64), np.zeros(0, dtype=np.uint32)
+                for node in range(i):
+                    if not np.array_equal(ca[ra[node]:ra[node + 1]], cb[rb[node]:rb[node + 1]]):
+                        changed.add(node)
+            assert changed <= set(got), (i, sorted(changed - set(got))[:8])
+    ok, why = graphs_equal(want, gi.export_graph())
+    assert ok, why
+    lib = eng._capi.load()
+    lib.hnsw_debug_tie_redone.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    red = C.c_uint64(0)
+    assert lib.hnsw_debug_tie_redone(gi._h, C.byref(red)) == 0
+    if kind == "uniform":
+        assert red.value < n // 8, red.value                                # the flagged few: the rest took the gated window
+    else:
+        assert red.value > n // 8, red.value
+    gi.close()
+    o.close()
