@@ -1180,13 +1180,24 @@ static void delete_node_from_neighbors(hnsw_oracle *o, scratch *s, uint32_t node
  * HashSet in the reference, i.e. an arbitrary node of the highest non-empty layer; the oracle
  * (and the engine) take the one with the SMALLEST ID.  Returns 0, or -1 if id is not a live node
  * ("Node: {:?} does not exist", :421).                                                         */
+static void delete_node_from_neighbors_std(hnsw_oracle *o, scratch *s, rscratch *z, uint32_t node, uint32_t lc, hnsw_oracle_counters *ct);
+static int delete_impl(hnsw_oracle *o, uint32_t id, uint32_t *touched, uint32_t touched_cap, uint32_t *n_touched, int std_heap);
 int hnsw_oracle_delete(hnsw_oracle *o, uint32_t id, uint32_t *touched, uint32_t touched_cap,
                        uint32_t *n_touched)
+{
+    return delete_impl(o, id, touched, touched_cap, n_touched, 0);
+}
+static int delete_impl(hnsw_oracle *o, uint32_t id, uint32_t *touched, uint32_t touched_cap, uint32_t *n_touched, int std_heap)
 {
     if (n_touched) *n_touched = 0;
     if (id >= o->node_count || o->dead[id]) return -1;  /* :419-422 */
     touch_reset(o);
     uint32_t top = o->nodes[id].level;                  /* :434 node.neighbors.len() rows */
+    if (std_heap) {
+        rscratch z; memset(&z, 0, sizeof z);
+        for (uint32_t lc = 0; lc <= top; lc++) delete_node_from_neighbors_std(o, &o->sc, &z, id, lc, &o->ins);
+        rscratch_free(&z);
+    } else
     for (uint32_t lc = 0; lc <= top; lc++)              /* :434-439 ascending         */
         delete_node_from_neighbors(o, &o->sc, id, lc, &o->ins);
     o->dead[id] = 1;                                    /* :419 nodes.remove, :424     */
@@ -1207,6 +1218,39 @@ int hnsw_oracle_delete(hnsw_oracle *o, uint32_t id, uint32_t *touched, uint32_t 
         o->max_layer = best >= 0 ? best_level : 0;
     }
     return 0;
+}
+
+/* HNSW.NODE.DEL in the RUST BINARY's tie order (test infrastructure): core.rs:824-863 with nconn a std BinaryHeap filled in
+ * the row's stored order (:832-844), select_neighbors / update_node_connections as insert_std runs them, the deleted node
+ * ignored (:853, :856).  Pinned against the transcription's "rust"-mode run with deletes (tests/golden/tiecase_rust_lattice_del.npz). */
+static void delete_node_from_neighbors_std(hnsw_oracle *o, scratch *s, rscratch *z, uint32_t node, uint32_t lc, hnsw_oracle_counters *ct)
+{
+    const nrow *nr = row_of(o, node, lc);
+    uint32_t cnt = nr->n;
+    uint32_t *nbrs = (uint32_t *)malloc((size_t)(cnt ? cnt : 1) * 4);
+    memcpy(nbrs, nr->ids, (size_t)cnt * 4);
+    for (uint32_t k = 0; k < cnt; k++) {                    /* :829 stored order */
+        uint32_t n = nbrs[k];
+        rheap *nconn = &z->econn;                           /* :832-844 */
+        nconn->n = 0; nconn->reverse = 0;
+        const nrow *r = row_of(o, n, lc);
+        const float *nv = vec(o, n);
+        for (uint32_t i = 0; i < r->n; i++) {
+            simpair p = { hnsw_oracle_euclidean(nv, vec(o, r->ids[i]), o->dim), r->ids[i] };
+            ct->n_dist++; ct->n_ids++;
+            rh_push(nconn, p);
+        }
+        uint32_t m_max = lc == 0 ? o->m_max0 : o->m_max;    /* :846 */
+        select_neighbors_std(o, s, z, n, nconn, m_max, lc, (int64_t)node, &z->enew, ct);    /* :853 */
+        touch_add(o, n);                                    /* :855 */
+        update_node_connections_std(o, z, n, &z->enew, nconn, lc, (int64_t)node);           /* :856 */
+    }
+    free(nbrs);
+}
+static int delete_impl(hnsw_oracle *o, uint32_t id, uint32_t *touched, uint32_t touched_cap, uint32_t *n_touched, int std_heap);
+int hnsw_oracle_delete_std_heap(hnsw_oracle *o, uint32_t id, uint32_t *touched, uint32_t touched_cap, uint32_t *n_touched)
+{
+    return delete_impl(o, id, touched, touched_cap, n_touched, 1);
 }
 
 void hnsw_oracle_last_add_ties(const hnsw_oracle *o, uint64_t out[4])

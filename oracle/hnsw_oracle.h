@@ -118,6 +118,8 @@ void hnsw_oracle_last_add_ties(const hnsw_oracle *o, uint64_t out[4]);
  * smallest id of that layer.  Returns 0, -1 if id is not a live node.                          */
 int hnsw_oracle_delete(hnsw_oracle *o, uint32_t id, uint32_t *touched, uint32_t touched_cap,
                        uint32_t *n_touched);
+/* the same in the Rust binary's own tie order (std BinaryHeap restated; hnsw_oracle_add_std_heap's counterpart) */
+int hnsw_oracle_delete_std_heap(hnsw_oracle *o, uint32_t id, uint32_t *touched, uint32_t touched_cap, uint32_t *n_touched);
 uint32_t hnsw_oracle_live_count(const hnsw_oracle *o);
 int hnsw_oracle_is_live(const hnsw_oracle *o, uint32_t id);
 

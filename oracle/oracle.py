@@ -47,6 +47,8 @@ def lib():
     L.hnsw_oracle_add.argtypes = [C.c_void_p, fp, C.c_int32, u32p, C.c_uint32, u32p]
     L.hnsw_oracle_delete.restype = C.c_int
     L.hnsw_oracle_delete.argtypes = [C.c_void_p, C.c_uint32, u32p, C.c_uint32, u32p]
+    L.hnsw_oracle_delete_std_heap.restype = C.c_int
+    L.hnsw_oracle_delete_std_heap.argtypes = [C.c_void_p, C.c_uint32, u32p, C.c_uint32, u32p]
     L.hnsw_oracle_live_count.restype = C.c_uint32
     L.hnsw_oracle_live_count.argtypes = [C.c_void_p]
     L.hnsw_oracle_is_live.restype = C.c_int
@@ -204,6 +206,16 @@ class OracleIndex:
         if rc != 0:
             raise KeyError("Node: %r does not exist" % (i,))
         assert n.value <= cap
+        return t[: n.value].copy() if want_touched else None
+
+    def delete_std_heap(self, i, want_touched=False):
+        """HNSW.NODE.DEL in the Rust binary's own tie order (sim-only comparisons on std's BinaryHeap, restated)"""
+        cap = 65536
+        t = np.empty(cap, dtype=np.uint32)
+        n = C.c_uint32(0)
+        rc = lib().hnsw_oracle_delete_std_heap(self._h, int(i), _u32p(t), cap, C.byref(n))
+        if rc != 0:
+            raise KeyError("Node: %r does not exist" % (i,))
         return t[: n.value].copy() if want_touched else None
 
     @property

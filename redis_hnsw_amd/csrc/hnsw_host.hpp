@@ -331,6 +331,7 @@ hnsw_status launch_insert_std(hnsw_index *h, uint32_t id, bool want_touched);
 hnsw_status launch_search_std(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t *d_ids, float *d_sims, uint32_t *d_nout, bool all,
                               hipStream_t st);
 hnsw_status ensure_tie_flags(hnsw_index *h, uint32_t B);
+hnsw_status launch_delete_std(hnsw_index *h, uint32_t id);
 hnsw_status std_status(hnsw_index *h, uint32_t *out);
 // hnsw_tu_occ.hip
 template <int MODE, int T>

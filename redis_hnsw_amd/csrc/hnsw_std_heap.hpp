@@ -465,6 +465,55 @@ __global__ __launch_bounds__(64) void k_insert_std_heap(GraphView g, StdScratch 
     atomicAdd(&g.hdr->ctr_insert[2], x.n_expand);
 }
 
+// HNSW.NODE.DEL in the reference binary's tie order (core.rs:414-475 -> delete_node_from_neighbors, :824-863): every neighbour
+// n of the node, layer by layer in stored order, gathers its connections in a heap (:832-844), re-selects with the node
+// ignored (:853) and is rewired (:856).  The host keeps the tombstone and re-elects the enterpoint as for any delete.
+__global__ __launch_bounds__(64) void k_delete_std_heap(GraphView g, StdScratch sc, uint32_t id, uint32_t mlinks, uint32_t *touched,
+                                                        uint32_t touched_cap)
+{
+    if (blockIdx.x != 0) return;
+    StdCtx x;
+    std_ctx_init(x, g, sc);
+    x.touched = touched; x.touched_cap = touched_cap;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t l = g.levels[id];
+    for (uint32_t lc = 0; lc <= l && !x.ovf; ++lc) {                  // :434-439
+        uint32_t dcnt;
+        const uint32_t *drow = std_row(x, id, lc, dcnt);              // not modified while it is walked (the node is ignored everywhere)
+        for (uint32_t kk = 0; kk < dcnt && !x.ovf; ++kk) {            // :829 stored order
+            const uint32_t n = drow[kk];
+            x.econn.n = 0; x.econn.reverse = 0;                       // :832-844
+            uint32_t cnt;
+            const uint32_t *er = std_row(x, n, lc, cnt);
+            const float *nv = std_vec(x, n);
+            for (uint32_t base = 0; base < cnt; base += 64u) {
+                const uint32_t nn = cnt - base < 64u ? cnt - base : 64u;
+                const bool in = lane < nn;
+                const uint32_t myid = in ? er[base + lane] : 0u;
+                const float mysim = std_sims_row(x, nv, myid, __ballot(in));
+                for (uint32_t i = 0; i < nn; ++i) {
+                    const StdPair p = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(mysim), (int)i)),
+                                       (uint32_t)__builtin_amdgcn_readlane((int)myid, (int)i)};
+                    x.n_dist += 1; x.n_ids += 1;
+                    std_push(x.econn, p, &x.ovf);
+                }
+            }
+            const uint32_t m_max = lc == 0 ? 2 * mlinks : mlinks;     // :846
+            std_select_neighbors(x, n, x.econn, m_max, lc, id, x.enew);   // :853
+            if (x.ovf) break;
+            std_touch(x, n);                                          // :855
+            std_update_node_connections(x, n, x.enew, x.econn, lc, id);   // :856
+        }
+        row_ptr(g, id, lc)[0] = 0u;                                   // the node is gone (core.rs:419)
+    }
+    *sc.epoch = x.epoch;
+    if (x.ovf) *sc.status = 1u;
+    g.hdr->n_touched = x.nt;
+    if (threadIdx.x != 0) return;
+    atomicAdd(&g.hdr->ctr_insert[0], x.n_dist);
+    atomicAdd(&g.hdr->ctr_insert[1], x.n_ids);
+}
+
 // which[0 .. *count) = the queries whose tie flag is set (all = 1: every query of the batch); any order
 __global__ void k_tie_compact(const uint32_t *flags, uint32_t B, uint32_t *which, uint32_t *count, uint32_t all)
 {

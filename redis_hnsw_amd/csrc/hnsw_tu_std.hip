@@ -60,6 +60,18 @@ hnsw_status launch_insert_std(hnsw_index *h, uint32_t id, bool want_touched)
     return HNSW_OK;
 }
 
+// one delete (every neighbour re-selected with the node ignored), on the handle's stream; the caller keeps the tombstone
+hnsw_status launch_delete_std(hnsw_index *h, uint32_t id)
+{
+    hnsw_status s = ensure_std_scratch(h);
+    if (s != HNSW_OK) return s;
+    StdScratch sc;
+    std::memcpy(&sc, &h->std_ctx0, sizeof sc);
+    hipLaunchKernelGGL(k_delete_std_heap, dim3(1), dim3(64), 0, h->stream, view(h), sc, id, h->m, h->d_touched, h->touched_cap);
+    HIP_TRY(h, hipGetLastError());
+    return HNSW_OK;
+}
+
 // tie_mode after a search launch on `st`: the queries whose tie flag the census kernel set (all = every query: tie_mode 2, or
 // a shape without a census kernel) are answered again in the reference binary's own tie order, results written over
 // d_ids / d_sims / d_nout.  Asynchronous on `st`; launches of this kind share the scratch contexts and are chained by an event.

@@ -78,3 +78,14 @@ def load_tiecase(name="tiecase_rust_lattice"):
              row_ptr=[z["row_ptr_%d" % l] for l in range(L)], col=[z["col_%d" % l] for l in range(L)], vectors=lattice(n, 1))
     return dict(n=n, dim=dim, m=m, ef=ef, k=k, Q=lattice(nq, 2), graph=g, ids=z["ids"], sim_bits=z["sim_bits"], n_out=z["n_out"],
                 accept_ties=int(z["accept_ties"]))
+
+
+def load_tiecase_del(name="tiecase_rust_lattice_del"):
+    """tests/transcription/make_rust_tie_del_golden.py: the transcription in its "rust" tie mode builds n0 nodes on lattice
+    data, deletes `victims` in that order, adds n1 more; the graph after all that"""
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    n0, n1, dim, m, ef = [int(x) for x in z["params"]]
+    L = int(z["max_layer"]) + 1
+    g = dict(levels=z["levels"].astype(np.uint32), enterpoint=int(z["enterpoint"]), max_layer=int(z["max_layer"]),
+             row_ptr=[z["row_ptr_%d" % l] for l in range(L)], col=[z["col_%d" % l] for l in range(L)])
+    return dict(n0=n0, n1=n1, dim=dim, m=m, ef=ef, V=z["V"], levels=z["levels"], victims=z["victims"], graph=g)

@@ -306,3 +306,59 @@ def test_single_adds_in_tie_mode_link_what_the_reference_binary_links(eng, oracl
         assert red.value > n // 8, red.value
     gi.close()
     o.close()
+
+
+def test_tie_mode_deletes_reproduce_the_transcription(eng):
+    """HNSW.NODE.DEL under tie_mode: delete_node_from_neighbors (core.rs:824-863) on std's BinaryHeap restated
+    (k_delete_std_heap).  The transcription's "rust"-mode run on lattice data -- 600 adds, 120 deletes (the enterpoint among
+    them), 80 more adds -- replayed through the C ABI with tie_mode = 1 (dim 8: no tie-counting plan kernel, so every insert
+    runs on the std-order kernel too) must leave the transcription's graph, row for row in stored order."""
+    from tests.golden_util import load_tiecase_del
+    c = load_tiecase_del()
+    gi = eng.Index("del-ties", c["dim"], c["m"], c["ef"])
+    gi.set_tuning("tie_mode", 1)
+    V, lv, n0 = c["V"], c["levels"], c["n0"]
+    gi.add_batch(V[:n0], levels=lv[:n0], mode="exact")
+    for v in c["victims"]:
+        gi.delete_node(gi._names[int(v)])
+    for i in range(n0, n0 + c["n1"]):
+        gi.add_node("late%d" % i, V[i], level=int(lv[i]))
+    ok, why = graphs_equal(c["graph"], gi.export_graph())
+    assert ok, why
+    gi.close()
+
+
+def test_tie_mode_adds_and_deletes_interleaved_equal_the_std_heap_oracle(eng, oracle_mod):
+    """dim 128, quantised data (distances on a coarse grid: ties at every turn), tie_mode = 1: a windowed build, then single
+    deletes and single adds interleaved; graph and touched sets against the std-heap oracle after every phase."""
+    dim, m, ef, n0, extra = 128, 12, 48, 700, 120
+    V = np.unique(np.round(make_data(n0 + extra + 64, dim, seed=44) * 2.0) / 2.0, axis=0)
+    np.random.default_rng(3).shuffle(V)
+    V = V[:n0 + extra]
+    lv = oracle_mod.draw_levels(len(V), m, 12)
+    o = oracle_mod.OracleIndex(dim, m, ef)
+    o.add_batch_std_heap(V[:n0], lv[:n0])
+    gi = eng.Index("mix-ties", dim, m, ef)
+    gi.set_tuning("tie_mode", 1)
+    gi.add_batch(V[:n0], levels=lv[:n0], mode="exact")
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    rng = np.random.default_rng(8)
+    alive = list(range(n0))
+    for j in range(extra):
+        v = alive.pop(int(rng.integers(0, len(alive))))
+        ot = o.delete_std_heap(v, want_touched=True)
+        got = []
+        gi.delete_node(gi._names[v], update_fn=lambda s, nid: got.append(nid))
+        assert sorted(got) == sorted(ot.tolist()), "touched set of delete %d" % v
+        i = n0 + j
+        o.add_batch_std_heap(V[i:i + 1], lv[i:i + 1])
+        gi.add_node("x%d" % i, V[i], level=int(lv[i]))
+        alive.append(i)
+        if j % 40 == 39:
+            ok, why = graphs_equal(o.export(), gi.export_graph())
+            assert ok, "after %d rounds: %s" % (j + 1, why)
+    ok, why = graphs_equal(o.export(), gi.export_graph())
+    assert ok, why
+    gi.close()
+    o.close()
