@@ -717,7 +717,7 @@ class Bench:
             s.engine_ties["tie_mode"] = dict(batch=s.B, ms_per_batch=round(t_mode * 1e3, 2), ms_per_batch_census_only=round(t_census * 1e3, 2),
                                              answers_changed=int((ids_total != ids_std).any(axis=1).sum()),
                                              note="one lone batch with tuning tie_mode = 1: the flagged queries are answered again as the "
-                                                  "Rust binary would (std BinaryHeap order, one lane per query)")
+                                                  "Rust binary would (std BinaryHeap order, one wavefront per query)")
         except Exception as e:                                            # a shape without a census kernel
             s.engine_ties = dict(queries=0, note="not counted: %s" % e)
         finally:
