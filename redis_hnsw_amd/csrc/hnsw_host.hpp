@@ -148,7 +148,7 @@ struct hnsw_index {
     bool select_shortcut = true;     // select_neighbors after search_level = the head of W (hnsw_insert.hpp); 0 = the full extension
     bool plan_lean = true;           // dim-128 insert plans (single adds, the windowed exact build) search with the specialised routine (hnsw_plan_lean.hpp)
     // tuning "tie_mode": 0 off; 1 an insert / a query the tie census flags is redone in the reference binary's own tie order
-    // (hnsw_std_heap.hpp: one lane, std's BinaryHeap restated); 2 EVERY insert and query runs there (tests: the port itself)
+    // (hnsw_std_heap.hpp: one wavefront per operation, std's BinaryHeap restated); 2 EVERY insert and query runs there (tests: the port itself)
     int tie_mode = 0;
     uint32_t *d_tie_flags = nullptr;  // [cap] per-query flags of the census kernel, then [4] a count, then [cap] the flagged queries
     uint32_t tie_flags_cap = 0;
@@ -326,7 +326,7 @@ uint32_t plan_lean_idbits(const hnsw_index *h, const InsertCfg &c);
 hnsw_status ensure_par(hnsw_index *h);
 size_t plan_lean_lds(int R);
 hnsw_status launch_occ_plan_lean(hnsw_index *h, const InsertCfg &c, const OccBufs &ob, uint32_t head, uint32_t count, bool *done);
-// hnsw_tu_std.hip: the reference binary's own tie order on one lane (tuning "tie_mode")
+// hnsw_tu_std.hip: the reference binary's own tie order on one wavefront per operation (tuning "tie_mode")
 hnsw_status launch_insert_std(hnsw_index *h, uint32_t id, bool want_touched);
 hnsw_status launch_search_std(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k, uint32_t *d_ids, float *d_sims, uint32_t *d_nout, bool all,
                               hipStream_t st);

@@ -156,7 +156,7 @@ def test_a_search_without_a_census_kernel_reads_as_unknown(eng, oracle_mod):
 @pytest.mark.parametrize("kind,n,dim,m,ef", [("binary", 1200, 128, 8, 48), ("binary", 700, 32, 5, 16), ("lattice", 900, 20, 6, 24),
                                              ("uniform", 800, 128, 16, 64)])
 def test_the_std_heap_kernel_builds_what_the_std_heap_oracle_builds(eng, oracle_mod, kind, n, dim, m, ef):
-    """tie_mode = 2: EVERY insert runs on the one-lane kernel that restates the reference's insert() on std's BinaryHeap
+    """tie_mode = 2: EVERY insert runs on the one-wavefront kernel that restates the reference's insert() on std's BinaryHeap
     (hnsw_std_heap.hpp) -- against hnsw_oracle_add_std_heap, which is pinned to the transcription's "rust"-mode golden.  Tie-
     heavy data (binary / lattice vectors: equal similarities at every turn, both metric orders), so the heap's sift order
     decides nearly every insert; rows must match in stored order."""
@@ -183,7 +183,7 @@ def test_the_std_heap_kernel_builds_what_the_std_heap_oracle_builds(eng, oracle_
 
 def test_tie_mode_builds_the_reference_binary_s_graph(eng, oracle_mod):
     """tie_mode = 1 on SURVEY's model shape (20 k x 128 uniform f32, M = 16, ef = 200): the windowed reference-order build,
-    with every insert the census flags -- in its plan or in the dry run of its commit -- handed UNTOUCHED to the one-lane
+    with every insert the census flags -- in its plan or in the dry run of its commit -- handed UNTOUCHED to the one-wavefront
     kernel that restates insert() on std's BinaryHeap.  The result must be the graph the transcription built in its
     "rust" tie mode (tests/golden/transcribed_20k_dim128.npz: 16 accept-test and 2 select-cut ties decided by the heap's
     sift order, after which the total order's graph differs in 3.7 % of the layer-0 rows): every row of every layer, in
@@ -209,7 +209,7 @@ def test_tie_mode_builds_the_reference_binary_s_graph(eng, oracle_mod):
                                                   ("lattice", 1500, 64, 8, 32, 1), ("uniform", 6000, 128, 16, 200, 1)])
 def test_tie_mode_answers_queries_as_the_reference_binary_does(eng, oracle_mod, kind, n, dim, m, ef, mode):
     """tie_mode on HNSW.SEARCH: the queries the census kernel flags (mode 1), or all of them (mode 2, and mode 1 on a shape
-    without a census kernel -- dim 64 here), are answered again by the one-lane kernel that restates search_knn / search_level
+    without a census kernel -- dim 64 here), are answered again by the one-wavefront kernel that restates search_knn / search_level
     on std's BinaryHeap: ids in the reference's pop order and similarities bit for bit against hnsw_oracle_search_std_heap,
     on a graph built in std order too.  On binary / lattice data nearly every query ties somewhere."""
     rng = np.random.default_rng(91)
