@@ -214,6 +214,7 @@ typedef struct {
      * different nodes -- the only places where the reference's sim-only order (core.rs:292-300) and this
      * file's (sim, id) order can part */
     uint64_t tie_stop, tie_accept, tie_select;
+    float evicted_max; int have_evicted;   /* census: the most similar entry W has evicted in this search_level */
     uint64_t tie_order;   /* equal similarities where only an ORDER is decided: inside a selection (link / shrink / append order), W's two nearest (entry point) */
 } scratch;
 
@@ -351,12 +352,14 @@ static void search_level(const hnsw_oracle *o, scratch *s, const float *query,
     heap_clear(C); heap_clear(W);
     heap_push(C, qpair);                                /* :627 */
     heap_push(W, qpair);                                /* :628 */
+    s->have_evicted = 0;
 
     while (C->n) {                                      /* :630 */
         simpair c = heap_pop(C);                        /* :631 nearest        */
         simpair f = heap_peek(W);                       /* :632 furthest       */
         if (c.sim == f.sim && c.id != f.id) s->tie_stop++;   /* census: :635 decided by something other than sim */
         if (stop_test(c, f)) break;                     /* :635 c.sim < f.sim  */
+        if (C->n && heap_peek(C).sim == c.sim) s->tie_order++;   /* census: the pop itself (:631) chose between equal candidates */
         ct->n_expand++;
         const nrow *nb = row_of(o, c.id, level);        /* :642-645            */
         for (uint32_t i = 0; i < nb->n; i++) {          /* :646 stored order   */
@@ -370,10 +373,15 @@ static void search_level(const hnsw_oracle *o, scratch *s, const float *query,
             if (accept_test(ep2, f) || W->n < ef) {     /* :657                */
                 heap_push(C, ep2);                      /* :659                */
                 heap_push(W, ep2);                      /* :660                */
-                if (W->n > ef) heap_pop(W);             /* :662-664            */
+                if (W->n > ef) {                        /* :662-664: which of two equal furthest entries goes is the heap's choice; it   */
+                    simpair out = heap_pop(W);          /* matters if the other one is still W's furthest when the search ends (census below) */
+                    if (!s->have_evicted || out.sim > s->evicted_max) { s->evicted_max = out.sim; s->have_evicted = 1; }
+                }
             }
         }
     }
+    /* census: the most similar entry W ever evicted is as similar as W's furthest now: which of the two stayed was the heap's choice */
+    if (s->have_evicted && W->n && heap_peek(W).sim == s->evicted_max) s->tie_order++;
 }
 
 /* nearest member of s->W (core.rs:670-674 rebuilds a nearest-top heap; :514,
@@ -943,11 +951,13 @@ static void search_level_std_ct(const hnsw_oracle *o, scratch *s, const float *q
     ct->n_dist++;
     C->n = W->n = res->n = 0; C->reverse = 0; W->reverse = 1; res->reverse = 0;
     rh_push(C, qpair); rh_push(W, qpair);
+    s->have_evicted = 0;
     while (C->n) {
         simpair c = rh_pop(C);
         simpair f = W->a[0];
         if (c.sim == f.sim && c.id != f.id) s->tie_stop++;
         if (c.sim < f.sim) break;                           /* :635 */
+        if (C->n && C->a[0].sim == c.sim) s->tie_order++;   /* census: the pop itself (:631) chose between equal candidates */
         ct->n_expand++;
         const nrow *nb = row_of(o, c.id, level);
         for (uint32_t i = 0; i < nb->n; i++) {
@@ -960,10 +970,14 @@ static void search_level_std_ct(const hnsw_oracle *o, scratch *s, const float *q
             if (W->n >= ef && e2.sim == f.sim) s->tie_accept++;
             if (e2.sim > f.sim || W->n < ef) {              /* :657 */
                 rh_push(C, e2); rh_push(W, e2);
-                if (W->n > ef) rh_pop(W);
+                if (W->n > ef) {
+                    simpair out = rh_pop(W);
+                    if (!s->have_evicted || out.sim > s->evicted_max) { s->evicted_max = out.sim; s->have_evicted = 1; }
+                }
             }
         }
     }
+    if (s->have_evicted && W->n && W->a[0].sim == s->evicted_max) s->tie_order++;   /* census: see search_level */
     for (uint32_t i = 0; i < W->n; i++) rh_push(res, W->a[i]);   /* :670-674 */
 }
 /* core.rs:489-599 */

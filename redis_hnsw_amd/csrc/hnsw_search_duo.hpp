@@ -191,6 +191,7 @@ __device__ __forceinline__ bool duo_keep(const GraphView &g, uint64_t *Wbuf, Duo
                 // core.rs:631 pop: the chosen candidate is in W or among these keys; ids are unique, the chosen key is
                 // unexpanded: its low word (id << 1) identifies it, adding the match sets bit 0
                 const uint32_t nlo = (uint32_t)nk;
+                if constexpr (TIES) ties[0] += tie_pop_test<R>(w, kk, take, nk, ties[1]);   // the pop itself (core.rs:631), see search_level_lean
 #pragma unroll
                 for (int r = 0; r < R; ++r) w[r] += ((uint32_t)w[r] == nlo) ? 1ull : 0ull;
                 kk += (take && (uint32_t)kk == nlo) ? 1ull : 0ull;

@@ -230,8 +230,8 @@ struct LeanW {
 // at a time (core.rs:657, e.sim == f.sim with W full) compares an ARRIVING key with the key that is W's last at that
 // moment; that key can only have moved outwards by the end of the row, so after the merge the two are neighbours in the
 // stretch from W's last slot outwards (or the arrival was rejected against the row's first threshold: counted by the
-// caller).  Counted here: arrivals with an equal neighbour there; tracked (ties[1]): the nearest key pushed out of W that
-// is still a candidate, for the stop test of the search's last pop (core.rs:635).
+// caller).  Counted here: arrivals with an equal neighbour there; tracked (ties[1]): the nearest key pushed out of W, for
+// the eviction (core.rs:662-664) and the stop test of the search's last pop (core.rs:635).
 template <int R, bool TIES = false>
 __device__ __forceinline__ uint32_t merge_apply_lean(uint64_t (&w)[R], uint64_t *Wbuf, uint32_t nW, uint32_t cap, uint64_t nk,
                                                      bool take, const uint32_t (&up)[R], uint32_t mypos, uint32_t n_new,
@@ -246,18 +246,11 @@ __device__ __forceinline__ uint32_t merge_apply_lean(uint64_t (&w)[R], uint64_t 
     lds_order();                    // one wave owns Wbuf; the LDS serves it in issue order
     if constexpr (TIES) {
         if (all >= cap) {
-            // (i) keys pushed out of W that are still candidates (unexpanded): the reference pops the nearest of them when
-            // every member of W has been expanded and stops there -- unless its similarity EQUALS W's last (core.rs:635),
-            // which the caller checks at the end against ties[1], the nearest such distance
-            if (all > cap) {
-                const bool in = (uint32_t)lane < all - cap;
-                const uint64_t ek = Wbuf[in ? cap + (uint32_t)lane : cap];
-                const uint64_t um = __ballot(in && !(ek & 1ull));
-                if (um) {
-                    const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ek >> 32), __ffsll((unsigned long long)um) - 1);
-                    ties[1] = min(ties[1], d);                          // (the stretch is sorted: the first unexpanded one is the nearest)
-                }
-            }
+            // (i) the nearest key pushed out of W (ties[1]).  If W's LAST key at the end of the search has that distance, which of
+            // the two stayed was the heap's choice: either at the eviction itself (two equal furthest entries, one goes:
+            // core.rs:662-664 -- expanded or not), or, for a key that is still a candidate, at the stop test of the last pop
+            // (core.rs:635, c.sim == f.sim).  The caller compares at the end; a pop against it is tie_pop_test's.
+            if (all > cap) ties[1] = min(ties[1], (uint32_t)(Wbuf[cap] >> 32));    // (the stretch beyond W is sorted)
             // (ii) an arriving key next to an equal one at or beyond W's last slot: the accept test it met (or set up for a
             // later arrival of the row) compared equal distances
             bool ev = false;
@@ -297,6 +290,18 @@ __device__ __forceinline__ void tie_stop_test(const uint64_t *Wbuf, uint32_t nW,
     if (nW < 2u) return;
     const uint64_t f = Wbuf[nW - 1u];
     if ((uint32_t)(f >> 32) == (uint32_t)(ckey >> 32) && (uint32_t)f >> 1 != (uint32_t)ckey >> 1) *ties += 1u;
+}
+
+// tie census, the pop (core.rs:631): 1 if another UNEXPANDED candidate -- in W (w[], bit 0 clear), among the keys accepted
+// but not merged yet (pkey / ptake), or the nearest one evicted from W (emin) -- has the chosen key's distance
+template <int R>
+__device__ __forceinline__ uint32_t tie_pop_test(const uint64_t (&w)[R], uint64_t pkey, bool ptake, uint64_t nkey, uint32_t emin)
+{
+    const uint32_t nd = (uint32_t)(nkey >> 32), nlo = (uint32_t)nkey & ~1u;
+    bool other = ptake && (uint32_t)(pkey >> 32) == nd && ((uint32_t)pkey & ~1u) != nlo;
+#pragma unroll
+    for (int r = 0; r < R; ++r) other = other || ((uint32_t)(w[r] >> 32) == nd && !(w[r] & 1ull) && (uint32_t)w[r] != nlo);
+    return (__ballot(other) != 0ull || emin == nd) ? 1u : 0u;
 }
 
 // search_level (core.rs:607-675) with W in registers; leaves w[] sorted (also copied to Wbuf) and returns |W|.
@@ -480,6 +485,10 @@ __device__ __forceinline__ uint32_t search_level_lean(const GraphView &g, uint64
         } while (c0 < cnt);
 
         if (!have_next) break;                                    // core.rs:630,635
+        // tie census, the pop itself (core.rs:631): C holds another candidate at the popped one's distance -- an unexpanded
+        // entry of W, a pending key, or the nearest one that fell out of W -- and which of the two is expanded first is the
+        // heap's choice (the other may never be: the expansion can move W's end past both)
+        if constexpr (TIES) ctr.n_tie += tie_pop_test<R>(w, pkey, ptake, nkey, ctr.tie_emin);
         // mark the chosen entry expanded (core.rs:631 pop).  Ids are unique in W and among the pending keys, and the
         // chosen key is unexpanded: its low word (id << 1) identifies it, and adding the match sets bit 0
         {

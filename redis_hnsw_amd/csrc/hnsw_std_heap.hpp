@@ -20,9 +20,13 @@ struct StdPair { float sim; uint32_t id; };
 // entries [0, lcap) -- the levels every sift passes through -- live in LDS (at g_std_lds + lo), the rest in HBM
 struct StdHeap { StdPair *a; uint32_t lo, n, cap, lcap; int reverse; };   // reverse: BinaryHeap<Reverse<SimPair>> (pops the smallest sim)
 
-// LDS entries of the ten heaps (C, W, res, w, wd, ccopy, nbrs, econn, enew, t): 6 912 x 8 B = 54 KB
-constexpr uint32_t kStdLdsTotal = 2048 + 512 + 512 + 2048 + 512 + 512 + 64 + 128 + 64 + 512;
-__shared__ StdPair g_std_lds[kStdLdsTotal];
+// LDS entries of the ten heaps (C, W, res, w, wd, ccopy, nbrs, econn, enew, t): 13 056 x 8 B = 102 KB of dynamic LDS.  w --
+// select_neighbors' working heap: the candidates and every fresh neighbour of theirs, ~3 000 entries after a layer-0 search
+// with ef 200 -- is the one that must not spill: a push into its HBM part is a memory round trip, 15 of them per row
+constexpr uint32_t kStdLdsW = 8192;
+constexpr uint32_t kStdLdsTotal = 2048 + 512 + 512 + kStdLdsW + 512 + 512 + 64 + 128 + 64 + 512;
+constexpr size_t kStdLdsBytes = (size_t)kStdLdsTotal * 8;
+extern __shared__ StdPair g_std_lds[];
 __device__ __forceinline__ StdPair std_get(const StdHeap &h, uint32_t i)
 {
     if (i < h.lcap) return g_std_lds[h.lo + i];
@@ -44,41 +48,100 @@ struct StdScratch {
 };
 
 __device__ __forceinline__ bool std_le(const StdHeap &h, float x, float y) { return h.reverse ? y <= x : x <= y; }
-__device__ __forceinline__ uint32_t std_sift_up(StdHeap &h, uint32_t start, uint32_t pos)
+// The sifts below are std's (library/alloc/src/collections/binary_heap: sift_up, sift_down_to_bottom) with their dependent
+// steps taken side by side: WHICH elements are compared and in which order they move is std's, so the array after a push / pop
+// is the array std leaves; only the waiting is different -- the ancestors of a hole (sift_up) and the greater-child choice
+// of every inner node (sift_down_to_bottom) are independent of the element being sifted, so the lanes fetch them at once.
+//
+// sift_up(0, pos) of element e already stored at pos: e climbs while it is not <= its parent.  Lane k holds the k-th
+// ancestor's parent; the first k whose parent stops e is where e lands; the parents below it move down one step each.
+__device__ __forceinline__ void std_sift_up(StdHeap &h, uint32_t pos, StdPair e)
 {
-    const StdPair e = std_get(h, pos);
-    while (pos > start) {
-        const uint32_t parent = (pos - 1) / 2;
-        if (std_le(h, e.sim, std_get(h, parent).sim)) break;                 // hole.element() <= hole.get(parent)
-        std_set(h, pos, std_get(h, parent));
-        pos = parent;
-    }
-    std_set(h, pos, e);
-    return pos;
+    if (pos == 0u) { std_set(h, 0u, e); return; }
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t depth = 31u - (uint32_t)__builtin_clz(pos + 1u);          // ancestors above pos: A[k] = ((pos + 1) >> k) - 1, k = 1 .. depth
+    const uint32_t sh = lane < 30u ? lane : 30u;                               // (depth <= 21: the lanes beyond it idle)
+    const uint32_t mine = ((pos + 1u) >> sh) - 1u;                             // A[lane]        (lane <= depth)
+    const uint32_t par = ((pos + 1u) >> (sh + 1u)) - 1u;                       // A[lane + 1]    (lane <  depth)
+    const bool in = lane < depth;
+    StdPair u = {0.f, 0u};
+    if (in) u = std_get(h, par);
+    const uint64_t stop = __ballot(in && std_le(h, e.sim, u.sim));            // hole.element() <= hole.get(parent): break
+    const uint32_t t = stop ? (uint32_t)__ffsll((unsigned long long)stop) - 1u : depth;
+    if (lane < t) std_set(h, mine, u);                                         // the parents e passed move down
+    const uint32_t land = ((pos + 1u) >> t) - 1u;
+    std_set(h, land, e);
 }
 __device__ __forceinline__ void std_push(StdHeap &h, StdPair x, uint32_t *status)
 {
     if (h.n >= h.cap) { *status = 1u; return; }
-    std_set(h, h.n++, x);
-    std_sift_up(h, 0, h.n - 1);
+    h.n += 1;
+    std_sift_up(h, h.n - 1u, x);
+}
+// pop of a heap whose array is in LDS and has at most 257 entries (W, the selections, the small working heaps): one pass for
+// the greater child of every inner node, the path to the bottom followed in registers, one pass for the elements on it
+__device__ __forceinline__ StdPair std_pop_small(StdHeap &h)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const StdPair last = g_std_lds[h.lo + --h.n];
+    if (h.n == 0u) return last;
+    const uint32_t end = h.n;
+    const StdPair top = g_std_lds[h.lo];
+    // greater child of inner node i (the right one when equal: `if hole.get(child) <= hole.get(child + 1) { child += 1 }`);
+    // a node with a left child only (child == end - 1) goes there; 0 = a leaf.  Node 0's children are read with `last`
+    // already standing at the root -- the root is never a child, so nothing changes for them.
+    uint32_t ch[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint32_t i = (uint32_t)r * 64u + lane, c = 2u * i + 1u;
+        uint32_t pick = 0u;
+        if (c + 1u < end) {
+            const float a = g_std_lds[h.lo + c].sim, b = g_std_lds[h.lo + c + 1u].sim;
+            pick = std_le(h, a, b) ? c + 1u : c;
+        } else if (c < end) pick = c;
+        ch[r] = pick;
+    }
+    // the path 0 = P[0] -> P[1] -> ... -> P[len] (a leaf); lane k keeps P[k] and P[k + 1]
+    uint32_t pk = 0u, pk1 = 0u, pos = 0u, len = 0u;
+    for (;;) {
+        const uint32_t c = pos < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)ch[0], (int)pos)
+                                     : (pos < 128u ? (uint32_t)__builtin_amdgcn_readlane((int)ch[1], (int)(pos - 64u)) : 0u);
+        if (c == 0u) break;
+        if (lane == len) { pk = pos; pk1 = c; }
+        pos = c;
+        len += 1u;
+    }
+    // sift_down_to_bottom moves old a[P[k + 1]] to P[k] for every k < len and leaves the hole at P[len]; sift_up then lifts
+    // `last` from there while it is not <= its parent -- the parents it meets are exactly those moved elements, bottom first
+    const bool in = lane < len;
+    StdPair v = {0.f, 0u};
+    if (in) v = g_std_lds[h.lo + pk1];
+    const uint64_t stop = __ballot(in && std_le(h, last.sim, v.sim));          // at P[k + 1], parent (now at P[k]) stops it
+    const int s_ = stop ? 63 - __builtin_clzll((unsigned long long)stop) : -1;  // the deepest one is met first
+    if (in && (int)lane <= s_) g_std_lds[h.lo + pk] = v;                       // (the elements below it are back where they were)
+    const uint32_t land = s_ < 0 ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)pk1, s_);
+    g_std_lds[h.lo + land] = last;
+    return top;
 }
 __device__ __forceinline__ StdPair std_pop(StdHeap &h)
 {
+    if (h.n <= 257u && h.n <= h.lcap) return std_pop_small(h);
     StdPair item = std_get(h, --h.n);
     if (h.n) {
-        const StdPair t = std_get(h, 0); std_set(h, 0, item); item = t;
+        const StdPair t = std_get(h, 0); item = t;
+        const StdPair e = std_get(h, h.n);                                // (the former last element: sifted from the root)
         const uint32_t end = h.n;
         uint32_t pos = 0, child = 1;
-        const StdPair e = std_get(h, 0);
         while (end >= 2 && child <= end - 2) {                        // sift_down_to_bottom
-            if (std_le(h, std_get(h, child).sim, std_get(h, child + 1).sim)) child++;
-            std_set(h, pos, std_get(h, child));
+            const StdPair a = std_get(h, child), b = std_get(h, child + 1);
+            const bool right = std_le(h, a.sim, b.sim);
+            std_set(h, pos, right ? b : a);
+            child += right ? 1u : 0u;
             pos = child;
             child = 2 * pos + 1;
         }
         if (child == end - 1) { std_set(h, pos, std_get(h, child)); pos = child; }
-        std_set(h, pos, e);
-        std_sift_up(h, 0, pos);
+        std_sift_up(h, pos, e);
     }
     return item;
 }
@@ -133,7 +196,17 @@ struct StdCtx {
     unsigned long long n_dist, n_ids, n_expand;
     uint32_t ovf;                 // a heap overflowed (written to sc.status when the operation ends)
     uint32_t *touched, touched_cap, nt;
+#ifdef HNSW_STD_PROF
+    unsigned long long tp[8], t0;
+#endif
 };
+#ifdef HNSW_STD_PROF
+#define STD_T0(x) (x).t0 = __builtin_amdgcn_s_memrealtime()
+#define STD_MARK(x, i) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); (x).tp[i] += n_ - (x).t0; (x).t0 = n_; } while (0)
+#else
+#define STD_T0(x)
+#define STD_MARK(x, i)
+#endif
 __device__ __forceinline__ void std_ctx_init(StdCtx &x, const GraphView &g, const StdScratch &sc)
 {
     x.g = g; x.sc = sc;
@@ -143,7 +216,7 @@ __device__ __forceinline__ void std_ctx_init(StdCtx &x, const GraphView &g, cons
         h.a = sc.heaps + (size_t)slot * sc.hcap; h.n = 0; h.cap = sc.hcap; h.reverse = 0;
         h.lo = off; h.lcap = lcap; off += lcap; slot += 1;
     };
-    init(x.C, 2048); init(x.W, 512); init(x.res, 512); init(x.w, 2048); init(x.wd, 512);
+    init(x.C, 2048); init(x.W, 512); init(x.res, 512); init(x.w, kStdLdsW); init(x.wd, 512);
     init(x.ccopy, 512); init(x.nbrs, 64); init(x.econn, 128); init(x.enew, 64); init(x.t, 512);
     x.epoch = *sc.epoch;
     x.n_dist = x.n_ids = x.n_expand = 0;
@@ -171,27 +244,48 @@ __device__ __forceinline__ float std_sims_row(const StdCtx &x, const float *a, u
     float mine = 0.f;
     if (dim % 32u == 0u) {
         const uint32_t s = lane & 31u, half = lane >> 5;
+        constexpr int U = 4;                                          // pairs per pass: 8 vectors' loads in flight (the pass is one memory round trip)
         while (mask) {
-            const uint32_t b0 = (uint32_t)__ffsll((unsigned long long)mask) - 1u;
-            mask &= mask - 1;
-            uint32_t b1 = b0;
-            if (mask) { b1 = (uint32_t)__ffsll((unsigned long long)mask) - 1u; mask &= mask - 1; }
-            const uint32_t id0 = (uint32_t)__builtin_amdgcn_readlane((int)myid, (int)b0), id1 = (uint32_t)__builtin_amdgcn_readlane((int)myid, (int)b1);
-            const float *b = x.g.vec + (size_t)(half ? id1 : id0) * dim;
-            float e = 0.f;
-            for (uint32_t i = 0; i < dim; i += 32) {
-                const float d = __fsub_rn(a[i + s], b[i + s]);
-                e = __fmaf_rn(d, d, e);
+            uint32_t bb[U][2];
+            const float *bp[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                // (a pass that runs out of entries repeats its last one: same bits, written to the same lane again)
+                uint32_t b0 = u ? bb[u - 1][1] : 0u, b1;
+                if (mask) { b0 = (uint32_t)__ffsll((unsigned long long)mask) - 1u; mask &= mask - 1; }
+                b1 = b0;
+                if (mask) { b1 = (uint32_t)__ffsll((unsigned long long)mask) - 1u; mask &= mask - 1; }
+                bb[u][0] = b0; bb[u][1] = b1;
+                const uint32_t id0 = (uint32_t)__builtin_amdgcn_readlane((int)myid, (int)b0), id1 = (uint32_t)__builtin_amdgcn_readlane((int)myid, (int)b1);
+                bp[u] = x.g.vec + (size_t)(half ? id1 : id0) * dim + s;
             }
-            e = __fadd_rn(e, __shfl_xor(e, 8));
-            e = __fadd_rn(e, __shfl_xor(e, 16));
-            e = __fadd_rn(e, __shfl_xor(e, 4));
-            e = __fadd_rn(e, __shfl_xor(e, 1));
-            e = __fadd_rn(e, __shfl_xor(e, 2));
-            const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), 0));
-            const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), 32));
-            if (lane == b0) mine = -r0;
-            if (lane == b1) mine = -r1;
+            float e[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) e[u] = 0.f;
+            for (uint32_t i = 0; i < dim; i += 32) {
+                const float av = a[i + s];
+                float bv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) bv[u] = bp[u][i];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float d = __fsub_rn(av, bv[u]);
+                    e[u] = __fmaf_rn(d, d, e[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float t = e[u];
+                t = __fadd_rn(t, __shfl_xor(t, 8));
+                t = __fadd_rn(t, __shfl_xor(t, 16));
+                t = __fadd_rn(t, __shfl_xor(t, 4));
+                t = __fadd_rn(t, __shfl_xor(t, 1));
+                t = __fadd_rn(t, __shfl_xor(t, 2));
+                const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 0));
+                const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 32));
+                if (lane == bb[u][0]) mine = -r0;
+                if (lane == bb[u][1]) mine = -r1;
+            }
         }
     } else {
         while (mask) {
@@ -300,6 +394,54 @@ __device__ __forceinline__ void std_search_level(StdCtx &x, const float *query, 
     for (uint32_t i = 0; i < x.W.n; ++i) std_push(x.res, std_get(x.W, i), &x.ovf);   // :670-674: into_iter order, pushed one by one
 }
 
+// core.rs:724-754, the part of select_neighbors after the candidates' neighbourhood is gathered in w.  As written it is a
+// sort: w pops nearest first; r takes the first element and then refuses everything (`e.sim > r.peek().sim` cannot hold for
+// what pops later), so the loop DRAINS w into wd -- ~3 000 pops after a layer-0 search with ef 200 -- and the second loop pops
+// wd back until r holds m.  Pushed in descending order neither heap sifts anything: r's array is the pop order.  Which
+// elements pop first is the heaps' business only among EQUAL similarities; when the m nearest eligible entries of w and the
+// one after them are pairwise different, r = those m, nearest first, whatever the heaps do.  That case is answered here by m
+// rounds of "the largest similarity below the previous one, and it occurs once" over w's array (all lanes, LDS); a
+// repeated similarity returns false with nothing touched, and the loops below decide as std decides.
+__device__ __forceinline__ bool std_select_distinct(StdCtx &x, uint32_t query, uint32_t ignored, uint32_t m, StdHeap &r)
+{
+    const StdHeap &w = x.w;
+    if (m < 2u || w.n > w.lcap || m > r.lcap) return false;
+    const uint32_t lane = threadIdx.x & 63u;
+    float prev = 0.f;
+    uint32_t found = 0;
+    while (found < m) {
+        float best = 0.f;
+        uint32_t bid = kEmpty, nbest = 0;                             // nbest: entries of this lane's share at `best`
+        for (uint32_t i = lane; i < w.n; i += 64u) {
+            const StdPair p = g_std_lds[w.lo + i];
+            if (p.id == query || p.id == ignored || (found && !(p.sim < prev))) continue;
+            if (!nbest || p.sim > best) { best = p.sim; bid = p.id; nbest = 1u; }
+            else if (p.sim == best) nbest += 1u;
+        }
+        const uint64_t have = __ballot(nbest != 0u);
+        if (!have) break;                                             // fewer than m eligible entries
+        float wmax = best;
+        bool any = nbest != 0u;
+        for (int d = 32; d >= 1; d >>= 1) {
+            const float o = __shfl_xor(wmax, d);
+            const bool oa = __shfl_xor((int)any, d) != 0;
+            if (oa && (!any || o > wmax)) wmax = o;
+            any = any || oa;
+        }
+        const uint64_t at = __ballot(nbest != 0u && best == wmax);
+        uint32_t total = (nbest != 0u && best == wmax) ? nbest : 0u;
+        for (int d = 32; d >= 1; d >>= 1) total += (uint32_t)__shfl_xor((int)total, d);
+        if (__builtin_amdgcn_readfirstlane(total) != 1u) return false;    // a repeated similarity: the heaps decide
+        const int wl = __ffsll((unsigned long long)at) - 1;
+        const StdPair win = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(wmax), wl)), (uint32_t)__builtin_amdgcn_readlane((int)bid, wl)};
+        g_std_lds[r.lo + found] = win;
+        found += 1u;
+        prev = win.sim;
+    }
+    r.n = found; r.reverse = 0;
+    return true;
+}
+
 // core.rs:677-757 (extend_candidates = keep_pruned_connections = true at every call site); result in r
 __device__ __forceinline__ void std_select_neighbors(StdCtx &x, uint32_t query, const StdHeap &c, uint32_t m, uint32_t lc, uint32_t ignored, StdHeap &r)
 {
@@ -334,6 +476,7 @@ __device__ __forceinline__ void std_select_neighbors(StdCtx &x, uint32_t query, 
         }
         if (x.ovf) return;
     }
+    if (std_select_distinct(x, query, ignored, m, r)) return;         // :724-754 when no similarity among the selected (or at the cut) repeats
     while (x.w.n && r.n < m) {                                        // :724-738
         const StdPair e = std_pop(x.w);
         if (e.id == query || e.id == ignored) continue;
@@ -406,15 +549,20 @@ __device__ __forceinline__ void std_insert(StdCtx &x, uint32_t query, uint32_t m
     }
     const uint32_t top = l_max < l ? l_max : l;
     for (uint32_t lcc = top + 1; lcc-- > 0;) {                        // :523
+        STD_T0(x);
         std_search_level(x, qv, ep, ef, lcc);                         // :524
         if (x.ovf) return;
+        STD_MARK(x, 0);
         std_select_neighbors(x, query, x.res, mlinks, lcc, kEmpty, x.nbrs);   // :525-531
         if (x.ovf) return;
+        STD_MARK(x, 1);
         std_clone(x.t, x.nbrs, &x.ovf);                          // :532 connect_neighbors (:759-774)
         while (x.t.n) { const StdPair n = std_pop(x.t); std_add_neighbor(x, query, lcc, n.id); std_add_neighbor(x, n.id, lcc, query); }
         for (uint32_t i = 0; i < x.nbrs.n; ++i) std_touch(x, std_get(x.nbrs, i).id);   // :535-537
         const uint32_t ep_next = std_get(x.res, 0).id;                       // :576 w.peek() (res is not touched below)
+        STD_MARK(x, 2);
         while (x.nbrs.n) {                                            // :540
+            STD_T0(x);
             const StdPair e = std_pop(x.nbrs);
             x.econn.n = 0; x.econn.reverse = 0;                       // :544-558
             uint32_t cnt;
@@ -434,10 +582,13 @@ __device__ __forceinline__ void std_insert(StdCtx &x, uint32_t query, uint32_t m
                 }
             }
             const uint32_t m_max = lcc == 0 ? 2 * mlinks : mlinks;    // :560
+            STD_MARK(x, 3);
             if (x.econn.n > m_max) {                                  // :561
                 std_select_neighbors(x, e.id, x.econn, m_max, lcc, kEmpty, x.enew);   // :568
                 if (x.ovf) return;
+                STD_MARK(x, 4);
                 std_update_node_connections(x, e.id, x.enew, x.econn, lcc, kEmpty);  // :569
+                STD_MARK(x, 5);
             }
             if (x.ovf) return;
         }
@@ -455,7 +606,15 @@ __global__ __launch_bounds__(64) void k_insert_std_heap(GraphView g, StdScratch 
     StdCtx x;
     std_ctx_init(x, g, sc);
     x.touched = touched; x.touched_cap = touched_cap;
+#ifdef HNSW_STD_PROF
+    for (int i = 0; i < 8; ++i) x.tp[i] = 0;
+#endif
     std_insert(x, id, mlinks, ef);
+#ifdef HNSW_STD_PROF
+    if (threadIdx.x == 0)
+        printf("STDPROF id %u search %llu select %llu connect %llu econn %llu shr_select %llu shr_update %llu dist %llu\n", id, x.tp[0], x.tp[1], x.tp[2],
+               x.tp[3], x.tp[4], x.tp[5], x.n_dist);
+#endif
     *sc.epoch = x.epoch;
     if (x.ovf) *sc.status = 1u;
     if (touched) g.hdr->n_touched = x.nt;

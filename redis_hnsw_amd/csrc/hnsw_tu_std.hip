@@ -5,6 +5,7 @@
 #include "hnsw_host.hpp"
 #include "hnsw_std_heap.hpp"
 #include <cstring>
+#include <mutex>
 
 namespace hnsw_host {
 
@@ -15,6 +16,17 @@ constexpr uint32_t kStdSearchCtx = 32;    // queries answered side by side (one 
 
 hnsw_status ensure_std_scratch(hnsw_index *h)
 {
+    {   // the kernels' heaps take 102 KB of dynamic LDS
+        static std::mutex mu;
+        static bool attr_set[16] = {false};
+        std::lock_guard<std::mutex> lock(mu);
+        if (!attr_set[h->device & 15]) {
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_std_heap), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStdLdsBytes));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_delete_std_heap), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStdLdsBytes));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_std_heap), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStdLdsBytes));
+            attr_set[h->device & 15] = true;
+        }
+    }
     const uint32_t hcap_ins = std::min<uint32_t>(std::max(h->cap, 4096u), 1u << 21) + 1024u;
     const uint32_t hcap_q = std::min<uint32_t>(std::max(h->cap, 4096u), 1u << 17) + 1024u;
     if (h->d_std_stamp && h->std_cap >= h->cap && h->std_hcap >= hcap_ins) return HNSW_OK;
@@ -54,7 +66,7 @@ hnsw_status launch_insert_std(hnsw_index *h, uint32_t id, bool want_touched)
     if (s != HNSW_OK) return s;
     StdScratch sc;
     std::memcpy(&sc, &h->std_ctx0, sizeof sc);
-    hipLaunchKernelGGL(k_insert_std_heap, dim3(1), dim3(64), 0, h->stream, view(h), sc, id, h->m, h->efc, want_touched ? h->d_touched : nullptr,
+    hipLaunchKernelGGL(k_insert_std_heap, dim3(1), dim3(64), kStdLdsBytes, h->stream, view(h), sc, id, h->m, h->efc, want_touched ? h->d_touched : nullptr,
                        want_touched ? h->touched_cap : 0u);
     HIP_TRY(h, hipGetLastError());
     return HNSW_OK;
@@ -67,7 +79,7 @@ hnsw_status launch_delete_std(hnsw_index *h, uint32_t id)
     if (s != HNSW_OK) return s;
     StdScratch sc;
     std::memcpy(&sc, &h->std_ctx0, sizeof sc);
-    hipLaunchKernelGGL(k_delete_std_heap, dim3(1), dim3(64), 0, h->stream, view(h), sc, id, h->m, h->d_touched, h->touched_cap);
+    hipLaunchKernelGGL(k_delete_std_heap, dim3(1), dim3(64), kStdLdsBytes, h->stream, view(h), sc, id, h->m, h->d_touched, h->touched_cap);
     HIP_TRY(h, hipGetLastError());
     return HNSW_OK;
 }
@@ -87,7 +99,7 @@ hnsw_status launch_search_std(hnsw_index *h, const float *dQ, uint32_t B, uint32
     HIP_TRY(h, hipMemsetAsync(reinterpret_cast<uint32_t *>(h->d_std_misc) + 1 + kStdSearchCtx, 0, 4, st));    // (an insert reads its own at once)
     hipLaunchKernelGGL(k_tie_compact, dim3((B + 255) / 256), dim3(256), 0, st, h->d_tie_flags, B, which, count, all ? 1u : 0u);
     const StdScratch *ctx = reinterpret_cast<const StdScratch *>(h->d_std_ctx) + 1;
-    hipLaunchKernelGGL(k_search_std_heap, dim3(kStdSearchCtx), dim3(64), 0, st, view(h), ctx, dQ, which, count, k, h->efc, d_ids, d_sims, d_nout);
+    hipLaunchKernelGGL(k_search_std_heap, dim3(kStdSearchCtx), dim3(64), kStdLdsBytes, st, view(h), ctx, dQ, which, count, k, h->efc, d_ids, d_sims, d_nout);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->std_ev, st));
     h->std_ev_valid = true;

@@ -2,6 +2,7 @@
 single adds, deletes and searches through the C ABI against the oracle's std-heap operations (hnsw_oracle_add_std_heap /
 delete_std_heap / search_std_heap -- the Rust binary's own tie order).  Graphs row for row in stored order, answers bit for bit.
 usage: python scripts/fuzz_ties.py [seconds] [first_seed]"""
+import os
 import sys
 import time
 import traceback
@@ -37,6 +38,8 @@ def run(seed):
     m = int(rng.choice([3, 5, 8, 12, 16, 24]))
     ef = int(rng.choice([max(m, 4), 24, 64, 200]))
     mode = int(rng.choice([1, 1, 1, 2]))
+    if os.environ.get("FUZZ_TIE_MODE"):                                     # (reproduction aid: the same case under the other mode)
+        mode = int(os.environ["FUZZ_TIE_MODE"])
     n0 = int(rng.choice([60, 300, 900]))
     V = data(kind, n0 + 200, dim, rng)
     n0 = min(n0, max(len(V) - 60, 8))
@@ -78,6 +81,12 @@ def run(seed):
                 ids, sims, n_out = gi.search_batch(Q, k)
                 for i, q in enumerate(Q):
                     oids, osims = o.search_std_heap(q, k)
+                    if not (n_out[i] == len(oids) and np.array_equal(ids[i, :len(oids)], oids)) and os.environ.get("FUZZ_TIE_DIAG"):
+                        tids, tsims = o.search(q, k)
+                        gi.reset_counters()
+                        one = gi.search_batch(q[None, :], k)
+                        print("DIAG k", k, "std", oids, osims, "total", tids, "engine", ids[i], "alone", one[0][0], "oracle census", o.tie_census(q[None, :], k),
+                              "engine counters", gi.tie_counters(), flush=True)
                     assert n_out[i] == len(oids) and np.array_equal(ids[i, :len(oids)], oids), "op %d: query %d" % (op, i)
                     assert np.array_equal(sims[i, :len(oids)].view(np.uint32), np.asarray(osims, dtype=np.float32).view(np.uint32))
             if op % 15 == 14:
@@ -94,6 +103,13 @@ def run(seed):
 if __name__ == "__main__":
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7000
+    if len(sys.argv) > 3:                                                   # explicit seeds: python scripts/fuzz_ties.py 0 0 9035 9069
+        for sd in sys.argv[3:]:
+            try:
+                print("ok", run(int(sd)), flush=True)
+            except Exception as e:
+                print("FAIL seed", sd, type(e).__name__, str(e).split("\n")[0][:200], flush=True)
+        sys.exit(0)
     t0 = time.time()
     done = bad = 0
     while time.time() - t0 < budget:
