@@ -289,7 +289,9 @@ hnsw_status hnsw_reset_counters(hnsw_index *h);
  * the smaller id.  The two can only part where a DECISION compared equal distances of two different nodes: the stop
  * test (core.rs:635), the accept test with W full (:657), a select_neighbors cut (:733, :741-754), equal distances
  * among the k + 1 nearest of an answer -- or where an ORDER is decided between equal distances: inside a selection (which
- * neighbour is linked / shrunk / appended first, :540-541, :765-772, :790-796) and W's two nearest (the next entry point).  The kernels count every such comparison they make -- a superset of the
+ * neighbour is linked / shrunk / appended first, :540-541, :765-772, :790-796), W's two nearest (the next entry point),
+ * the pop of :631 when another candidate is as similar as the popped one, and the eviction of :662-664 when W's furthest
+ * entry at the end of a search is as similar as one that was pushed out.  The kernels count every such comparison they make -- a superset of the
  * reference's own (a whole adjacency row is merged at once where the reference walks it id by id), never fewer:
  *   out[0] events in searches      (only while tuning "tie_census" = 1: the census form of the dim-128 search kernel,
  *          f32 rows, ef_construction <= 256; if a search of the period ran on another kernel while the tuning was on,
