@@ -261,7 +261,8 @@ hnsw_status hnsw_deserialize(const void *buf, uint64_t bytes, uint64_t seed, int
  *             implies tie_census; a single hnsw_add is gated the same way (one-node window, its commit dry-run first);
  *             shapes other than dim-128 f32 rows: every insert runs there; 2: every insert / query runs there (tests);
  *             every hnsw_delete in tie mode runs there too (core.rs:824-863 on the same heap); a heap overflow of
- *             those kernels is HNSW_ERR_CAPACITY),
+ *             those kernels is HNSW_ERR_CAPACITY; f32 rows only: a search on a compress_bf16 / compress_fp8 index
+ *             under tie_mode is HNSW_ERR_INVALID),
  *             "grid_stride", "query_in_lds", "time_launches",
  *             "lds_buckets" / "lds_hash_bits" / "tag_table" / "tag_bb" / "idbits" / "grid" (tests)
  *   build     "occ_window" (slots of the exact parallel insert, 0 = serial), "occ_min_batch",

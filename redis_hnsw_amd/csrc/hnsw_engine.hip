@@ -503,6 +503,7 @@ hnsw_status launch_search(hnsw_index *h, const float *dQ, uint32_t B, uint32_t k
                           float *d_sims, uint32_t *d_nout, hipStream_t st)
 {
     if (!h->tie_mode) return launch_search_kernels(h, dQ, B, k, d_ids, d_sims, d_nout, st);
+    if (h->fmt) return fail(h, HNSW_ERR_INVALID, "tie_mode serves f32 rows only (a bf16 / fp8 index keeps no f32 vectors: there is no reference arithmetic to reproduce)");
     hnsw_status s = ensure_tie_flags(h, B);
     if (s != HNSW_OK) return s;
     const bool was = h->tie_uncounted;

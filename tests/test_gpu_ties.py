@@ -362,3 +362,21 @@ def test_tie_mode_adds_and_deletes_interleaved_equal_the_std_heap_oracle(eng, or
     assert ok, why
     gi.close()
     o.close()
+
+
+def test_tie_mode_refuses_a_compressed_index(eng, oracle_mod):
+    """bf16 / fp8 storage modes keep no f32 vectors: the std-order kernels have nothing to compute the reference's similarities
+    from, and a search under tie_mode says so instead of answering from the wrong bytes"""
+    n, dim, m, ef = 600, 128, 8, 40
+    V = make_data(n, dim, seed=71)
+    gi = eng.Index("fmt-ties", dim, m, ef)
+    gi.add_batch(V, levels=oracle_mod.draw_levels(n, m, 3), mode="exact")
+    gi.set_tuning("compress_bf16", 1)
+    gi.search_batch(V[:8], 5)                                               # the compressed walk, as ever
+    gi.set_tuning("tie_mode", 1)
+    with pytest.raises(Exception) as e:
+        gi.search_batch(V[:8], 5)
+    assert "tie_mode" in str(e.value)
+    gi.set_tuning("tie_mode", 0)
+    gi.search_batch(V[:8], 5)
+    gi.close()
